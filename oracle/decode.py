@@ -1,0 +1,885 @@
+"""Restatement of the reference's Swift host logic for the decode path - test infrastructure only.
+
+Each function cites the reference file:line (relative to /root/reference/Sources/WhisperKit) it
+follows.  Arithmetic notes where this restatement knowingly differs from an arm64 run of the
+reference (and why that cannot be pinned here) are marked NOTE(parity).
+
+NOTE(parity) logits: the reference receives logits as Float16 from CoreML (Core/Models.swift:1041)
+and runs the timestamp log-softmax in Float16 on arm64 (Core/Text/LogitsFilter.swift:152-237).
+The oracle keeps logits in float32/float64; the product does the same (DESIGN.md "numerics").
+NOTE(parity) sampling at T>0 uses the unseeded system RNG in the reference
+(Core/Text/TokenSampler.swift:61,169); oracle and product share a seeded counter-based
+generator (`uniform01`) so that T>0 decoding is reproducible.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import zlib
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+SAMPLE_RATE = 16000            # WhisperKit.sampleRate       (Core/WhisperKit.swift:38)
+SECONDS_PER_TIME_TOKEN = 0.02  # WhisperKit.secondsPerTimeToken (Core/WhisperKit.swift:40)
+WINDOW_SAMPLES = 480000        # Constants.defaultWindowSamples (Core/Models.swift:1457)
+MAX_TOKEN_CONTEXT = 448 // 2   # Constants.maxTokenContext    (Core/Models.swift:1334)
+NEG_INF = -np.inf
+
+
+# ----------------------------------------------------------------------------- types
+@dataclasses.dataclass(frozen=True)
+class SpecialTokens:
+    """Core/Models.swift:1111-1149."""
+    endToken: int = 50257
+    englishToken: int = 50259
+    noSpeechToken: int = 50362
+    noTimestampsToken: int = 50363
+    specialTokenBegin: int = 50257
+    startOfPreviousToken: int = 50361
+    startOfTranscriptToken: int = 50258
+    timeTokenBegin: int = 50364
+    transcribeToken: int = 50359
+    translateToken: int = 50358
+    whitespaceToken: int = 220
+
+
+def special_tokens_for_vocab(n_vocab: int) -> Tuple[SpecialTokens, List[int]]:
+    """Token ids of the three Whisper vocabularies (openai/whisper tokenizer.py special-token order:
+    eot, sot, languages, translate, transcribe, startoflm, startofprev, nospeech, notimestamps, <|0.00|>...).
+    Multilingual defaults equal Core/Models.swift:1309-1322.  Returns (SpecialTokens, language token ids)."""
+    if n_vocab == 51864:      # *.en (gpt2 vocab): eot 50256; language slots exist but only <|en|> is meaningful
+        eot, n_lang = 50256, 99
+    elif n_vocab == 51865:
+        eot, n_lang = 50257, 99
+    elif n_vocab == 51866:    # large-v3 (+ <|yue|>)
+        eot, n_lang = 50257, 100
+    else:
+        raise ValueError(f"unknown Whisper vocabulary size {n_vocab}")
+    sot = eot + 1
+    lang0 = sot + 1
+    translate = lang0 + n_lang
+    st = SpecialTokens(endToken=eot, englishToken=lang0, noSpeechToken=translate + 4,
+                       noTimestampsToken=translate + 5, specialTokenBegin=eot,
+                       startOfPreviousToken=translate + 3, startOfTranscriptToken=sot,
+                       timeTokenBegin=translate + 6, transcribeToken=translate + 1,
+                       translateToken=translate, whitespaceToken=220)
+    assert st.timeTokenBegin + 1501 == n_vocab
+    return st, list(range(lang0, lang0 + n_lang))
+
+
+@dataclasses.dataclass
+class DecodingOptions:
+    """Core/Configurations.swift:155-247 (same names, same defaults)."""
+    verbose: bool = False
+    task: str = "transcribe"
+    language: Optional[str] = None
+    temperature: float = 0.0
+    temperatureIncrementOnFallback: float = 0.2
+    temperatureFallbackCount: int = 5
+    sampleLength: int = MAX_TOKEN_CONTEXT
+    topK: int = 5
+    usePrefillPrompt: bool = True
+    detectLanguage: Optional[bool] = None
+    skipSpecialTokens: bool = False
+    withoutTimestamps: bool = False
+    wordTimestamps: bool = False
+    maxInitialTimestamp: Optional[float] = None
+    maxWindowSeek: Optional[int] = None
+    clipTimestamps: List[float] = dataclasses.field(default_factory=list)
+    windowClipTime: float = 1.0
+    promptTokens: Optional[List[int]] = None
+    prefixTokens: Optional[List[int]] = None
+    suppressBlank: bool = False
+    suppressTokens: List[int] = dataclasses.field(default_factory=list)
+    compressionRatioThreshold: Optional[float] = 2.4
+    logProbThreshold: Optional[float] = -1.0
+    firstTokenLogProbThreshold: Optional[float] = -1.5
+    noSpeechThreshold: Optional[float] = 0.6
+    concurrentWorkerCount: int = 4
+    chunkingStrategy: Optional[str] = None
+
+    def __post_init__(self):
+        if self.detectLanguage is None:   # Configurations.swift:222
+            self.detectLanguage = not self.usePrefillPrompt
+
+    def prepareSeekClips(self, contentFrames: int) -> List[Tuple[int, int]]:
+        """Utilities/Extensions+Internal.swift:112-130."""
+        seek_points = [int(_swift_round(np.float32(t) * np.float32(SAMPLE_RATE))) for t in self.clipTimestamps]
+        if len(seek_points) == 0:
+            seek_points.append(0)
+        if len(seek_points) % 2 == 1:
+            seek_points.append(contentFrames)
+        clips = []
+        for i in range(0, len(seek_points), 2):
+            start = seek_points[i]
+            end = seek_points[i + 1] if i + 1 < len(seek_points) else contentFrames
+            clips.append((start, end))
+        return clips
+
+
+def _swift_round(x: float) -> float:
+    """Swift `round()` = schoolbook rounding (half away from zero)."""
+    return math.floor(abs(x) + 0.5) * (1 if x >= 0 else -1)
+
+
+def _rounded(x: float, places: int) -> float:
+    """Float.rounded(_ places:) (ArgmaxCore FloatType helpers): round(x * 10^p) / 10^p in Float."""
+    m = np.float32(10.0 ** places)
+    return float(np.float32(_swift_round(float(np.float32(x) * m))) / m)
+
+
+@dataclasses.dataclass
+class DecodingFallback:
+    needsFallback: bool
+    fallbackReason: str
+
+
+def decoding_fallback(options: DecodingOptions, isFirstTokenLogProbTooLow: bool, noSpeechProb: float,
+                      compressionRatio: float, avgLogProb: float) -> Optional[DecodingFallback]:
+    """Core/Models.swift:357-381 - NOTE: order matters."""
+    if isFirstTokenLogProbTooLow:
+        return DecodingFallback(True, "firstTokenLogProbThreshold")
+    if options.noSpeechThreshold is not None and noSpeechProb > options.noSpeechThreshold:
+        return DecodingFallback(False, "silence")
+    if options.compressionRatioThreshold is not None and compressionRatio > options.compressionRatioThreshold:
+        return DecodingFallback(True, "compressionRatioThreshold")
+    if options.logProbThreshold is not None and avgLogProb < options.logProbThreshold:
+        return DecodingFallback(True, "logProbThreshold")
+    return None
+
+
+@dataclasses.dataclass
+class DecodingResult:
+    """Core/Models.swift:383-439 (text omitted unless a tokenizer is supplied)."""
+    language: str
+    tokens: List[int]
+    tokenLogProbs: List[Dict[int, float]]
+    avgLogProb: float
+    noSpeechProb: float
+    temperature: float
+    compressionRatio: float
+    fallback: Optional[DecodingFallback]
+    alignment: Optional[np.ndarray] = None   # DecodingCache.alignmentWeights [224, 1500]
+    text: str = ""
+    languageProbs: Dict[str, float] = dataclasses.field(default_factory=dict)
+    isFirstTokenLogProbTooLow: bool = False
+    steps: int = 0
+
+
+@dataclasses.dataclass
+class WordTiming:
+    word: str
+    tokens: List[int]
+    start: float
+    end: float
+    probability: float
+
+    @property
+    def duration(self) -> float:
+        return float(np.float32(self.end) - np.float32(self.start))
+
+
+@dataclasses.dataclass
+class TranscriptionSegment:
+    """Core/Models.swift TranscriptionSegment."""
+    id: int
+    seek: int
+    start: float
+    end: float
+    text: str
+    tokens: List[int]
+    tokenLogProbs: List[Dict[int, float]]
+    temperature: float
+    avgLogprob: float
+    compressionRatio: float
+    noSpeechProb: float
+    words: Optional[List[WordTiming]] = None
+
+
+# ----------------------------------------------------------------------------- compression ratio
+def compression_ratio(tokens: Sequence[int]) -> float:
+    """Utilities/TextUtilities.swift:14-30: len(int32 bytes) / len(NSData.compressed(using: .zlib)).
+    Apple's `.zlib` is a raw DEFLATE stream (RFC 1951, no zlib header) at level 5.
+    NOTE(parity): Apple's encoder is not bit-identical to zlib's; sizes can differ by a few bytes.
+    Empty input: NSData.compressed throws on empty data -> +inf (TextUtilities.swift:26-29)."""
+    data = np.asarray(list(tokens), dtype="<i4").tobytes()
+    if len(data) == 0:
+        return float("inf")
+    c = zlib.compressobj(5, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    return float(np.float32(len(data)) / np.float32(len(comp)))
+
+
+# ----------------------------------------------------------------------------- logits filters
+class SuppressTokensFilter:
+    """Core/Text/LogitsFilter.swift:12-25."""
+    def __init__(self, suppressTokens: Sequence[int]):
+        self.suppressTokens = list(suppressTokens)
+
+    def filterLogits(self, logits: np.ndarray, tokens: Sequence[int]) -> np.ndarray:
+        for t in self.suppressTokens:
+            logits[t] = NEG_INF
+        return logits
+
+
+class SuppressBlankFilter:
+    """Core/Text/LogitsFilter.swift:27-51."""
+    def __init__(self, specialTokens: SpecialTokens, sampleBegin: int):
+        self.specialTokens, self.sampleBegin = specialTokens, sampleBegin
+
+    def filterLogits(self, logits, tokens):
+        if len(tokens) != self.sampleBegin:
+            return logits
+        logits[self.specialTokens.whitespaceToken] = NEG_INF
+        logits[self.specialTokens.endToken] = NEG_INF
+        return logits
+
+
+class TimestampRulesFilter:
+    """Core/Text/LogitsFilter.swift:54-243."""
+    def __init__(self, specialTokens: SpecialTokens, sampleBegin: int, maxInitialTimestampIndex: Optional[int],
+                 isModelMultilingual: bool):
+        self.specialTokens, self.sampleBegin = specialTokens, sampleBegin
+        self.maxInitialTimestampIndex, self.isModelMultilingual = maxInitialTimestampIndex, isModelMultilingual
+
+    def _sampleBegin(self, tokens) -> Optional[int]:       # :131-142
+        st = self.specialTokens
+        if self.isModelMultilingual:
+            for i, t in enumerate(tokens[:3]):
+                if t == st.transcribeToken or t == st.translateToken:
+                    return max(i + 1, self.sampleBegin)
+            return None
+        return self.sampleBegin
+
+    def filterLogits(self, logits, tokens):
+        st = self.specialTokens
+        sb = self._sampleBegin(tokens)
+        if sb is None or not (sb <= len(tokens)):
+            return logits
+        logits[st.noTimestampsToken] = NEG_INF                                   # :81
+        if len(tokens) > sb:                                                      # :83-110
+            sampled = list(tokens[sb:])
+            lastWasTimestamp = len(sampled) >= 1 and sampled[-1] >= st.timeTokenBegin
+            penultimateWasTimestamp = len(sampled) < 2 or sampled[-2] >= st.timeTokenBegin
+            if lastWasTimestamp:
+                if penultimateWasTimestamp:
+                    logits[st.timeTokenBegin:] = NEG_INF
+                else:
+                    logits[: st.endToken] = NEG_INF
+            timestamps = [t for t in sampled if t >= st.timeTokenBegin]
+            if timestamps:
+                last = timestamps[-1]
+                timestampLast = last if (lastWasTimestamp and not penultimateWasTimestamp) else last + 1
+                logits[st.timeTokenBegin: timestampLast] = NEG_INF
+        # :112-122 initial-timestamp rule is commented out in the reference - restated as absent.
+        if self._sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, st.timeTokenBegin):   # :125
+            logits[: st.timeTokenBegin] = NEG_INF
+        return logits
+
+    @staticmethod
+    def _sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, timeTokenBegin) -> bool:
+        """:144-242  logsumexp(logprobs[tb:]) > max(logprobs[:tb]); the log-softmax normaliser is common
+        to both sides, so it is evaluated on the logits directly (float64)."""
+        x = np.asarray(logits, dtype=np.float64)
+        ts, tx = x[timeTokenBegin:], x[:timeTokenBegin]
+        mts = ts.max() if ts.size else NEG_INF
+        if not np.isfinite(mts):
+            return False if mts == NEG_INF else True
+        timestampLogProb = mts + math.log(float(np.exp(ts - mts).sum()))
+        maxText = tx.max() if tx.size else NEG_INF
+        return bool(timestampLogProb > maxText)
+
+
+class LanguageLogitsFilter:
+    """Core/Text/LogitsFilter.swift:245-276."""
+    def __init__(self, allLanguageTokens: Sequence[int], logitsDim: int, sampleBegin: int):
+        self.allLanguageTokens, self.logitsDim, self.sampleBegin = set(allLanguageTokens), logitsDim, sampleBegin
+
+    def filterLogits(self, logits, tokens):
+        if not (len(tokens) >= self.sampleBegin):
+            return logits
+        keep = np.zeros(self.logitsDim, dtype=bool)
+        keep[list(self.allLanguageTokens)] = True
+        logits[~keep] = NEG_INF
+        return logits
+
+
+def create_logits_filters(options: DecodingOptions, prefilledIndex: int, initialPromptIndex: int,
+                          st: SpecialTokens, isModelMultilingual: bool, custom=()):
+    """Core/TextDecoder.swift:857-899 (order: custom, SuppressBlank, SuppressTokens, TimestampRules)."""
+    fs = list(custom)
+    if options.suppressBlank:
+        fs.append(SuppressBlankFilter(st, sampleBegin=prefilledIndex))
+    if len(options.suppressTokens) > 0:
+        fs.append(SuppressTokensFilter([t for t in options.suppressTokens if t < st.specialTokenBegin]))
+    if not options.withoutTimestamps:
+        mi = None
+        if options.maxInitialTimestamp is not None:
+            mi = int(np.float32(options.maxInitialTimestamp) / np.float32(SECONDS_PER_TIME_TOKEN))
+        fs.append(TimestampRulesFilter(st, sampleBegin=initialPromptIndex, maxInitialTimestampIndex=mi,
+                                       isModelMultilingual=isModelMultilingual))
+    return fs
+
+
+# ----------------------------------------------------------------------------- sampler
+def uniform01(seed: int, counter: int) -> float:
+    """Counter-based uniform in [0,1): splitmix64(seed + counter * golden) top 24 bits.
+    Shared (by specification, not by code) with the HIP sampler kernel."""
+    M = (1 << 64) - 1
+    z = (seed + (counter + 1) * 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    return (z >> 40) * (1.0 / (1 << 24))
+
+
+class GreedyTokenSampler:
+    """Core/Text/TokenSampler.swift:29-252.  T == 0: argmax + log softmax; T != 0: softmax(logits / T),
+    top-k, multinomial over the k (BNNS path :140-180)."""
+    def __init__(self, temperature: float, eotToken: int, decodingOptions: DecodingOptions, seed: int = 0):
+        self.temperature = float(np.float16(temperature))   # FloatType on arm64
+        self.eotToken, self.decodingOptions, self.seed = eotToken, decodingOptions, seed
+
+    def sample(self, logits: np.ndarray, counter: int = 0) -> Tuple[int, float]:
+        x = np.asarray(logits, dtype=np.float64)
+        if self.temperature != 0.0:
+            x = x * float(np.float32(1.0) / np.float32(self.temperature))     # :116-121 alpha = Float(1/temperature)
+        m = x.max()
+        lse = m + math.log(float(np.exp(x - m).sum()))
+        if self.temperature != 0.0:
+            k = self.decodingOptions.topK
+            order = np.argsort(-x, kind="stable")[:k]                         # top-k, descending, ties -> lower id
+            probs = np.exp(x[order] - lse)
+            total = float(probs.sum())
+            rnd = uniform01(self.seed, counter) * total                       # Float.random(in: 0..<sum)
+            acc, chosen = 0.0, 0
+            for i in range(len(order)):
+                acc += float(probs[i])
+                if rnd < acc:
+                    chosen = i
+                    break
+            tok = int(order[chosen])
+        else:
+            tok = int(np.argmax(x))                                           # first maximum
+        return tok, float(x[tok] - lse)
+
+    def update(self, tokens: List[int], logits: np.ndarray, logProbs: List[float], counter: int = 0):
+        tok, lp = self.sample(logits, counter)
+        return tokens + [tok], logProbs + [lp], tok == self.eotToken          # :215-240
+
+    def finalize(self, tokens: List[int], logProbs: List[float]):             # :242-251
+        t, l = list(tokens), list(logProbs)
+        if not t or t[-1] != self.eotToken:
+            t.append(self.eotToken)
+            l.append(0.0)
+        return t, l
+
+
+# ----------------------------------------------------------------------------- prompt
+def prefill_prompt(options: Optional[DecodingOptions], st: SpecialTokens, isModelMultilingual: bool,
+                   languageToken: Optional[int] = None) -> List[int]:
+    """Core/TextDecoder.swift:163-216.  `languageToken`: id of "<|{options.language ?? en}|>" resolved by the
+    caller's tokenizer; falls back to englishToken like the reference (:184)."""
+    prefill = [st.startOfTranscriptToken]
+    if options is not None:
+        if isModelMultilingual:
+            prefill.append(languageToken if languageToken is not None else st.englishToken)
+            prefill.append(st.translateToken if options.task == "translate" else st.transcribeToken)
+        prefill.append(st.noTimestampsToken if options.withoutTimestamps else st.timeTokenBegin)
+        if options.promptTokens is not None:
+            maxPromptLen = (MAX_TOKEN_CONTEXT // 2) - 1
+            trimmed = [t for t in options.promptTokens[-maxPromptLen:] if t < st.specialTokenBegin]
+            prefill = [st.startOfPreviousToken] + trimmed + prefill
+        if options.prefixTokens is not None:
+            trimmedPrefix = [t for t in options.prefixTokens[-(MAX_TOKEN_CONTEXT // 2):] if t < st.specialTokenBegin]
+            prefill += trimmedPrefix
+    return prefill
+
+
+# ----------------------------------------------------------------------------- decodeText
+StepFn = Callable[[int, int], np.ndarray]    # (token, cacheLength/tokenIndex) -> logits[V]  (float32)
+
+
+def decode_text(step: StepFn, initialPrompt: List[int], sampler: GreedyTokenSampler, options: DecodingOptions,
+                st: SpecialTokens, isModelMultilingual: bool, languageTokens: Sequence[int] = (),
+                prefilledIndex: int = 0, custom_filters=(), alignment: Optional[np.ndarray] = None,
+                record_logits: Optional[list] = None) -> DecodingResult:
+    """Core/TextDecoder.swift:541-855."""
+    initialPromptIndex = len(initialPrompt)
+    currentTokens = list(initialPrompt)
+    nextToken = initialPrompt[-1]
+    logProbs = [0.0] * len(currentTokens)
+    filters = create_logits_filters(options, prefilledIndex, initialPromptIndex, st, isModelMultilingual, custom_filters)
+    loopCount = min(options.sampleLength, MAX_TOKEN_CONTEXT - 1)
+    isFirstTokenLogProbTooLow = False
+    steps = 0
+    for tokenIndex in range(prefilledIndex, loopCount):
+        isPrefill = tokenIndex < initialPromptIndex - 1
+        isLastPrefillToken = tokenIndex == initialPromptIndex - 1
+        isFirstToken = tokenIndex == prefilledIndex
+        if tokenIndex < initialPromptIndex:                                                    # :581-594
+            isTimestampToken = currentTokens[tokenIndex] >= st.timeTokenBegin
+            modelPredictedTimestamp = nextToken >= st.timeTokenBegin
+            if not (isLastPrefillToken and isTimestampToken and modelPredictedTimestamp):
+                nextToken = currentTokens[tokenIndex]
+            else:
+                currentTokens[tokenIndex] = nextToken
+        logits = np.array(step(nextToken, tokenIndex), dtype=np.float32, copy=True)             # :616
+        steps += 1
+        if record_logits is not None:
+            record_logits.append((tokenIndex, nextToken, logits.copy()))
+        for f in filters:                                                                       # :641-643
+            logits = f.filterLogits(logits, currentTokens)
+        tok, lp = sampler.sample(logits, counter=tokenIndex)                                     # :652
+        nextToken, nextTokenLogProb = tok, lp
+        completed = tok == sampler.eotToken
+        isFirstTokenLogProbTooLow = bool(isFirstToken and options.firstTokenLogProbThreshold is not None
+                                         and nextTokenLogProb < options.firstTokenLogProbThreshold)   # :662-667
+        isSegmentCompleted = completed or len(currentTokens) >= MAX_TOKEN_CONTEXT - 1 or isFirstTokenLogProbTooLow
+        if isSegmentCompleted:
+            break
+        if not isPrefill:                                                                       # :682-686
+            currentTokens.append(nextToken)
+            logProbs.append(nextTokenLogProb)
+    segmentTokens, segmentLogProbs = sampler.finalize(currentTokens, logProbs)                   # :776
+    startIndex = segmentTokens.index(st.startOfTranscriptToken) if st.startOfTranscriptToken in segmentTokens else 0
+    endIndex = segmentTokens.index(st.endToken) if st.endToken in segmentTokens else len(segmentTokens)
+    filteredTokens = segmentTokens[startIndex: endIndex + 1]
+    filteredLogProbs = segmentLogProbs[startIndex: endIndex + 1]
+    s = np.float32(0)
+    for v in filteredLogProbs:
+        s = np.float32(s + np.float32(v))
+    avgLogProbs = float(s / np.float32(len(filteredLogProbs)))
+    tokenProbs = [{t: float(np.float32(l))} for t, l in zip(filteredTokens, filteredLogProbs)]
+    wordTokens = [t for t in filteredTokens if t < st.specialTokenBegin]
+    finalCompressionRatio = compression_ratio(wordTokens)
+    temperature = _rounded(float(np.float16(sampler.temperature)), 3)                            # :796-800
+    noSpeechProb = 0.0                                                                           # :802 (TODO in reference)
+    language = options.language or "en"
+    if options.language is None:                                                                 # :807-822
+        language = "en"
+        for t in filteredTokens:
+            if t in set(languageTokens):
+                language = f"<lang:{t}>"     # text needs a tokenizer; ids are the parity target
+                break
+    fallback = decoding_fallback(options, isFirstTokenLogProbTooLow, noSpeechProb, finalCompressionRatio, avgLogProbs)
+    return DecodingResult(language=language, tokens=filteredTokens, tokenLogProbs=tokenProbs, avgLogProb=avgLogProbs,
+                          noSpeechProb=noSpeechProb, temperature=temperature, compressionRatio=finalCompressionRatio,
+                          fallback=fallback, alignment=alignment, isFirstTokenLogProbTooLow=isFirstTokenLogProbTooLow,
+                          steps=steps)
+
+
+def detect_language(step: StepFn, sampler: GreedyTokenSampler, st: SpecialTokens, languageTokens: Sequence[int],
+                    logitsSize: int) -> Tuple[int, float]:
+    """Core/TextDecoder.swift:420-539: one step on SOT at position 0, LanguageLogitsFilter, sample.
+    Returns (language token id, logprob)."""
+    currentTokens = [st.startOfTranscriptToken]
+    logits = np.array(step(currentTokens[0], 0), dtype=np.float32, copy=True)
+    logits = LanguageLogitsFilter(languageTokens, logitsSize, sampleBegin=0).filterLogits(logits, currentTokens)
+    tok, lp = sampler.sample(logits, counter=0)
+    return tok, lp
+
+
+def fallback_temperatures(options: DecodingOptions) -> List[float]:
+    """Core/TranscribeTask.swift:327 - built in FloatType (Float16 on arm64)."""
+    t0, inc = np.float16(options.temperature), np.float16(options.temperatureIncrementOnFallback)
+    return [float(np.float16(t0 + np.float16(i) * inc)) for i in range(options.temperatureFallbackCount + 1)]
+
+
+# ----------------------------------------------------------------------------- segments
+def find_seek_point_and_segments(res: DecodingResult, options: DecodingOptions, allSegmentsCount: int,
+                                 currentSeek: int, segmentSize: int, st: SpecialTokens,
+                                 decode_fn: Optional[Callable[[List[int]], str]] = None,
+                                 sampleRate: int = SAMPLE_RATE):
+    """Core/Text/SegmentSeeker.swift:41-189."""
+    timeToken = st.timeTokenBegin
+    decode_fn = decode_fn or (lambda toks: "")
+    seek = currentSeek
+    f32 = np.float32
+    timeOffset = f32(seek) / f32(sampleRate)
+    spt = f32(SECONDS_PER_TIME_TOKEN)
+    if options.noSpeechThreshold is not None:
+        shouldSkip = res.noSpeechProb > options.noSpeechThreshold
+        if options.logProbThreshold is not None and res.avgLogProb > options.logProbThreshold:
+            shouldSkip = False
+        if shouldSkip:
+            return seek + segmentSize, None
+    segs: List[TranscriptionSegment] = []
+    cur, curLP = res.tokens, res.tokenLogProbs
+    isTs = [t >= timeToken for t in cur]
+    last3 = isTs[-3:]
+    singleTimestampEnding = last3 == [False, True, False]
+    noTimestampEnding = last3 == [False, False, False]
+    sliceIndexes = []
+    prev = False
+    for i, c in enumerate(isTs):
+        if prev and c:
+            sliceIndexes.append(i)
+        prev = c
+
+    def mk(tokens, lps, start, end):
+        wordTokens = [t for t in tokens if t < st.specialTokenBegin]
+        text = decode_fn(wordTokens if options.skipSpecialTokens else tokens)
+        return TranscriptionSegment(id=allSegmentsCount + len(segs), seek=seek0, start=float(start), end=float(end),
+                                    text=text, tokens=list(tokens), tokenLogProbs=list(lps), temperature=res.temperature,
+                                    avgLogprob=res.avgLogProb, compressionRatio=res.compressionRatio,
+                                    noSpeechProb=res.noSpeechProb)
+
+    seek0 = seek
+    if sliceIndexes:
+        if singleTimestampEnding:
+            sliceIndexes.append(max(i for i, c in enumerate(isTs) if c) + 1)
+        elif noTimestampEnding:
+            sliceIndexes.append(len(cur))
+        lastSliceStart = 0
+        for currentSliceEnd in sliceIndexes:
+            sl, slp = cur[lastSliceStart:currentSliceEnd], curLP[lastSliceStart:currentSliceEnd]
+            tts = [t for t in sl if t >= timeToken]
+            startS = f32(tts[0] - timeToken) * spt
+            endS = f32(tts[-1] - timeToken) * spt
+            segs.append(mk(sl, slp, timeOffset + startS, timeOffset + endS))
+            lastSliceStart = currentSliceEnd
+        if not noTimestampEnding:
+            lastTimestampToken = cur[lastSliceStart - (1 if singleTimestampEnding else 0)] - timeToken
+            lastTimestampSeconds = f32(lastTimestampToken) * spt
+            seek += int(lastTimestampSeconds * f32(sampleRate))
+        else:
+            seek += segmentSize
+    else:
+        durationSeconds = f32(segmentSize) / f32(sampleRate)
+        tts = [t for t in cur if t > timeToken]
+        if tts:
+            durationSeconds = f32(tts[-1] - timeToken) * spt
+        segs.append(mk(cur, curLP, timeOffset, timeOffset + durationSeconds))
+        seek += segmentSize
+    return seek, segs
+
+
+# ----------------------------------------------------------------------------- DTW / word timestamps
+def dynamic_time_warping(matrix: np.ndarray) -> Tuple[List[int], List[int]]:
+    """Core/Text/SegmentSeeker.swift:195-278: DP over -matrix in Double with the reference's exact
+    tie-breaking (strict `<` for diagonal and up; otherwise left) and backtrace."""
+    m = -np.asarray(matrix, dtype=np.float64)
+    n_rows, n_cols = m.shape
+    cost = np.full((n_rows + 1, n_cols + 1), np.inf)
+    trace = np.full((n_rows + 1, n_cols + 1), -1, dtype=np.int64)
+    cost[0, 0] = 0
+    trace[0, 1:] = 2
+    trace[1:, 0] = 1
+    for r in range(1, n_rows + 1):
+        row_prev, row_cur, mv = cost[r - 1], cost[r], m[r - 1]
+        tr = trace[r]
+        for c in range(1, n_cols + 1):
+            v = mv[c - 1]
+            c0, c1, c2 = row_prev[c - 1] + v, row_prev[c] + v, row_cur[c - 1] + v
+            if c0 < c1 and c0 < c2:
+                row_cur[c], tr[c] = c0, 0
+            elif c1 < c0 and c1 < c2:
+                row_cur[c], tr[c] = c1, 1
+            else:
+                row_cur[c], tr[c] = c2, 2
+    i, j = n_rows, n_cols
+    ti, tj = [], []
+    while i > 0 or j > 0:
+        ti.append(i - 1)
+        tj.append(j - 1)
+        t = trace[i, j]
+        if t == 0:
+            i -= 1; j -= 1
+        elif t == 1:
+            i -= 1
+        elif t == 2:
+            j -= 1
+        else:
+            break
+    return ti[::-1], tj[::-1]
+
+
+def default_split_to_word_tokens(tokenIds: List[int], st: SpecialTokens):
+    """Stand-in for WhisperTokenizerWrapper.splitToWordTokens (Core/Models.swift:1226-1306) when no
+    tokenizer.json exists (none in this image): every token is its own word, text is "<id>"."""
+    return [f"<{t}>" for t in tokenIds], [[t] for t in tokenIds]
+
+
+def find_alignment(wordTokenIds: List[int], alignmentWeights: np.ndarray, tokenLogProbs: List[float],
+                   split_fn: Callable) -> List[WordTiming]:
+    """Core/Text/SegmentSeeker.swift:340-408."""
+    textIndices, timeIndices = dynamic_time_warping(alignmentWeights)
+    words, wordTokens = split_fn(wordTokenIds)
+    if len(wordTokens) <= 1:
+        return []
+    f32 = np.float32
+    spt = f32(SECONDS_PER_TIME_TOKEN)
+    startTimes, endTimes = [f32(0.0)], []
+    currentTokenIndex = textIndices[0] if textIndices else 0
+    for idx in range(len(textIndices)):
+        if textIndices[idx] != currentTokenIndex:
+            currentTokenIndex = textIndices[idx]
+            t = f32(timeIndices[idx]) * spt
+            startTimes.append(t)
+            endTimes.append(t)
+    endTimes.append(f32(timeIndices[-1] if timeIndices else 1500) * spt)
+    out = []
+    currentTokenIndex = 0
+    for index, wta in enumerate(wordTokens):
+        startIndex = currentTokenIndex
+        wordStart = startTimes[currentTokenIndex]
+        currentTokenIndex += len(wta) - 1
+        wordEnd = endTimes[currentTokenIndex]
+        currentTokenIndex += 1
+        probs = tokenLogProbs[startIndex:currentTokenIndex]
+        s = f32(0)
+        for p in probs:
+            s = f32(s + f32(p))
+        prob = s / f32(len(probs))
+        out.append(WordTiming(words[index], list(wta), float(wordStart), float(wordEnd), float(np.exp(f32(prob)))))
+    return out
+
+
+def calculate_word_duration_constraints(alignment: List[WordTiming]) -> Tuple[float, float]:
+    """Core/Text/SegmentSeeker.swift:498-507."""
+    durs = sorted(d for d in (w.duration for w in alignment) if d > 0)
+    median = durs[len(durs) // 2] if durs else 0.0
+    cm = min(np.float32(0.7), np.float32(median))
+    return float(cm), float(cm * np.float32(2))
+
+
+def truncate_long_words_at_sentence_boundaries(alignment: List[WordTiming], maxDuration: float) -> List[WordTiming]:
+    """Core/Text/SegmentSeeker.swift:509-526."""
+    marks = [".", "。", "!", "！", "?", "？"]
+    out = [dataclasses.replace(w) for w in alignment]
+    for i in range(1, len(out)):
+        if out[i].duration > maxDuration:
+            if out[i].word in marks:
+                out[i].end = float(np.float32(out[i].start) + np.float32(maxDuration))
+            elif out[i - 1].word in marks:
+                out[i].start = float(np.float32(out[i].end) - np.float32(maxDuration))
+    return out
+
+
+def merge_punctuations(alignment: List[WordTiming], prepended: str = "\"'“¡¿([{-",
+                       appended: str = "\"'.。,，!！?？:：”)]}、") -> List[WordTiming]:
+    """Core/Text/SegmentSeeker.swift:280-338 (defaults: Constants.defaultPrepend/AppendPunctuations)."""
+    if not alignment:
+        return []
+    al = [dataclasses.replace(w) for w in alignment]
+    pre: List[WordTiming] = []
+    app: List[WordTiming] = []
+    if al[0].word.strip(" \t") not in prepended or al[0].word.strip(" \t") == "":
+        # Swift `String.contains("")` is false for the empty string
+        pre.append(al[0])
+    for i in range(1, len(al)):
+        cur, prev = dataclasses.replace(al[i]), al[i - 1]
+        pw = prev.word.strip(" \t")
+        if prev.word[:1].isspace() and prev.word[:1] in " \t " and pw != "" and pw in prepended:
+            cur.word = prev.word + cur.word
+            cur.tokens = prev.tokens + cur.tokens
+            if not pre:
+                pre.append(cur)
+            else:
+                pre[-1] = cur
+        else:
+            pre.append(cur)
+    if pre:
+        app.append(pre[0])
+    for i in range(1, len(pre)):
+        cur, prev = pre[i], dataclasses.replace(pre[i - 1])
+        cw = cur.word.strip(" \t")
+        if not prev.word.endswith(" ") and cw != "" and cw in appended:
+            prev.word = prev.word + cur.word
+            prev.tokens = prev.tokens + cur.tokens
+            app[-1] = prev
+        else:
+            app.append(cur)
+    return [w for w in app if w.word != "" and not (w.word in appended) and not (w.word in prepended)]
+
+
+# ----------------------------------------------------------------------------- VAD / chunking
+def calculate_voice_activity_in_chunks(signal: np.ndarray, chunkCount: int, frameLengthSamples: int,
+                                       frameOverlapSamples: int = 0, energyThreshold: float = 0.022) -> List[bool]:
+    """Core/Audio/AudioProcessor.swift:673-702 (vDSP_rmsqv per chunk > threshold)."""
+    out = []
+    n = len(signal)
+    for i in range(chunkCount):
+        s = i * frameLengthSamples
+        e = min(s + frameLengthSamples + frameOverlapSamples, n)
+        chunk = np.asarray(signal[s:e], dtype=np.float32)
+        rms = np.float32(math.sqrt(float(np.mean(chunk.astype(np.float64) ** 2)))) if len(chunk) else np.float32(0)
+        out.append(bool(rms > np.float32(energyThreshold)))
+    return out
+
+
+class EnergyVAD:
+    """Core/Audio/EnergyVAD.swift + VoiceActivityDetector.swift."""
+    def __init__(self, sampleRate: int = SAMPLE_RATE, frameLength: float = 0.1, frameOverlap: float = 0.0,
+                 energyThreshold: float = 0.02, frameLengthSamples: Optional[int] = None,
+                 frameOverlapSamples: Optional[int] = None):
+        self.sampleRate = sampleRate
+        self.frameLengthSamples = frameLengthSamples if frameLengthSamples is not None else int(np.float32(frameLength) * np.float32(sampleRate))
+        self.frameOverlapSamples = frameOverlapSamples if frameOverlapSamples is not None else int(np.float32(frameOverlap) * np.float32(sampleRate))
+        self.energyThreshold = energyThreshold
+
+    def voiceActivity(self, waveform) -> List[bool]:
+        count = int(math.ceil(len(waveform) / self.frameLengthSamples))
+        return calculate_voice_activity_in_chunks(waveform, count, self.frameLengthSamples, self.frameOverlapSamples,
+                                                  self.energyThreshold)
+
+    def calculateActiveChunks(self, waveform) -> List[Tuple[int, int]]:
+        vad = self.voiceActivity(waveform)
+        result: List[List[int]] = []
+        cur = None
+        for i, v in enumerate(vad):
+            if v:
+                cs = i * self.frameLengthSamples
+                ce = min(cs + self.frameLengthSamples, len(waveform))
+                if cur is not None:
+                    result[-1][1] = ce
+                else:
+                    cur = cs
+                    result.append([cs, ce])
+            else:
+                cur = None
+        return [(a, b) for a, b in result]
+
+    def voiceActivityIndexToAudioSampleIndex(self, index: int) -> int:
+        return index * self.frameLengthSamples
+
+    def voiceActivityIndexToSeconds(self, index: int) -> float:
+        return float(np.float32(self.voiceActivityIndexToAudioSampleIndex(index)) / np.float32(self.sampleRate))
+
+    @staticmethod
+    def findLongestSilence(vadResult: Sequence[bool]) -> Optional[Tuple[int, int]]:
+        best, bestCount, i = None, 0, 0
+        while i < len(vadResult):
+            if vadResult[i]:
+                i += 1
+            else:
+                e = i
+                while e < len(vadResult) and not vadResult[e]:
+                    e += 1
+                if e - i > bestCount:
+                    bestCount, best = e - i, (i, e)
+                i = e
+        return best
+
+    def voiceActivityClipTimestamps(self, waveform) -> List[float]:
+        out = []
+        for s, e in self.calculateActiveChunks(waveform):
+            out += [float(np.float32(s) / np.float32(self.sampleRate)), float(np.float32(e) / np.float32(self.sampleRate))]
+        return out
+
+    def calculateNonSilentSeekClips(self, waveform) -> List[Tuple[int, int]]:
+        return DecodingOptions(clipTimestamps=self.voiceActivityClipTimestamps(waveform)).prepareSeekClips(len(waveform))
+
+
+def vad_chunk_all(audio: np.ndarray, maxChunkLength: int = WINDOW_SAMPLES, options: Optional[DecodingOptions] = None,
+                  windowPadding: int = 16000, vad: Optional[EnergyVAD] = None) -> List[Tuple[int, np.ndarray]]:
+    """Core/Audio/AudioChunker.swift:43-107 -> [(seekOffsetIndex, samples)]."""
+    vad = vad or EnergyVAD()
+    n = len(audio)
+    if n <= maxChunkLength:
+        return [(0, audio)]
+    options = options or DecodingOptions()
+    out = []
+    for clipStart, clipEnd in options.prepareSeekClips(n):
+        startIndex = clipStart
+        while startIndex < clipEnd - windowPadding:
+            if not (0 <= startIndex < n):
+                raise ValueError("startIndex is outside the buffer size")
+            endIndex = clipEnd
+            if startIndex + maxChunkLength < endIndex:
+                e = min(n, startIndex + maxChunkLength)
+                mid = startIndex + (e - startIndex) // 2
+                va = vad.voiceActivity(audio[mid:e])
+                sil = vad.findLongestSilence(va)
+                if sil is not None:
+                    silMid = sil[0] + (sil[1] - sil[0]) // 2
+                    endIndex = mid + vad.voiceActivityIndexToAudioSampleIndex(silMid)
+                else:
+                    endIndex = e
+            if not endIndex > startIndex:
+                break
+            out.append((startIndex, audio[startIndex:endIndex]))
+            startIndex = endIndex
+    return out
+
+
+# ----------------------------------------------------------------------------- TranscribeTask.run
+@dataclasses.dataclass
+class TranscriptionResult:
+    segments: List[TranscriptionSegment]
+    tokens: List[int]
+    language: str
+    windows: int = 0
+    fallbacks: int = 0
+    seeks: List[int] = dataclasses.field(default_factory=list)
+    temperatures: List[float] = dataclasses.field(default_factory=list)
+
+
+def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], st: SpecialTokens,
+                        isModelMultilingual: bool, languageTokens: Sequence[int], logitsSize: int,
+                        encode_window: Callable[[np.ndarray], object],
+                        make_step: Callable[[object], StepFn],
+                        seed: int = 0, get_alignment: Optional[Callable[[], np.ndarray]] = None,
+                        split_fn: Optional[Callable] = None) -> TranscriptionResult:
+    """Core/TranscribeTask.swift:57-296 (window loop) + :316-411 (decodeWithFallback).
+
+    encode_window(pcm[480000]) -> opaque encoder output (padOrTrim + logMel + encode, :126-151)
+    make_step(encoder_output)  -> fresh StepFn with reset decoder state (decoderInputs.reset, :271,398)
+    """
+    options = options or DecodingOptions()
+    contentFrames = len(audio)
+    allSegments: List[TranscriptionSegment] = []
+    allTokens: List[int] = []
+    detectedLanguage = None
+    prompt = [st.startOfTranscriptToken]
+    if options.usePrefillPrompt:
+        prompt = prefill_prompt(options, st, isModelMultilingual)
+    result = TranscriptionResult([], [], "en")
+    for clipStart, clipEnd in options.prepareSeekClips(contentFrames):
+        seek = clipStart
+        windowPadding = int(np.float32(options.windowClipTime) * np.float32(SAMPLE_RATE))
+        while seek < clipEnd - windowPadding:
+            segmentSize = min(WINDOW_SAMPLES, contentFrames - seek, clipEnd - seek)
+            pcm = np.zeros(WINDOW_SAMPLES, dtype=np.float32)
+            pcm[:segmentSize] = audio[seek:seek + segmentSize]
+            enc = encode_window(pcm)
+            result.seeks.append(seek)
+            # ---- decodeWithFallback
+            res = None
+            for i, temp in enumerate(fallback_temperatures(options)):
+                sampler = GreedyTokenSampler(temp, st.endToken, options, seed=seed + 1000003 * result.windows + i)
+                curOptions = options
+                step = make_step(enc)
+                if isModelMultilingual and options.language is None and options.detectLanguage:
+                    ltok, _ = detect_language(step, sampler, st, languageTokens, logitsSize)
+                    detectedLanguage = f"<lang:{ltok}>"
+                    if options.usePrefillPrompt:
+                        prompt = prefill_prompt(curOptions, st, isModelMultilingual, languageToken=ltok)
+                    step = make_step(enc)
+                res = decode_text(step, prompt, sampler, curOptions, st, isModelMultilingual, languageTokens,
+                                  alignment=None)
+                if get_alignment is not None:
+                    res.alignment = get_alignment()
+                result.temperatures.append(res.temperature)
+                if detectedLanguage is None:
+                    detectedLanguage = res.language
+                if res.fallback is not None and res.fallback.needsFallback:
+                    result.fallbacks += 1
+                else:
+                    break
+            # ---- windowing
+            previousSeek = seek
+            newSeek, cur = find_seek_point_and_segments(res, options, len(allSegments), seek, segmentSize, st)
+            seek = max(seek, newSeek)
+            if options.maxWindowSeek is not None:
+                seek = min(seek, previousSeek + options.maxWindowSeek)
+            if cur is None:
+                continue
+            allSegments += cur
+            for s in cur:
+                allTokens += s.tokens
+            result.windows += 1
+    result.segments, result.tokens, result.language = allSegments, allTokens, detectedLanguage or "en"
+    return result

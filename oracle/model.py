@@ -1,0 +1,132 @@
+"""Whisper encoder / decoder-step oracle (torch CPU fp32) - test infrastructure only.
+
+Restates openai/whisper `model.py` (AudioEncoder, TextDecoder, ResidualAttentionBlock,
+MultiHeadAttention) = transformers 5.15.0 `modeling_whisper.py:267-309,371-377,431-446,
+566-573,622-624,676-682,965-970`.  The reference executes this math inside CoreML bundles
+(Sources/WhisperKit/Core/AudioEncoder.swift:60, Core/TextDecoder.swift:406), one decoder
+call per token with an explicit KV cache (Core/TextDecoder.swift:573-717); `DecoderState.step`
+mirrors that call pattern: (token, cache_length) -> logits, and appends this step's K/V.
+
+Weights come in as a dict of openai/whisper-named float32 numpy arrays
+(`whisperkit_amd.weights.synthetic_state_dict` or a converted checkpoint).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(a) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+class OracleWhisper:
+    def __init__(self, dims, sd: Dict[str, np.ndarray], alignment_heads: Optional[Sequence[Tuple[int, int]]] = None):
+        self.dims = dims
+        self.w = {k: _t(v) for k, v in sd.items()}
+        self.alignment_heads = list(alignment_heads) if alignment_heads is not None else [
+            (l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
+
+    # ---------------------------------------------------------------- encoder
+    def _mha(self, p: str, x: torch.Tensor, xa: torch.Tensor, n_head: int, mask=None, return_qk=False):
+        w = self.w
+        q = F.linear(x, w[p + ".query.weight"], w[p + ".query.bias"])
+        k = F.linear(xa, w[p + ".key.weight"])
+        v = F.linear(xa, w[p + ".value.weight"], w[p + ".value.bias"])
+        return self._attend(p, q, k, v, n_head, mask, return_qk)
+
+    def _attend(self, p, q, k, v, n_head, mask=None, return_qk=False):
+        w = self.w
+        tq, d = q.shape
+        hd = d // n_head
+        qh = q.view(tq, n_head, hd).permute(1, 0, 2) * hd ** -0.5
+        kh = k.view(-1, n_head, hd).permute(1, 2, 0)
+        vh = v.view(-1, n_head, hd).permute(1, 0, 2)
+        qk = qh @ kh                                   # [H, tq, tk]
+        if mask is not None:
+            qk = qk + mask
+        pr = torch.softmax(qk, dim=-1)
+        o = (pr @ vh).permute(1, 0, 2).reshape(tq, d)
+        o = F.linear(o, w[p + ".out.weight"], w[p + ".out.bias"])
+        return (o, pr) if return_qk else o
+
+    def encode(self, mel: np.ndarray) -> np.ndarray:
+        """mel [n_mels, 3000] -> encoder output [1500, d] float32."""
+        w, dims = self.w, self.dims
+        with torch.no_grad():
+            x = _t(mel)[None]
+            x = F.gelu(F.conv1d(x, w["encoder.conv1.weight"], w["encoder.conv1.bias"], padding=1))
+            x = F.gelu(F.conv1d(x, w["encoder.conv2.weight"], w["encoder.conv2.bias"], stride=2, padding=1))
+            x = x[0].T + w["encoder.positional_embedding"]
+            for i in range(dims.n_audio_layer):
+                p = f"encoder.blocks.{i}"
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".attn_ln.weight"], w[p + ".attn_ln.bias"])
+                x = x + self._mha(p + ".attn", xn, xn, dims.n_audio_head)
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".mlp_ln.weight"], w[p + ".mlp_ln.bias"])
+                h = F.gelu(F.linear(xn, w[p + ".mlp.0.weight"], w[p + ".mlp.0.bias"]))
+                x = x + F.linear(h, w[p + ".mlp.2.weight"], w[p + ".mlp.2.bias"])
+            x = F.layer_norm(x, (x.shape[-1],), w["encoder.ln_post.weight"], w["encoder.ln_post.bias"])
+        return x.numpy()
+
+    # ---------------------------------------------------------------- decoder
+    def new_state(self, enc: np.ndarray) -> "DecoderState":
+        return DecoderState(self, enc)
+
+
+class DecoderState:
+    """Per-window decode state = the reference's `DecodingInputs` (Core/Models.swift:291-323):
+    self-attention key/value caches of 224 positions + the alignment matrix [224, 1500]."""
+
+    MAX_CTX = 224
+
+    def __init__(self, model: OracleWhisper, enc: np.ndarray):
+        self.m = model
+        w, dims = model.w, model.dims
+        xa = _t(enc)
+        with torch.no_grad():
+            self.cross_k = [F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.key.weight"]) for i in range(dims.n_text_layer)]
+            self.cross_v = [F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.value.weight"],
+                                     w[f"decoder.blocks.{i}.cross_attn.value.bias"]) for i in range(dims.n_text_layer)]
+        self.reset()
+
+    def reset(self):
+        dims = self.m.dims
+        d = dims.n_text_state
+        self.k = [torch.zeros(self.MAX_CTX, d) for _ in range(dims.n_text_layer)]
+        self.v = [torch.zeros(self.MAX_CTX, d) for _ in range(dims.n_text_layer)]
+        self.alignment = np.zeros((self.MAX_CTX, dims.n_audio_ctx), dtype=np.float32)
+
+    def step(self, token: int, pos: int, want_alignment: bool = True):
+        """One decoder call (TextDecoder.predictLogits + updateKVCache + updateAlignmentWeights,
+        Core/TextDecoder.swift:381-418,218-296): returns logits [V]; writes K/V at `pos` and the
+        alignment row at `pos + 1` (reference writes row tokenIndex+1)."""
+        m, w, dims = self.m, self.m.w, self.m.dims
+        nh = dims.n_text_head
+        with torch.no_grad():
+            x = (w["decoder.token_embedding.weight"][token] + w["decoder.positional_embedding"][pos])[None]
+            align_rows = []
+            for i in range(dims.n_text_layer):
+                p = f"decoder.blocks.{i}"
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".attn_ln.weight"], w[p + ".attn_ln.bias"])
+                q = F.linear(xn, w[p + ".attn.query.weight"], w[p + ".attn.query.bias"])
+                self.k[i][pos] = F.linear(xn, w[p + ".attn.key.weight"])[0]
+                self.v[i][pos] = F.linear(xn, w[p + ".attn.value.weight"], w[p + ".attn.value.bias"])[0]
+                x = x + m._attend(p + ".attn", q, self.k[i][: pos + 1], self.v[i][: pos + 1], nh)
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".cross_attn_ln.weight"], w[p + ".cross_attn_ln.bias"])
+                q = F.linear(xn, w[p + ".cross_attn.query.weight"], w[p + ".cross_attn.query.bias"])
+                o, pr = m._attend(p + ".cross_attn", q, self.cross_k[i], self.cross_v[i], nh, return_qk=True)
+                x = x + o
+                for (l, h) in m.alignment_heads:
+                    if l == i:
+                        align_rows.append(pr[h, 0])
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".mlp_ln.weight"], w[p + ".mlp_ln.bias"])
+                hdn = F.gelu(F.linear(xn, w[p + ".mlp.0.weight"], w[p + ".mlp.0.bias"]))
+                x = x + F.linear(hdn, w[p + ".mlp.2.weight"], w[p + ".mlp.2.bias"])
+            x = F.layer_norm(x, (x.shape[-1],), w["decoder.ln.weight"], w["decoder.ln.bias"])
+            logits = F.linear(x, w["decoder.token_embedding.weight"])[0]
+            if want_alignment and align_rows and pos + 1 < self.MAX_CTX:
+                self.alignment[pos + 1] = torch.stack(align_rows).mean(0).numpy()
+        return logits.numpy()

@@ -1,0 +1,82 @@
+"""Generate the committed golden fixtures under tests/golden/ (run once, in the build container).
+
+    python tests/golden/make_golden.py
+
+Sources of truth used here (none of them is available on the GPU box, hence the fixtures):
+  * /root/reference/Tests/WhisperKitTests/Resources/jfk.wav - the reference's own audio fixture, used by its
+    VAD / seek-clip known-answer tests (Tests/WhisperKitTests/UnitTests.swift:2119-2189).  Stored as PCM16.
+  * transformers 5.15.0 `WhisperFeatureExtractor` and `WhisperForConditionalGeneration` - the other public
+    implementation of the openai/whisper algorithm; the reference's own CoreML graphs/weights are not in its
+    repo so no output of the reference itself can be produced here.
+
+Outputs (all small, strided subsets of the full tensors; the stride is stored with the data):
+  jfk_pcm16.npz           int16 [176000]
+  hf_mel_jfk.npz          HF log-mel of jfk.wav, 80 and 128 bands, frames ::7
+  hf_mel_synth.npz        HF log-mel of the bench's synthetic chunk (seed 1234), frames ::7
+  hf_model_micro.npz      HF encoder output rows ::25 and decoder logits[::13] for a teacher-forced
+                          8-token sequence, `test-micro` dims, synthetic weights seed 0, mel = HF mel of jfk
+"""
+import os
+import sys
+import wave
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+from whisperkit_amd import weights as W  # noqa: E402
+from whisperkit_amd.synth import synthetic_chunk  # noqa: E402
+
+
+def main():
+    import torch
+    from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperForConditionalGeneration
+
+    w = wave.open("/root/reference/Tests/WhisperKitTests/Resources/jfk.wav")
+    assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+    pcm16 = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    np.savez_compressed(os.path.join(HERE, "jfk_pcm16.npz"), pcm16=pcm16)
+    jfk = pcm16.astype(np.float32) / 32768.0
+
+    out = {"stride": np.int32(7)}
+    for nm in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=nm)
+        out[f"mel{nm}"] = fe(jfk, sampling_rate=16000, return_tensors="np")["input_features"][0][:, ::7].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "hf_mel_jfk.npz"), **out)
+
+    syn = synthetic_chunk(1234)
+    out = {"stride": np.int32(7)}
+    for nm in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=nm)
+        out[f"mel{nm}"] = fe(syn, sampling_rate=16000, return_tensors="np")["input_features"][0][:, ::7].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "hf_mel_synth.npz"), **out)
+
+    dims = W.MODEL_DIMS["test-micro"]
+    sd = W.synthetic_state_dict(dims, seed=0)
+    cfg = WhisperConfig(vocab_size=dims.n_vocab, num_mel_bins=dims.n_mels, d_model=dims.n_audio_state,
+                        encoder_layers=dims.n_audio_layer, encoder_attention_heads=dims.n_audio_head,
+                        decoder_layers=dims.n_text_layer, decoder_attention_heads=dims.n_text_head,
+                        encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
+                        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
+                        activation_function="gelu", scale_embedding=False, dropout=0.0, attention_dropout=0.0,
+                        activation_dropout=0.0, pad_token_id=50256, bos_token_id=50257, eos_token_id=50256,
+                        decoder_start_token_id=50257)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    missing, unexpected = model.load_state_dict(W.to_hf_state_dict(sd), strict=False)
+    assert not unexpected, unexpected
+    assert all("embed_positions" in m or "proj_out" in m for m in missing), missing
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    mel = fe(jfk, sampling_rate=16000, return_tensors="pt")["input_features"]
+    tokens = [50257, 50362, 464, 1282, 50363, 2, 50400, 50400]   # arbitrary teacher-forced ids incl. timestamps
+    with torch.no_grad():
+        enc = model.model.encoder(mel).last_hidden_state
+        logits = model(input_features=mel, decoder_input_ids=torch.tensor([tokens])).logits[0]
+    np.savez_compressed(os.path.join(HERE, "hf_model_micro.npz"), tokens=np.array(tokens, np.int32),
+                        enc_stride=np.int32(25), enc=enc[0, ::25].numpy().astype(np.float32),
+                        logit_stride=np.int32(13), logits=logits[:, ::13].numpy().astype(np.float32))
+    print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+if __name__ == "__main__":
+    main()

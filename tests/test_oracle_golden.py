@@ -1,0 +1,72 @@
+"""Pin the oracle's model math against the committed HF-transformers golden vectors
+(tests/golden/make_golden.py wrote them in the build container).  CPU only."""
+import numpy as np
+
+from conftest import golden
+from oracle import mel as omel
+from oracle.model import OracleWhisper
+from whisperkit_amd import weights as W
+from whisperkit_amd.synth import synthetic_chunk
+
+# HF computes the log-mel in float32 after a float64 STFT; the oracle is float64 throughout.
+MEL_TOL = 1e-4
+
+
+def test_mel_matches_hf_on_jfk(jfk_pcm):
+    g = golden("hf_mel_jfk.npz")
+    s = int(g["stride"])
+    for nm in (80, 128):
+        mine = omel.log_mel_spectrogram(jfk_pcm, nm)
+        assert mine.shape == (nm, 3000)          # reference shape pin: UnitTests.swift:676-693 ([1,80,1,3000])
+        np.testing.assert_allclose(mine[:, ::s], g[f"mel{nm}"], atol=MEL_TOL, rtol=0)
+
+
+def test_mel_matches_hf_on_synthetic_chunk():
+    g = golden("hf_mel_synth.npz")
+    s = int(g["stride"])
+    x = synthetic_chunk(1234)
+    for nm in (80, 128):
+        np.testing.assert_allclose(omel.log_mel_spectrogram(x, nm)[:, ::s], g[f"mel{nm}"], atol=MEL_TOL, rtol=0)
+
+
+def test_mel_edge_cases():
+    # empty / short / over-long inputs are zero-padded or trimmed to 480000 (AudioProcessor.swift:151-174)
+    z = omel.log_mel_spectrogram(np.zeros(0, np.float32), 80)
+    assert z.shape == (80, 3000) and np.allclose(z, (np.log10(1e-10) + 4) / 4)
+    x = synthetic_chunk(7, n=500000)
+    a = omel.log_mel_spectrogram(x, 80)
+    b = omel.log_mel_spectrogram(x[:480000], 80)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_encoder_decoder_match_hf(jfk_pcm):
+    g = golden("hf_model_micro.npz")
+    dims = W.MODEL_DIMS["test-micro"]
+    sd = W.synthetic_state_dict(dims, seed=0)
+    m = OracleWhisper(dims, sd)
+    mel = omel.log_mel_spectrogram(jfk_pcm, dims.n_mels).astype(np.float32)
+    enc = m.encode(mel)
+    assert enc.shape == (1500, dims.n_audio_state)   # UnitTests.swift:721-732 pins [1,384,1,1500] for tiny
+    np.testing.assert_allclose(enc[::int(g["enc_stride"])], g["enc"], atol=2e-4, rtol=0)
+    stt = m.new_state(enc)
+    ls = int(g["logit_stride"])
+    for pos, tok in enumerate(g["tokens"]):
+        logits = stt.step(int(tok), pos)
+        assert logits.shape == (dims.n_vocab,)
+        np.testing.assert_allclose(logits[::ls], g["logits"][pos], atol=2e-4, rtol=0)
+
+
+def test_weight_blob_roundtrip():
+    dims = W.MODEL_DIMS["test-micro"]
+    sd = W.synthetic_state_dict(dims, seed=0)
+    blob = W.pack_blob(dims, sd)
+    d2, t = W.unpack_blob(blob)
+    assert d2 == dims
+    assert t["enc.0.qkv.w"].shape == (3 * dims.n_audio_state, dims.n_audio_state) and t["enc.0.qkv.w"].dtype == np.float16
+    # the folded query scale is exact: q rows == 0.125 * W_q
+    np.testing.assert_array_equal(t["enc.0.qkv.w"][: dims.n_audio_state].astype(np.float32),
+                                  (sd["encoder.blocks.0.attn.query.weight"] * 0.125).astype(np.float16).astype(np.float32))
+    assert t["dec.ckv.w"].shape == (dims.n_text_layer * 2 * dims.n_text_state, dims.n_text_state)
+    assert t["enc.conv1.w"].shape == (dims.n_audio_state, 3 * dims.n_mels)
+    # conv tap re-ordering [co][kk][ci]
+    np.testing.assert_array_equal(t["enc.conv1.w"][5, 1 * dims.n_mels + 7], np.float16(sd["encoder.conv1.weight"][5, 7, 1]))
