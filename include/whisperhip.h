@@ -1,0 +1,275 @@
+/*
+ * whisperhip.h - C ABI of the MI355X (gfx950) Whisper hot path.
+ *
+ * This is the drop-in boundary for the three model-stage protocols of argmaxinc/WhisperKit and the
+ * host logic that drives them.  Every entry point cites the reference interface it replaces
+ * (paths relative to /root/reference/Sources/WhisperKit).  Plain C types only: pointers, sizes,
+ * PODs.  All functions return a wh_status (0 = ok) unless stated; the message of the last failure
+ * on the calling thread is returned by wh_last_error().  Nothing here ever aborts the process.
+ *
+ * Object model (reference analogue):
+ *   wh_model    immutable weights + dims, shareable across threads   (the three loaded MLModels,
+ *               Core/WhisperKit.swift:372-427)
+ *   wh_session  per-task decode state for up to `max_batch` 30 s windows in flight: PCM, mel,
+ *               encoder output, cross-attention K/V, self-attention KV cache, alignment matrix,
+ *               token/log-prob history (DecodingInputs, Core/Models.swift:291-323;
+ *               one per TranscribeTask, Core/TranscribeTask.swift:83).  Bound to one HIP stream.
+ *
+ * Layouts handed across the boundary are the reference's logical shapes in row-major float32:
+ *   mel      [n_mels][3000]        (FeatureExtractor output  [1, n_mels, 1, 3000], Core/Models.swift:877)
+ *   encoder  [1500][d]             (AudioEncoder output      [1, d, 1, 1500] transposed; a Swift shim
+ *                                   transposes - see INTEGRATION.md)
+ *   logits   [n_vocab]             (TextDecoder output       [1, 1, n_vocab],      Core/Models.swift:1041)
+ *   alignment[224][1500]           (DecodingInputs.alignmentWeights,               Core/TextDecoder.swift:141)
+ */
+#ifndef WHISPERHIP_H
+#define WHISPERHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wh_model wh_model;
+typedef struct wh_session wh_session;
+typedef struct wh_transcription wh_transcription;
+
+/* Utilities/WhisperError.swift:7-18 */
+typedef enum wh_status {
+    WH_OK = 0,
+    WH_ERR_TOKENIZER_UNAVAILABLE = 1,
+    WH_ERR_MODELS_UNAVAILABLE = 2,
+    WH_ERR_PREFILL_FAILED = 3,
+    WH_ERR_AUDIO_PROCESSING_FAILED = 4,
+    WH_ERR_DECODING_LOGITS_FAILED = 5,
+    WH_ERR_SEGMENTING_FAILED = 6,
+    WH_ERR_LOAD_AUDIO_FAILED = 7,
+    WH_ERR_PREPARE_DECODER_INPUTS_FAILED = 8,
+    WH_ERR_TRANSCRIPTION_FAILED = 9,
+    WH_ERR_DECODING_FAILED = 10,
+    WH_ERR_INVALID_ARGUMENT = 100,
+    WH_ERR_HIP = 101
+} wh_status;
+
+#define WH_WINDOW_SAMPLES 480000 /* Constants.defaultWindowSamples, Core/Models.swift:1457 */
+#define WH_MEL_FRAMES 3000
+#define WH_AUDIO_CTX 1500
+#define WH_MAX_TOKEN_CONTEXT 224 /* Constants.maxTokenContext, Core/Models.swift:1334 */
+#define WH_MAX_RESULT_TOKENS 232
+#define WH_SAMPLE_RATE 16000     /* WhisperKit.sampleRate, Core/WhisperKit.swift:38 */
+
+/* openai/whisper ModelDimensions; written into the weight blob header */
+typedef struct wh_dims {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wh_dims;
+
+/* SpecialTokens, Core/Models.swift:1111-1149 (+ the contiguous language-token range that
+ * WhisperTokenizer.allLanguageTokens enumerates, Core/Models.swift:1160) */
+typedef struct wh_special_tokens {
+    int32_t end_token, english_token, no_speech_token, no_timestamps_token, special_token_begin;
+    int32_t start_of_previous_token, start_of_transcript_token, time_token_begin;
+    int32_t transcribe_token, translate_token, whitespace_token;
+    int32_t language_token_begin, n_language_tokens;
+} wh_special_tokens;
+
+/* DecodingOptions, Core/Configurations.swift:155-247.  Optionals: NAN / -1 / NULL mean `nil`. */
+typedef struct wh_decoding_options {
+    int32_t task;                 /* 0 transcribe, 1 translate */
+    int32_t language_token;       /* id of "<|lang|>" or -1 (nil) */
+    float temperature;
+    float temperature_increment_on_fallback;
+    int32_t temperature_fallback_count;
+    int32_t sample_length;
+    int32_t top_k;
+    int32_t use_prefill_prompt;
+    int32_t detect_language;      /* -1: default (= !use_prefill_prompt) */
+    int32_t skip_special_tokens;
+    int32_t without_timestamps;
+    int32_t word_timestamps;
+    float max_initial_timestamp;  /* NAN = nil */
+    int32_t max_window_seek;      /* -1 = nil */
+    const float* clip_timestamps;
+    int32_t n_clip_timestamps;
+    float window_clip_time;
+    const int32_t* prompt_tokens; /* NULL = nil */
+    int32_t n_prompt_tokens;
+    const int32_t* prefix_tokens; /* NULL = nil */
+    int32_t n_prefix_tokens;
+    int32_t suppress_blank;
+    const int32_t* suppress_tokens;
+    int32_t n_suppress_tokens;
+    float compression_ratio_threshold; /* NAN = nil */
+    float log_prob_threshold;
+    float first_token_log_prob_threshold;
+    float no_speech_threshold;
+    uint64_t seed;                /* seeds the T>0 multinomial draw (reference: unseeded system RNG) */
+} wh_decoding_options;
+
+/* DecodingFallback.fallbackReason, Core/Models.swift:357-381 */
+enum { WH_FALLBACK_NONE = 0, WH_FALLBACK_FIRST_TOKEN_LOGPROB = 1, WH_FALLBACK_SILENCE = 2,
+       WH_FALLBACK_COMPRESSION_RATIO = 3, WH_FALLBACK_LOGPROB = 4 };
+
+/* DecodingResult, Core/Models.swift:383-439 (tokens are SOT..EOT inclusive) */
+typedef struct wh_decoding_result {
+    int32_t n_tokens;
+    int32_t tokens[WH_MAX_RESULT_TOKENS];
+    float token_logprobs[WH_MAX_RESULT_TOKENS];
+    float avg_logprob;
+    float no_speech_prob;
+    float temperature;
+    float compression_ratio;
+    int32_t language_token;       /* first language token among the result tokens, or -1 */
+    int32_t fallback_reason;      /* WH_FALLBACK_* */
+    int32_t needs_fallback;
+    int32_t is_first_token_logprob_too_low;
+    int32_t steps;                /* decoder forward passes executed (timings.totalDecodingLoops) */
+} wh_decoding_result;
+
+/* TranscriptionSegment / WordTiming, Core/Models.swift:560-641 */
+typedef struct wh_segment {
+    int32_t id, seek;
+    float start, end;
+    int32_t token_offset, n_tokens; /* into the transcription's flat token / logprob arrays */
+    float temperature, avg_logprob, compression_ratio, no_speech_prob;
+    int32_t word_offset, n_words;
+} wh_segment;
+
+typedef struct wh_word_timing {
+    int32_t token_offset, n_tokens;
+    float start, end, probability;
+} wh_word_timing;
+
+/* TranscriptionTimings, Core/Models.swift:730-844 (seconds; device stages measured with HIP events) */
+typedef struct wh_timings {
+    double audio_processing, logmels, encoding, decoding_init, decoding_predictions, decoding_filtering,
+        decoding_sampling, decoding_kv_caching, decoding_word_timestamps, decoding_fallback, decoding_windowing,
+        decoding_loop, full_pipeline, input_audio_seconds;
+    double total_decoding_loops, total_decoding_windows, total_decoding_fallbacks, total_encoding_runs,
+        total_logmel_runs;
+} wh_timings;
+
+const char* wh_last_error(void);
+const char* wh_version(void);
+
+/* ---- model: WhisperKit.loadModels (Core/WhisperKit.swift:358-442) ------------------------------ */
+int wh_model_create(const void* blob, size_t nbytes, int device, wh_model** out); /* WHIPW001 blob (weights.py) */
+int wh_model_load(const char* path, int device, wh_model** out);
+void wh_model_destroy(wh_model* m);
+int wh_model_dims(const wh_model* m, wh_dims* out);
+/* alignment heads for word timestamps: (layer, head) pairs; default = upper half of the decoder layers */
+int wh_model_set_alignment_heads(wh_model* m, const int32_t* layer_head_pairs, int n_pairs);
+
+/* dimension getters the reference introspects from the CoreML models */
+int wh_mel_count(const wh_model* m);                    /* FeatureExtracting.melCount        Core/FeatureExtractor.swift:24 */
+int wh_window_samples(const wh_model* m);               /* FeatureExtracting.windowSamples   Core/FeatureExtractor.swift:32 */
+int wh_embed_size(const wh_model* m);                   /* AudioEncoding.embedSize           Core/AudioEncoder.swift:24 */
+int wh_logits_size(const wh_model* m);                  /* TextDecoding.logitsSize           Core/TextDecoder.swift:313 */
+int wh_kv_cache_embed_dim(const wh_model* m);           /* TextDecoding.kvCacheEmbedDim      Core/TextDecoder.swift:317 */
+int wh_kv_cache_max_sequence_length(const wh_model* m); /* TextDecoding.kvCacheMaxSequenceLength :321 */
+int wh_window_size(const wh_model* m);                  /* TextDecoding.windowSize           Core/TextDecoder.swift:325 */
+int wh_is_model_multilingual(const wh_model* m);        /* TextDecoding.isModelMultilingual  Utilities/ModelUtilities.swift:124 */
+int wh_supports_word_timestamps(const wh_model* m);     /* TextDecoding.supportsWordTimestamps Core/TextDecoder.swift:309 */
+int wh_special_tokens_default(const wh_model* m, wh_special_tokens* out); /* ids implied by the vocabulary size */
+void wh_decoding_options_default(wh_decoding_options* out);  /* DecodingOptions() defaults */
+
+/* ---- session: prepareDecoderInputs (Core/TextDecoder.swift:109-161) ------------------------------ */
+int wh_session_create(wh_model* m, int max_batch, wh_session** out);
+void wh_session_destroy(wh_session* s);
+int wh_session_max_batch(const wh_session* s);
+int wh_session_synchronize(wh_session* s);
+void* wh_session_stream(wh_session* s);                 /* hipStream_t of the session */
+
+/* AudioProcessing.padOrTrimAudio (Core/Audio/AudioProcessor.swift:151-174): copy <=480000 samples into slot b, zero pad */
+int wh_set_audio(wh_session* s, int b, const float* pcm_host, int n_samples);
+int wh_set_audio_device(wh_session* s, int b, const float* pcm_device, int n_samples);
+
+/* FeatureExtracting.logMelSpectrogram (Core/FeatureExtractor.swift:40-56) for slots [0, batch) */
+int wh_log_mel_spectrogram(wh_session* s, int batch);
+int wh_get_mel(wh_session* s, int b, float* out_host /* [n_mels][3000] */);
+int wh_set_mel(wh_session* s, int b, const float* mel_host /* [n_mels][3000] */);
+
+/* AudioEncoding.encodeFeatures (Core/AudioEncoder.swift:50-63) for slots [0, batch) */
+int wh_encode_features(wh_session* s, int batch);
+int wh_get_encoder_output(wh_session* s, int b, float* out_host /* [1500][d] */);
+int wh_set_encoder_output(wh_session* s, int b, const float* enc_host /* [1500][d] */);
+
+/* TextDecoding.prepareDecoderInputs + DecodingInputs.reset: project the encoder output to the per-layer
+ * cross-attention K/V (once per window) and clear the decode state of slots [0, batch) */
+int wh_prepare_decoder_inputs(wh_session* s, int batch);
+int wh_reset_decoder_inputs(wh_session* s, int batch);  /* DecodingInputs.reset, Core/Models.swift:312-322 */
+
+/* TextDecoding.predictLogits + updateKVCache + updateAlignmentWeights (Core/TextDecoder.swift:381-418,218-296):
+ * one decoder call per slot; writes this step's K/V at `positions[b]` and the alignment row at positions[b]+1. */
+int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens, const int32_t* positions,
+                      float* logits_out_host /* [batch][n_vocab] or NULL */);
+int wh_get_alignment_weights(wh_session* s, int b, float* out_host /* [224][1500] */);
+
+/* LogitsFiltering.filterLogits for the built-in chain of createLogitsFilters (Core/TextDecoder.swift:857-899,
+ * Core/Text/LogitsFilter.swift) applied on device to caller-supplied logits; `tokens` = currentTokens,
+ * `prefilled_index`/`initial_prompt_index` as in decodeText.  language_filter != 0 applies LanguageLogitsFilter instead. */
+int wh_filter_logits(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st,
+                     const int32_t* tokens, int n_tokens, int prefilled_index, int initial_prompt_index,
+                     int language_filter, float* logits_inout_host, int n_logits);
+/* TokenSampling.update for GreedyTokenSampler (Core/Text/TokenSampler.swift:29-252) on device */
+int wh_sample_token(wh_session* s, const float* logits_host, int n_logits, float temperature, int top_k,
+                    uint64_t seed, int counter, int32_t* token_out, float* logprob_out);
+
+/* TextDecoding.decodeText (Core/TextDecoder.swift:541-855) for slots [0, batch), whole token loop on device.
+ * temperatures[b] is the sampler temperature of slot b; active[b]==0 skips the slot (may be NULL = all active). */
+int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,
+                   const int32_t* prompt, int n_prompt, const float* temperatures, const int32_t* active,
+                   uint64_t seed, wh_decoding_result* out /* [batch] */);
+/* TextDecoding.detectLanguage (Core/TextDecoder.swift:420-539) */
+int wh_detect_language(wh_session* s, int batch, const wh_special_tokens* st, int32_t* language_tokens_out,
+                       float* logprobs_out);
+/* prefillDecoderInputs (Core/TextDecoder.swift:163-216): builds the forced prompt; returns its length */
+int wh_prefill_prompt(const wh_model* m, const wh_decoding_options* opt, const wh_special_tokens* st,
+                      int32_t language_token, int32_t* prompt_out, int capacity);
+
+/* ---- TranscribeTask.run (Core/TranscribeTask.swift:57-296) --------------------------------------- */
+int wh_transcribe(wh_session* s, const float* pcm_host, int n_samples, const wh_decoding_options* opt,
+                  const wh_special_tokens* st, wh_transcription** out);
+/* WhisperKit.transcribe(audioArrays:) (Core/WhisperKit.swift:716-812): independent audios/chunks, batched on device */
+int wh_transcribe_batch(wh_session* s, const float* const* pcm_host, const int32_t* n_samples, int n_audio,
+                        const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out /* [n_audio] */);
+void wh_transcription_free(wh_transcription* t);
+int wh_transcription_n_segments(const wh_transcription* t);
+int wh_transcription_segment(const wh_transcription* t, int i, wh_segment* out);
+int wh_transcription_n_words(const wh_transcription* t);
+int wh_transcription_word(const wh_transcription* t, int i, wh_word_timing* out);
+int wh_transcription_tokens(const wh_transcription* t, const int32_t** tokens, const float** logprobs, int* n);
+int wh_transcription_language_token(const wh_transcription* t);
+int wh_transcription_timings(const wh_transcription* t, wh_timings* out);
+int wh_transcription_window_seeks(const wh_transcription* t, const int32_t** seeks, int* n);
+
+/* ---- host utilities restated from the reference -------------------------------------------------- */
+float wh_compression_ratio(const int32_t* tokens, int n);          /* TextUtilities.compressionRatio, Utilities/TextUtilities.swift:14-30 */
+/* SegmentSeeker.dynamicTimeWarping (Core/Text/SegmentSeeker.swift:195-278); returns path length */
+int wh_dynamic_time_warping(const float* matrix, int rows, int cols, int32_t* text_indices, int32_t* time_indices, int capacity);
+/* DecodingFallback.init? (Core/Models.swift:357-381) -> WH_FALLBACK_*; *needs_fallback set */
+int wh_decoding_fallback(const wh_decoding_options* opt, int is_first_token_logprob_too_low, float no_speech_prob,
+                         float compression_ratio, float avg_logprob, int32_t* needs_fallback);
+/* SegmentSeeker.findSeekPointAndSegments (Core/Text/SegmentSeeker.swift:41-189); returns number of segments or -1 (skip) */
+int wh_find_seek_point_and_segments(const wh_decoding_result* res, const wh_decoding_options* opt,
+                                    const wh_special_tokens* st, int all_segments_count, int current_seek,
+                                    int segment_size, int32_t* new_seek, wh_segment* segments_out, int capacity);
+/* EnergyVAD.voiceActivity (Core/Audio/EnergyVAD.swift:41-57); returns number of frames written */
+int wh_vad_voice_activity(const float* pcm, int n, int frame_length_samples, int frame_overlap_samples,
+                          float energy_threshold, uint8_t* out, int capacity);
+/* VADAudioChunker.chunkAll (Core/Audio/AudioChunker.swift:66-107); returns number of chunks */
+int wh_vad_chunk_all(const float* pcm, int n, int max_chunk_length, const wh_decoding_options* opt,
+                     int32_t* chunk_start, int32_t* chunk_end, int capacity);
+
+/* ---- measurement (bench.py roofline leg; no reference analogue) --------------------------------------
+ * n_steps eager decoder steps with a HIP event pair around every kernel launch on the session stream; average
+ * microseconds and launch counts per kernel kind: 0 gemv_qkv 1 self_attn 2 gemv_cq 3 cross_attn 4 gemv_fc1
+ * 5 gemv_fc2 6 gemv_logits 7 sampler.  Uses the prompt / sampler configuration of the last wh_decode_text call. */
+int wh_measure_decoder_kernels(wh_session* s, int batch, int n_steps, double* avg_us, int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPERHIP_H */

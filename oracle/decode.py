@@ -427,10 +427,11 @@ def decode_text(step: StepFn, initialPrompt: List[int], sampler: GreedyTokenSamp
                 currentTokens[tokenIndex] = nextToken
         logits = np.array(step(nextToken, tokenIndex), dtype=np.float32, copy=True)             # :616
         steps += 1
-        if record_logits is not None:
-            record_logits.append((tokenIndex, nextToken, logits.copy()))
+        raw = logits.copy() if record_logits is not None else None
         for f in filters:                                                                       # :641-643
             logits = f.filterLogits(logits, currentTokens)
+        if record_logits is not None:
+            record_logits.append((tokenIndex, nextToken, raw, logits.copy()))
         tok, lp = sampler.sample(logits, counter=tokenIndex)                                     # :652
         nextToken, nextTokenLogProb = tok, lp
         completed = tok == sampler.eotToken

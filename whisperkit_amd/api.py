@@ -1,0 +1,438 @@
+"""Host-side mirror of the WhisperKit interfaces over the C ABI (include/whisperhip.h).
+
+Names and argument meaning follow the reference (Sources/WhisperKit/Core/*.swift) so that the parity
+tests read like the reference's own tests:
+
+    WhisperKit(config).transcribe(audioArray=...)            Core/WhisperKit.swift:867
+    featureExtractor.logMelSpectrogram(fromAudio:)           Core/FeatureExtractor.swift:40
+    audioEncoder.encodeFeatures(_:)                          Core/AudioEncoder.swift:50
+    textDecoder.predictLogits / decodeText / detectLanguage  Core/TextDecoder.swift:381,541,420
+    DecodingOptions(...)                                     Core/Configurations.swift:155
+
+All compute happens in libwhisperhip.so on the GPU; this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .weights import MODEL_DIMS, WhisperDims, pack_blob, synthetic_state_dict
+
+
+class WhisperError(RuntimeError):
+    """Utilities/WhisperError.swift: carries the wh_status code and the library's message."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[wh_status {code}] {message}")
+        self.code = code
+
+
+def _check(code: int):
+    if code != 0:
+        raise WhisperError(code, L.load().wh_last_error().decode())
+
+
+@dataclasses.dataclass
+class DecodingOptions:
+    """Core/Configurations.swift:155-247 - same fields, same defaults.  `language` is the language *token id*
+    here (the library never needs a tokenizer); None = nil."""
+    task: str = "transcribe"
+    language: Optional[int] = None
+    temperature: float = 0.0
+    temperatureIncrementOnFallback: float = 0.2
+    temperatureFallbackCount: int = 5
+    sampleLength: int = L.MAX_TOKEN_CONTEXT
+    topK: int = 5
+    usePrefillPrompt: bool = True
+    detectLanguage: Optional[bool] = None
+    skipSpecialTokens: bool = False
+    withoutTimestamps: bool = False
+    wordTimestamps: bool = False
+    maxInitialTimestamp: Optional[float] = None
+    maxWindowSeek: Optional[int] = None
+    clipTimestamps: Sequence[float] = ()
+    windowClipTime: float = 1.0
+    promptTokens: Optional[Sequence[int]] = None
+    prefixTokens: Optional[Sequence[int]] = None
+    suppressBlank: bool = False
+    suppressTokens: Sequence[int] = ()
+    compressionRatioThreshold: Optional[float] = 2.4
+    logProbThreshold: Optional[float] = -1.0
+    firstTokenLogProbThreshold: Optional[float] = -1.5
+    noSpeechThreshold: Optional[float] = 0.6
+    seed: int = 0
+
+    def to_c(self):
+        o = L.WhDecodingOptions()
+        keep = []   # keep numpy buffers alive as long as the struct
+
+        def arr(seq, ct, npdt):
+            a = np.ascontiguousarray(list(seq), dtype=npdt)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(ct)), len(a)
+
+        nan = float("nan")
+        o.task = 1 if self.task == "translate" else 0
+        o.language_token = -1 if self.language is None else int(self.language)
+        o.temperature = self.temperature
+        o.temperature_increment_on_fallback = self.temperatureIncrementOnFallback
+        o.temperature_fallback_count = self.temperatureFallbackCount
+        o.sample_length = self.sampleLength
+        o.top_k = self.topK
+        o.use_prefill_prompt = int(self.usePrefillPrompt)
+        o.detect_language = -1 if self.detectLanguage is None else int(self.detectLanguage)
+        o.skip_special_tokens = int(self.skipSpecialTokens)
+        o.without_timestamps = int(self.withoutTimestamps)
+        o.word_timestamps = int(self.wordTimestamps)
+        o.max_initial_timestamp = nan if self.maxInitialTimestamp is None else self.maxInitialTimestamp
+        o.max_window_seek = -1 if self.maxWindowSeek is None else self.maxWindowSeek
+        o.clip_timestamps, o.n_clip_timestamps = arr(self.clipTimestamps, C.c_float, np.float32)
+        o.window_clip_time = self.windowClipTime
+        if self.promptTokens is not None:
+            o.prompt_tokens, o.n_prompt_tokens = arr(self.promptTokens, C.c_int32, np.int32)
+        if self.prefixTokens is not None:
+            o.prefix_tokens, o.n_prefix_tokens = arr(self.prefixTokens, C.c_int32, np.int32)
+        o.suppress_blank = int(self.suppressBlank)
+        o.suppress_tokens, o.n_suppress_tokens = arr(self.suppressTokens, C.c_int32, np.int32)
+        o.compression_ratio_threshold = nan if self.compressionRatioThreshold is None else self.compressionRatioThreshold
+        o.log_prob_threshold = nan if self.logProbThreshold is None else self.logProbThreshold
+        o.first_token_log_prob_threshold = nan if self.firstTokenLogProbThreshold is None else self.firstTokenLogProbThreshold
+        o.no_speech_threshold = nan if self.noSpeechThreshold is None else self.noSpeechThreshold
+        o.seed = self.seed
+        o._keep = keep
+        return o
+
+
+FALLBACK_REASONS = {0: None, 1: "firstTokenLogProbThreshold", 2: "silence", 3: "compressionRatioThreshold", 4: "logProbThreshold"}
+
+
+@dataclasses.dataclass
+class DecodingResult:
+    tokens: List[int]
+    tokenLogProbs: List[float]
+    avgLogProb: float
+    noSpeechProb: float
+    temperature: float
+    compressionRatio: float
+    languageToken: int
+    fallbackReason: Optional[str]
+    needsFallback: bool
+    isFirstTokenLogProbTooLow: bool
+    steps: int
+
+    @classmethod
+    def from_c(cls, r):
+        n = r.n_tokens
+        return cls(list(r.tokens[:n]), list(r.token_logprobs[:n]), r.avg_logprob, r.no_speech_prob, r.temperature,
+                   r.compression_ratio, r.language_token, FALLBACK_REASONS[r.fallback_reason], bool(r.needs_fallback),
+                   bool(r.is_first_token_logprob_too_low), r.steps)
+
+
+@dataclasses.dataclass
+class WordTiming:
+    tokens: List[int]
+    start: float
+    end: float
+    probability: float
+
+
+@dataclasses.dataclass
+class TranscriptionSegment:
+    id: int
+    seek: int
+    start: float
+    end: float
+    tokens: List[int]
+    tokenLogProbs: List[float]
+    temperature: float
+    avgLogprob: float
+    compressionRatio: float
+    noSpeechProb: float
+    words: List[WordTiming]
+
+
+@dataclasses.dataclass
+class TranscriptionResult:
+    segments: List[TranscriptionSegment]
+    tokens: List[int]
+    languageToken: int
+    timings: dict
+    seeks: List[int]
+
+
+class Model:
+    """The three loaded model stages (weights on one GPU)."""
+
+    def __init__(self, dims: WhisperDims, state_dict=None, device: int = 0, blob: Optional[bytes] = None):
+        self.lib = L.load()
+        self.dims = dims
+        if blob is None:
+            blob = pack_blob(dims, state_dict)
+        self.handle = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _check(self.lib.wh_model_create(buf, len(blob), device, C.byref(self.handle)))
+        st = L.WhSpecialTokens()
+        _check(self.lib.wh_special_tokens_default(self.handle, C.byref(st)))
+        self.specialTokens = st
+
+    @classmethod
+    def synthetic(cls, name: str, seed: int = 0, device: int = 0, **kw):
+        dims = MODEL_DIMS[name]
+        return cls(dims, synthetic_state_dict(dims, seed=seed, **kw), device=device)
+
+    # dimension getters introspected by the reference from the CoreML models
+    melCount = property(lambda s: s.lib.wh_mel_count(s.handle))
+    windowSamples = property(lambda s: s.lib.wh_window_samples(s.handle))
+    embedSize = property(lambda s: s.lib.wh_embed_size(s.handle))
+    logitsSize = property(lambda s: s.lib.wh_logits_size(s.handle))
+    kvCacheEmbedDim = property(lambda s: s.lib.wh_kv_cache_embed_dim(s.handle))
+    kvCacheMaxSequenceLength = property(lambda s: s.lib.wh_kv_cache_max_sequence_length(s.handle))
+    windowSize = property(lambda s: s.lib.wh_window_size(s.handle))
+    isModelMultilingual = property(lambda s: bool(s.lib.wh_is_model_multilingual(s.handle)))
+    supportsWordTimestamps = property(lambda s: bool(s.lib.wh_supports_word_timestamps(s.handle)))
+
+    def setAlignmentHeads(self, pairs):
+        a = np.ascontiguousarray(np.array(list(pairs), dtype=np.int32).reshape(-1))
+        _check(self.lib.wh_model_set_alignment_heads(self.handle, a.ctypes.data_as(L.PI32), len(a) // 2))
+
+    def close(self):
+        if self.handle:
+            self.lib.wh_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session:
+    """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
+
+    def __init__(self, model: Model, maxBatch: int = 1):
+        self.model, self.lib, self.B = model, model.lib, maxBatch
+        self.handle = C.c_void_p()
+        _check(self.lib.wh_session_create(model.handle, maxBatch, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.wh_session_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.lib.wh_session_synchronize(self.handle))
+
+    # ---- AudioProcessing.padOrTrimAudio
+    def padOrTrim(self, audio, slot: int = 0):
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        _check(self.lib.wh_set_audio(self.handle, slot, a.ctypes.data, len(a)))
+
+    def padOrTrimDevice(self, device_ptr: int, n: int, slot: int = 0):
+        _check(self.lib.wh_set_audio_device(self.handle, slot, device_ptr, n))
+
+    # ---- FeatureExtracting
+    def logMelSpectrogram(self, batch: int = 1):
+        _check(self.lib.wh_log_mel_spectrogram(self.handle, batch))
+
+    def getMel(self, slot: int = 0) -> np.ndarray:
+        out = np.empty((self.model.dims.n_mels, L.MEL_FRAMES), np.float32)
+        _check(self.lib.wh_get_mel(self.handle, slot, out.ctypes.data))
+        return out
+
+    def setMel(self, mel, slot: int = 0):
+        a = np.ascontiguousarray(mel, dtype=np.float32)
+        assert a.shape == (self.model.dims.n_mels, L.MEL_FRAMES)
+        _check(self.lib.wh_set_mel(self.handle, slot, a.ctypes.data))
+
+    # ---- AudioEncoding
+    def encodeFeatures(self, batch: int = 1):
+        _check(self.lib.wh_encode_features(self.handle, batch))
+
+    def getEncoderOutput(self, slot: int = 0) -> np.ndarray:
+        out = np.empty((L.AUDIO_CTX, self.model.dims.n_audio_state), np.float32)
+        _check(self.lib.wh_get_encoder_output(self.handle, slot, out.ctypes.data))
+        return out
+
+    def setEncoderOutput(self, enc, slot: int = 0):
+        a = np.ascontiguousarray(enc, dtype=np.float32)
+        assert a.shape == (L.AUDIO_CTX, self.model.dims.n_audio_state)
+        _check(self.lib.wh_set_encoder_output(self.handle, slot, a.ctypes.data))
+
+    # ---- TextDecoding
+    def prepareDecoderInputs(self, batch: int = 1):
+        _check(self.lib.wh_prepare_decoder_inputs(self.handle, batch))
+
+    def resetDecoderInputs(self, batch: int = 1):
+        _check(self.lib.wh_reset_decoder_inputs(self.handle, batch))
+
+    def predictLogits(self, tokens: Sequence[int], positions: Sequence[int]) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        p = np.ascontiguousarray(positions, dtype=np.int32)
+        out = np.empty((len(t), self.model.dims.n_vocab), np.float32)
+        _check(self.lib.wh_predict_logits(self.handle, len(t), t.ctypes.data_as(L.PI32), p.ctypes.data_as(L.PI32), out.ctypes.data))
+        return out
+
+    def getAlignmentWeights(self, slot: int = 0) -> np.ndarray:
+        out = np.empty((L.MAX_TOKEN_CONTEXT, L.AUDIO_CTX), np.float32)
+        _check(self.lib.wh_get_alignment_weights(self.handle, slot, out.ctypes.data))
+        return out
+
+    def filterLogits(self, logits, tokens: Sequence[int], options: DecodingOptions, specialTokens=None, prefilledIndex: int = 0,
+                     initialPromptIndex: int = 0, languageFilter: bool = False) -> np.ndarray:
+        x = np.ascontiguousarray(logits, dtype=np.float32).copy()
+        t = np.ascontiguousarray(list(tokens), dtype=np.int32)
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = options.to_c()
+        _check(self.lib.wh_filter_logits(self.handle, C.byref(o), C.byref(st), t.ctypes.data_as(L.PI32), len(t), prefilledIndex,
+                                         initialPromptIndex, int(languageFilter), x.ctypes.data, len(x)))
+        return x
+
+    def sampleToken(self, logits, temperature: float = 0.0, topK: int = 5, seed: int = 0, counter: int = 0):
+        x = np.ascontiguousarray(logits, dtype=np.float32)
+        tok, lp = C.c_int32(), C.c_float()
+        _check(self.lib.wh_sample_token(self.handle, x.ctypes.data, len(x), temperature, topK, seed, counter, C.byref(tok), C.byref(lp)))
+        return tok.value, lp.value
+
+    def prefillPrompt(self, options: DecodingOptions, languageToken: Optional[int] = None, specialTokens=None) -> List[int]:
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = options.to_c()
+        buf = (C.c_int32 * 256)()
+        n = self.lib.wh_prefill_prompt(self.model.handle, C.byref(o), C.byref(st), -1 if languageToken is None else languageToken, buf, 256)
+        if n <= 0:
+            raise WhisperError(3, "prefill prompt does not fit")
+        return list(buf[:n])
+
+    def decodeText(self, prompt: Sequence[int], options: DecodingOptions, batch: int = 1, temperatures: Optional[Sequence[float]] = None,
+                   active: Optional[Sequence[int]] = None, seed: int = 0, specialTokens=None) -> List[DecodingResult]:
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = options.to_c()
+        p = np.ascontiguousarray(list(prompt), dtype=np.int32)
+        temps = np.ascontiguousarray(temperatures if temperatures is not None else [options.temperature] * batch, dtype=np.float32)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+        res = (L.WhDecodingResult * batch)()
+        _check(self.lib.wh_decode_text(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                                       temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+        return [DecodingResult.from_c(r) for r in res]
+
+    def detectLanguage(self, batch: int = 1, specialTokens=None):
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        lt = (C.c_int32 * batch)()
+        lp = (C.c_float * batch)()
+        _check(self.lib.wh_detect_language(self.handle, batch, C.byref(st), lt, lp))
+        return list(lt), list(lp)
+
+    # ---- TranscribeTask.run / WhisperKit.transcribe(audioArrays:)
+    def transcribe(self, audioArrays: Sequence[np.ndarray], options: Optional[DecodingOptions] = None, specialTokens=None) -> List[TranscriptionResult]:
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = (options or DecodingOptions()).to_c()
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in audioArrays]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_int32 * n)(*[len(a) for a in arrs])
+        outs = (C.c_void_p * n)()
+        _check(self.lib.wh_transcribe_batch(self.handle, ptrs, lens, n, C.byref(o), C.byref(st), outs))
+        results = []
+        for h in outs:
+            results.append(self._collect(h))
+            self.lib.wh_transcription_free(h)
+        return results
+
+    def _collect(self, h) -> TranscriptionResult:
+        lib = self.lib
+        tp, lp, n = L.PI32(), L.PF(), C.c_int()
+        _check(lib.wh_transcription_tokens(h, C.byref(tp), C.byref(lp), C.byref(n)))
+        toks = [tp[i] for i in range(n.value)]
+        lps = [lp[i] for i in range(n.value)]
+        words = []
+        for i in range(lib.wh_transcription_n_words(h)):
+            w = L.WhWordTiming()
+            _check(lib.wh_transcription_word(h, i, C.byref(w)))
+            words.append(w)
+        segs = []
+        for i in range(lib.wh_transcription_n_segments(h)):
+            g = L.WhSegment()
+            _check(lib.wh_transcription_segment(h, i, C.byref(g)))
+            ws = [WordTiming(toks[w.token_offset:w.token_offset + w.n_tokens], w.start, w.end, w.probability)
+                  for w in words[g.word_offset:g.word_offset + g.n_words]]
+            segs.append(TranscriptionSegment(g.id, g.seek, g.start, g.end, toks[g.token_offset:g.token_offset + g.n_tokens],
+                                             lps[g.token_offset:g.token_offset + g.n_tokens], g.temperature, g.avg_logprob,
+                                             g.compression_ratio, g.no_speech_prob, ws))
+        t = L.WhTimings()
+        _check(lib.wh_transcription_timings(h, C.byref(t)))
+        sp, sn = L.PI32(), C.c_int()
+        _check(lib.wh_transcription_window_seeks(h, C.byref(sp), C.byref(sn)))
+        return TranscriptionResult(segs, toks, lib.wh_transcription_language_token(h),
+                                   {k: getattr(t, k) for k, _ in L.WhTimings._fields_}, [sp[i] for i in range(sn.value)])
+
+
+# ---- host utilities (no GPU needed) ---------------------------------------------------------------
+def compressionRatio(tokens: Sequence[int]) -> float:
+    a = np.ascontiguousarray(list(tokens), dtype=np.int32)
+    return float(L.load().wh_compression_ratio(a.ctypes.data_as(L.PI32), len(a)))
+
+
+def dynamicTimeWarping(matrix: np.ndarray):
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    cap = m.shape[0] + m.shape[1] + 8
+    ti, tj = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    n = L.load().wh_dynamic_time_warping(m.ctypes.data_as(L.PF), m.shape[0], m.shape[1], ti, tj, cap)
+    if n < 0:
+        raise WhisperError(6, "dynamicTimeWarping failed")
+    return list(ti[:n]), list(tj[:n])
+
+
+def decodingFallback(options: DecodingOptions, isFirstTokenLogProbTooLow: bool, noSpeechProb: float, compressionRatio_: float, avgLogProb: float):
+    o = options.to_c()
+    need = C.c_int32()
+    r = L.load().wh_decoding_fallback(C.byref(o), int(isFirstTokenLogProbTooLow), noSpeechProb, compressionRatio_, avgLogProb, C.byref(need))
+    return FALLBACK_REASONS[r], bool(need.value)
+
+
+def voiceActivity(audio, frameLengthSamples: int = 1600, frameOverlapSamples: int = 0, energyThreshold: float = 0.02) -> List[bool]:
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    lib = L.load()
+    n = lib.wh_vad_voice_activity(a.ctypes.data_as(L.PF), len(a), frameLengthSamples, frameOverlapSamples, energyThreshold, None, 0)
+    if n <= 0:
+        return []
+    out = (C.c_uint8 * n)()
+    lib.wh_vad_voice_activity(a.ctypes.data_as(L.PF), len(a), frameLengthSamples, frameOverlapSamples, energyThreshold, out, n)
+    return [bool(v) for v in out]
+
+
+def vadChunkAll(audio, maxChunkLength: int = L.WINDOW_SAMPLES, options: Optional[DecodingOptions] = None):
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    o = (options or DecodingOptions()).to_c()
+    cap = max(4, len(a) // 16000 + 4)
+    cs, ce = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    n = L.load().wh_vad_chunk_all(a.ctypes.data_as(L.PF), len(a), maxChunkLength, C.byref(o), cs, ce, cap)
+    if n < 0:
+        raise WhisperError(4, "vadChunkAll failed")
+    return [(cs[i], ce[i]) for i in range(n)]
+
+
+def findSeekPointAndSegments(tokens: Sequence[int], logprobs: Sequence[float], options: DecodingOptions, specialTokens,
+                             allSegmentsCount: int, currentSeek: int, segmentSize: int, avgLogProb: float = 0.0,
+                             noSpeechProb: float = 0.0):
+    r = L.WhDecodingResult()
+    r.n_tokens = len(tokens)
+    for i, (t, l) in enumerate(zip(tokens, logprobs)):
+        r.tokens[i], r.token_logprobs[i] = t, l
+    r.avg_logprob, r.no_speech_prob = avgLogProb, noSpeechProb
+    o = options.to_c()
+    seek = C.c_int32()
+    segs = (L.WhSegment * L.WH_MAX_RESULT_TOKENS)()
+    n = L.load().wh_find_seek_point_and_segments(C.byref(r), C.byref(o), C.byref(specialTokens), allSegmentsCount, currentSeek,
+                                                 segmentSize, C.byref(seek), segs, L.WH_MAX_RESULT_TOKENS)
+    return seek.value, (None if n < 0 else [segs[i] for i in range(n)])

@@ -1,0 +1,591 @@
+// C-ABI implementation: model / session objects and the three model-stage entry points
+// (FeatureExtracting, AudioEncoding, TextDecoding of argmaxinc/WhisperKit) over the gfx950 kernels.
+// See include/whisperhip.h for the reference interface each function replaces.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "internal.h"
+
+using namespace wh;
+
+namespace whi {
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace whi
+using whi::set_error;
+
+extern "C" const char* wh_last_error(void) { return whi::g_err; }
+extern "C" const char* wh_version(void) { return "whisperhip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------ mel tables
+static double hz_to_mel(double f) {   // slaney scale
+    const double min_log_hz = 1000.0, min_log_mel = 15.0, logstep = 27.0 / log(6.4);
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) * logstep : 3.0 * f / 200.0;
+}
+static double mel_to_hz(double m) {
+    const double min_log_hz = 1000.0, min_log_mel = 15.0, logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : 200.0 * m / 3.0;
+}
+
+static int build_mel_tables(wh_model* m) {
+    const int n_mels = m->dims.n_mels;
+    const size_t nb = (size_t)200 * kBinsPad, nf = (size_t)kBins * n_mels;
+    std::vector<float> bc(nb, 0.f), bs(nb, 0.f), filt(nf, 0.f);
+    std::vector<int2> rng(n_mels);
+    for (int n = 1; n <= 200; ++n) {
+        double w = 0.5 - 0.5 * cos(2.0 * M_PI * n / 400.0);
+        for (int k = 0; k < kBins; ++k) {
+            int ph = (int)(((long long)n * k) % 400);   // exact phase reduction
+            double ang = 2.0 * M_PI * ph / 400.0;
+            bc[(size_t)(n - 1) * kBinsPad + k] = (float)(w * cos(ang));
+            bs[(size_t)(n - 1) * kBinsPad + k] = (n == 200) ? 0.0f : (float)(w * sin(ang));
+        }
+    }
+    // slaney mel filterbank (transformers audio_utils.mel_filter_bank, norm="slaney", mel_scale="slaney")
+    std::vector<double> ff(n_mels + 2);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i) ff[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    for (int j = 0; j < n_mels; ++j) {
+        int lo = kBins, hi = -1;
+        double enorm = 2.0 / (ff[j + 2] - ff[j]);
+        for (int k = 0; k < kBins; ++k) {
+            double f = 8000.0 * k / (kBins - 1);
+            double down = (f - ff[j]) / (ff[j + 1] - ff[j]);
+            double up = (ff[j + 2] - f) / (ff[j + 2] - ff[j + 1]);
+            double v = std::max(0.0, std::min(down, up)) * enorm;
+            filt[(size_t)k * n_mels + j] = (float)v;
+            if (v > 0) { lo = std::min(lo, k); hi = std::max(hi, k); }
+        }
+        if (hi < lo) { lo = 0; hi = -1; }
+        rng[j] = int2{lo, hi};
+    }
+    size_t bytes = (2 * nb + nf) * sizeof(float) + n_mels * sizeof(int2);
+    char* dev = nullptr;
+    WH_HIP(hipMalloc((void**)&dev, bytes));
+    m->mel_tables_dev = dev;
+    WH_HIP(hipMemcpy(dev, bc.data(), nb * 4, hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + nb * 4, bs.data(), nb * 4, hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + 2 * nb * 4, filt.data(), nf * 4, hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + 2 * nb * 4 + nf * 4, rng.data(), n_mels * sizeof(int2), hipMemcpyHostToDevice));
+    m->mel.basis_c = (const float*)dev;
+    m->mel.basis_s = (const float*)(dev + nb * 4);
+    m->mel.filt = (const float*)(dev + 2 * nb * 4);
+    m->mel.filt_range = (const int2*)(dev + 2 * nb * 4 + nf * 4);
+    m->mel.n_mels = n_mels;
+    return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ model
+#pragma pack(push, 1)
+struct BlobEntry {
+    char name[64];
+    int32_t dtype, ndim;
+    int64_t shape[4];
+    int64_t offset, nbytes;
+};
+#pragma pack(pop)
+
+template <typename T>
+static int get_tensor(wh_model* m, const std::string& name, const T** out, int dtype) {
+    auto it = m->t.find(name);
+    if (it == m->t.end()) return set_error(WH_ERR_MODELS_UNAVAILABLE, "weight blob has no tensor '%s'", name.c_str());
+    if (it->second.dtype != dtype) return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor '%s' has dtype %d, expected %d", name.c_str(), it->second.dtype, dtype);
+    *out = (const T*)it->second.dev;
+    return WH_OK;
+}
+#define GET16(name, field) do { int _r = get_tensor<f16>(m, name, &(field), 0); if (_r) return _r; } while (0)
+#define GET32(name, field) do { int _r = get_tensor<float>(m, name, &(field), 1); if (_r) return _r; } while (0)
+
+static int bind_weights(wh_model* m) {
+    const wh_dims& D = m->dims;
+    GET16("enc.conv1.w", m->conv1_w); GET32("enc.conv1.b", m->conv1_b);
+    GET16("enc.conv2.w", m->conv2_w); GET32("enc.conv2.b", m->conv2_b);
+    GET32("enc.pos", m->enc_pos); GET32("enc.lnp.g", m->lnp_g); GET32("enc.lnp.b", m->lnp_b);
+    m->enc.resize(D.n_audio_layer);
+    for (int i = 0; i < D.n_audio_layer; ++i) {
+        std::string p = "enc." + std::to_string(i);
+        EncLayerW& w = m->enc[i];
+        GET32(p + ".ln1.g", w.ln1_g); GET32(p + ".ln1.b", w.ln1_b); GET16(p + ".qkv.w", w.qkv_w); GET32(p + ".qkv.b", w.qkv_b);
+        GET16(p + ".o.w", w.o_w); GET32(p + ".o.b", w.o_b); GET32(p + ".ln2.g", w.ln2_g); GET32(p + ".ln2.b", w.ln2_b);
+        GET16(p + ".fc1.w", w.fc1_w); GET32(p + ".fc1.b", w.fc1_b); GET16(p + ".fc2.w", w.fc2_w); GET32(p + ".fc2.b", w.fc2_b);
+    }
+    GET16("dec.emb", m->emb); GET32("dec.pos", m->dec_pos); GET16("dec.ckv.w", m->ckv_w); GET32("dec.ckv.b", m->ckv_b);
+    GET32("dec.ln.g", m->lnf_g); GET32("dec.ln.b", m->lnf_b);
+    m->dec.resize(D.n_text_layer);
+    for (int i = 0; i < D.n_text_layer; ++i) {
+        std::string p = "dec." + std::to_string(i);
+        DecLayerW& w = m->dec[i];
+        GET32(p + ".ln1.g", w.ln1_g); GET32(p + ".ln1.b", w.ln1_b); GET16(p + ".qkv.w", w.qkv_w); GET32(p + ".qkv.b", w.qkv_b);
+        GET16(p + ".o.w", w.o_w); GET32(p + ".o.b", w.o_b);
+        GET32(p + ".ln2.g", w.ln2_g); GET32(p + ".ln2.b", w.ln2_b); GET16(p + ".cq.w", w.cq_w); GET32(p + ".cq.b", w.cq_b);
+        GET16(p + ".co.w", w.co_w); GET32(p + ".co.b", w.co_b);
+        GET32(p + ".ln3.g", w.ln3_g); GET32(p + ".ln3.b", w.ln3_b);
+        GET16(p + ".fc1.w", w.fc1_w); GET32(p + ".fc1.b", w.fc1_b); GET16(p + ".fc2.w", w.fc2_w); GET32(p + ".fc2.b", w.fc2_b);
+    }
+    return WH_OK;
+}
+
+static int set_alignment_heads(wh_model* m, const int32_t* pairs, int n) {
+    const int L = m->dims.n_text_layer, H = m->dims.n_text_head;
+    std::vector<int> slot(L * H, -1);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        int l = pairs[2 * i], h = pairs[2 * i + 1];
+        if (l < 0 || l >= L || h < 0 || h >= H) return set_error(WH_ERR_INVALID_ARGUMENT, "alignment head (%d,%d) out of range", l, h);
+        if (slot[l * H + h] < 0) slot[l * H + h] = cnt++;
+    }
+    m->align_slot = slot;
+    m->n_align = cnt;
+    if (!m->align_slot_dev) WH_HIP(hipMalloc((void**)&m->align_slot_dev, sizeof(int) * L * H));
+    WH_HIP(hipMemcpy(m->align_slot_dev, slot.data(), sizeof(int) * L * H, hipMemcpyHostToDevice));
+    return WH_OK;
+}
+
+extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_model** out) {
+    if (!blob || !out || nbytes < 56) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_model_create: null or truncated blob");
+    const unsigned char* p = (const unsigned char*)blob;
+    if (memcmp(p, "WHIPW001", 8) != 0) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_model_create: bad magic (expected WHIPW001)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(WH_ERR_HIP, "no HIP device visible: the whisperhip product path has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(WH_ERR_INVALID_ARGUMENT, "device %d out of range (%d visible)", device, ndev);
+    WH_HIP(hipSetDevice(device));
+    wh_model* m = new wh_model();
+    m->device = device;
+    memcpy(&m->dims, p + 8, sizeof(wh_dims));
+    int32_t n_tensors;
+    memcpy(&n_tensors, p + 48, 4);
+    const wh_dims& D = m->dims;
+    if (D.n_audio_ctx != kCtx || D.n_audio_state % 64 || D.n_audio_state / D.n_audio_head != 64 || D.n_text_state / D.n_text_head != 64 ||
+        D.n_audio_state != D.n_text_state || D.n_audio_state > 1280 || (D.n_mels != 80 && D.n_mels != 128) || n_tensors <= 0 ||
+        56 + (size_t)n_tensors * sizeof(BlobEntry) > nbytes) {
+        delete m;
+        return set_error(WH_ERR_MODELS_UNAVAILABLE, "unsupported model dimensions in blob header");
+    }
+    hipError_t e = hipMalloc(&m->blob_dev, nbytes);
+    if (e != hipSuccess) { delete m; return set_error(WH_ERR_HIP, "hipMalloc(%zu) for weights failed: %s", nbytes, hipGetErrorString(e)); }
+    m->blob_bytes = nbytes;
+    e = hipMemcpy(m->blob_dev, blob, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { wh_model_destroy(m); return set_error(WH_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < n_tensors; ++i) {
+        BlobEntry en;
+        memcpy(&en, p + 56 + (size_t)i * sizeof(BlobEntry), sizeof(BlobEntry));
+        if (en.offset < 0 || (size_t)(en.offset + en.nbytes) > nbytes) { wh_model_destroy(m); return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor %d out of blob bounds", i); }
+        WhTensor t;
+        t.dev = (char*)m->blob_dev + en.offset;
+        t.dtype = en.dtype; t.ndim = en.ndim; t.nbytes = (size_t)en.nbytes;
+        for (int k = 0; k < 4; ++k) t.shape[k] = en.shape[k];
+        char nm[65]; memcpy(nm, en.name, 64); nm[64] = 0;
+        m->t[nm] = t;
+    }
+    int r = bind_weights(m);
+    if (!r) r = build_mel_tables(m);
+    if (!r) {
+        std::vector<int32_t> pairs;   // default: every head of the upper half of the decoder (openai/whisper model.py)
+        for (int l = D.n_text_layer / 2; l < D.n_text_layer; ++l)
+            for (int h = 0; h < D.n_text_head; ++h) { pairs.push_back(l); pairs.push_back(h); }
+        r = set_alignment_heads(m, pairs.data(), (int)pairs.size() / 2);
+    }
+    if (r) { wh_model_destroy(m); return r; }
+    *out = m;
+    return WH_OK;
+}
+
+extern "C" int wh_model_load(const char* path, int device, wh_model** out) {
+    if (!path) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_model_load: null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_error(WH_ERR_MODELS_UNAVAILABLE, "cannot open model file '%s'", path);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> buf((size_t)n);
+    size_t got = fread(buf.data(), 1, (size_t)n, f);
+    fclose(f);
+    if (got != (size_t)n) return set_error(WH_ERR_MODELS_UNAVAILABLE, "short read on '%s'", path);
+    return wh_model_create(buf.data(), buf.size(), device, out);
+}
+
+extern "C" void wh_model_destroy(wh_model* m) {
+    if (!m) return;
+    if (m->blob_dev) hipFree(m->blob_dev);
+    if (m->mel_tables_dev) hipFree(m->mel_tables_dev);
+    if (m->align_slot_dev) hipFree(m->align_slot_dev);
+    delete m;
+}
+
+extern "C" int wh_model_dims(const wh_model* m, wh_dims* out) {
+    if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "model is null");
+    *out = m->dims;
+    return WH_OK;
+}
+extern "C" int wh_model_set_alignment_heads(wh_model* m, const int32_t* pairs, int n) {
+    if (!m || (!pairs && n > 0)) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_model_set_alignment_heads: null argument");
+    return set_alignment_heads(m, pairs, n);
+}
+extern "C" int wh_mel_count(const wh_model* m) { return m ? m->dims.n_mels : -1; }
+extern "C" int wh_window_samples(const wh_model* m) { return m ? kWindowSamples : -1; }
+extern "C" int wh_embed_size(const wh_model* m) { return m ? m->dims.n_audio_state : -1; }
+extern "C" int wh_logits_size(const wh_model* m) { return m ? m->dims.n_vocab : -1; }
+extern "C" int wh_kv_cache_embed_dim(const wh_model* m) { return m ? m->dims.n_text_state * m->dims.n_text_layer : -1; }
+extern "C" int wh_kv_cache_max_sequence_length(const wh_model* m) { return m ? kMaxTok : -1; }
+extern "C" int wh_window_size(const wh_model* m) { return m ? m->dims.n_audio_ctx : -1; }
+extern "C" int wh_is_model_multilingual(const wh_model* m) { return m ? (m->dims.n_vocab >= 51865) : -1; }
+extern "C" int wh_supports_word_timestamps(const wh_model* m) { return m ? (m->n_align > 0) : -1; }
+
+extern "C" int wh_special_tokens_default(const wh_model* m, wh_special_tokens* o) {
+    if (!m || !o) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_special_tokens_default: null argument");
+    int V = m->dims.n_vocab, eot, nlang;
+    if (V == 51864) { eot = 50256; nlang = 99; }
+    else if (V == 51865) { eot = 50257; nlang = 99; }
+    else if (V == 51866) { eot = 50257; nlang = 100; }
+    else return set_error(WH_ERR_TOKENIZER_UNAVAILABLE, "no default special tokens for vocabulary size %d", V);
+    int sot = eot + 1, lang0 = sot + 1, translate = lang0 + nlang;
+    o->end_token = eot; o->english_token = lang0; o->no_speech_token = translate + 4; o->no_timestamps_token = translate + 5;
+    o->special_token_begin = eot; o->start_of_previous_token = translate + 3; o->start_of_transcript_token = sot;
+    o->time_token_begin = translate + 6; o->transcribe_token = translate + 1; o->translate_token = translate; o->whitespace_token = 220;
+    o->language_token_begin = lang0; o->n_language_tokens = nlang;
+    return WH_OK;
+}
+
+extern "C" void wh_decoding_options_default(wh_decoding_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->task = 0; o->language_token = -1; o->temperature = 0.0f; o->temperature_increment_on_fallback = 0.2f;
+    o->temperature_fallback_count = 5; o->sample_length = WH_MAX_TOKEN_CONTEXT; o->top_k = 5; o->use_prefill_prompt = 1;
+    o->detect_language = -1; o->skip_special_tokens = 0; o->without_timestamps = 0; o->word_timestamps = 0;
+    o->max_initial_timestamp = NAN; o->max_window_seek = -1; o->clip_timestamps = nullptr; o->n_clip_timestamps = 0;
+    o->window_clip_time = 1.0f; o->prompt_tokens = nullptr; o->n_prompt_tokens = 0; o->prefix_tokens = nullptr; o->n_prefix_tokens = 0;
+    o->suppress_blank = 0; o->suppress_tokens = nullptr; o->n_suppress_tokens = 0;
+    o->compression_ratio_threshold = 2.4f; o->log_prob_threshold = -1.0f; o->first_token_log_prob_threshold = -1.5f;
+    o->no_speech_threshold = 0.6f; o->seed = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ session
+template <typename T>
+static int dalloc(T** p, size_t n, bool zero = true) {
+    WH_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    if (zero) WH_HIP(hipMemset(*p, 0, n * sizeof(T)));
+    return WH_OK;
+}
+#define DALLOC(ptr, n) do { int _r = dalloc(&(ptr), (size_t)(n)); if (_r) { wh_session_destroy(s); return _r; } } while (0)
+
+extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
+    if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
+    if (max_batch < 1 || max_batch > 64) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 64]", max_batch);
+    WH_HIP(hipSetDevice(m->device));
+    wh_session* s = new wh_session();
+    s->m = m; s->B = max_batch;
+    const wh_dims& D = m->dims;
+    const size_t B = max_batch, d = D.n_audio_state, L = D.n_text_layer, V = D.n_vocab, H = D.n_text_head;
+    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
+    DALLOC(s->pcm, B * kWindowSamples); DALLOC(s->n_valid, B);
+    DALLOC(s->logspec, B * D.n_mels * kFrames); DALLOC(s->maxkey, B);
+    DALLOC(s->mel_t, B * kFramesPad * D.n_mels); DALLOC(s->mel_f32, B * D.n_mels * kFrames);
+    DALLOC(s->h1, B * kFramesPad * d); DALLOC(s->x, B * kCtx * d); DALLOC(s->xn, B * kCtx * d);
+    DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
+    DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
+    DALLOC(s->cross_kv, B * kCtx * L * 2 * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
+    DALLOC(s->xa, B * d); DALLOC(s->xb, B * d); DALLOC(s->q, B * d); DALLOC(s->partial, B * H * d); DALLOC(s->logits, B * V);
+    DALLOC(s->hbuf, B * 4 * d);
+    DALLOC(s->align_mean, B * kMaxTok * kCtx);
+    DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress);
+    DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
+    if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
+    for (auto& e : s->ev) hipEventCreate(&e);
+    *out = s;
+    return WH_OK;
+}
+
+extern "C" void wh_session_destroy(wh_session* s) {
+    if (!s) return;
+    if (s->st) hipStreamSynchronize(s->st);
+    whi::drop_session_graphs(s);
+    void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
+                    s->hmlp, s->enc16, s->enc32, s->cross_kv, s->self_k, s->self_v, s->xa, s->xb, s->q, s->partial, s->logits, s->hbuf,
+                    s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (s->seq_host) hipHostFree(s->seq_host);
+    for (auto& e : s->ev) if (e) hipEventDestroy(e);
+    if (s->st) hipStreamDestroy(s->st);
+    delete s;
+}
+extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1; }
+extern "C" int wh_session_synchronize(wh_session* s) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "session is null");
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+extern "C" void* wh_session_stream(wh_session* s) { return s ? (void*)s->st : nullptr; }
+
+#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); } while (0)
+#define CHECK_SLOT(s, b) do { if ((b) < 0 || (b) >= (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: slot %d out of range [0,%d)", __func__, (b), (s)->B); } while (0)
+#define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
+
+// ------------------------------------------------------------------------------------------------ audio / mel
+static int set_audio_common(wh_session* s, int b, const float* pcm, int n, hipMemcpyKind kind) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (n < 0 || (!pcm && n > 0)) return set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "wh_set_audio: invalid buffer (n=%d)", n);
+    int m = std::min(n, kWindowSamples);   // trim
+    float* dst = s->pcm + (size_t)b * kWindowSamples;
+    if (m > 0) WH_HIP(hipMemcpyAsync(dst, pcm, sizeof(float) * m, kind, s->st));
+    if (m < kWindowSamples) WH_HIP(hipMemsetAsync(dst + m, 0, sizeof(float) * (kWindowSamples - m), s->st));   // pad (vDSP_vclr)
+    WH_HIP(hipMemcpyAsync(s->n_valid + b, &m, sizeof(int), hipMemcpyHostToDevice, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));   // &m is a stack temporary
+    return WH_OK;
+}
+extern "C" int wh_set_audio(wh_session* s, int b, const float* pcm_host, int n) { return set_audio_common(s, b, pcm_host, n, hipMemcpyHostToDevice); }
+extern "C" int wh_set_audio_device(wh_session* s, int b, const float* pcm_dev, int n) { return set_audio_common(s, b, pcm_dev, n, hipMemcpyDeviceToDevice); }
+
+extern "C" int wh_log_mel_spectrogram(wh_session* s, int batch) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    launch_log_mel(s->m->mel, s->pcm, s->n_valid, batch, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->st);
+    WH_CHECK_LAUNCH();
+    return WH_OK;
+}
+extern "C" int wh_get_mel(wh_session* s, int b, float* out) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_mel: null output");
+    size_t n = (size_t)s->m->dims.n_mels * kFrames;
+    WH_HIP(hipMemcpyAsync(out, s->mel_f32 + b * n, n * 4, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+extern "C" int wh_set_mel(wh_session* s, int b, const float* mel) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!mel) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_set_mel: null input");
+    const int nm = s->m->dims.n_mels;
+    size_t n = (size_t)nm * kFrames;
+    WH_HIP(hipMemcpyAsync(s->mel_f32 + b * n, mel, n * 4, hipMemcpyHostToDevice, s->st));
+    launch_mel_import(s->mel_f32 + b * n, nm, 1, s->mel_t + (size_t)b * kFramesPad * nm, s->st);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+extern "C" int wh_encode_features(wh_session* s, int batch) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    const wh_model* m = s->m;
+    const wh_dims& D = m->dims;
+    const int d = D.n_audio_state, nm = D.n_mels, M = batch * kCtx;
+    hipStream_t st = s->st;
+    GemmArgs g{};
+    // conv1 (k3 s1 p1) + GELU as a GEMM over 3 consecutive rows of the padded time-major mel
+    g.A = s->mel_t; g.W = m->conv1_w; g.bias = m->conv1_b; g.M = batch * kFrames; g.N = d; g.K = 3 * nm; g.lda = nm;
+    g.a_rows_per_batch = kFrames; g.a_batch_stride = (long long)kFramesPad * nm; g.ldc = d; g.out16 = s->h1; g.rows_per_batch_out = kFrames;
+    launch_gemm(EPI_CONV1, g, st);
+    // conv2 (k3 s2 p1) + GELU + positional embedding -> fp32 residual stream
+    g = GemmArgs{};
+    g.A = s->h1; g.W = m->conv2_w; g.bias = m->conv2_b; g.M = M; g.N = d; g.K = 3 * d; g.lda = 2 * d;
+    g.a_rows_per_batch = kCtx; g.a_batch_stride = (long long)kFramesPad * d; g.ldc = d; g.out32 = s->x; g.pos = m->enc_pos; g.rows_per_batch_out = kCtx;
+    launch_gemm(EPI_CONV2, g, st);
+    for (int l = 0; l < D.n_audio_layer; ++l) {
+        const EncLayerW& w = m->enc[l];
+        launch_layernorm(s->x, w.ln1_g, w.ln1_b, M, d, s->xn, nullptr, st);
+        g = GemmArgs{};
+        g.A = s->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.M = M; g.N = 3 * d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = d;
+        g.out16 = s->q16; g.k16 = s->k16; g.vt16 = s->vt16; g.d_model = d; g.rows_per_batch_out = kCtx;
+        launch_gemm(EPI_QKV_ENC, g, st);
+        launch_encoder_attention(s->q16, s->k16, s->vt16, s->att16, batch, D.n_audio_head, d, st);
+        g = GemmArgs{};
+        g.A = s->att16; g.W = w.o_w; g.bias = w.o_b; g.M = M; g.N = d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = d; g.out32 = s->x;
+        launch_gemm(EPI_RESID_F32, g, st);
+        launch_layernorm(s->x, w.ln2_g, w.ln2_b, M, d, s->xn, nullptr, st);
+        g = GemmArgs{};
+        g.A = s->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.M = M; g.N = 4 * d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = 4 * d; g.out16 = s->hmlp;
+        launch_gemm(EPI_GELU_F16, g, st);
+        g = GemmArgs{};
+        g.A = s->hmlp; g.W = w.fc2_w; g.bias = w.fc2_b; g.M = M; g.N = d; g.K = 4 * d; g.lda = 4 * d; g.a_rows_per_batch = M; g.ldc = d; g.out32 = s->x;
+        launch_gemm(EPI_RESID_F32, g, st);
+    }
+    launch_layernorm(s->x, m->lnp_g, m->lnp_b, M, d, s->enc16, s->enc32, st);
+    WH_CHECK_LAUNCH();
+    return WH_OK;
+}
+extern "C" int wh_get_encoder_output(wh_session* s, int b, float* out) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_encoder_output: null output");
+    size_t n = (size_t)kCtx * s->m->dims.n_audio_state;
+    WH_HIP(hipMemcpyAsync(out, s->enc32 + b * n, n * 4, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+extern "C" int wh_set_encoder_output(wh_session* s, int b, const float* enc) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!enc) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_set_encoder_output: null input");
+    size_t n = (size_t)kCtx * s->m->dims.n_audio_state;
+    WH_HIP(hipMemcpyAsync(s->enc32 + b * n, enc, n * 4, hipMemcpyHostToDevice, s->st));
+    launch_f32_to_f16(s->enc32 + b * n, s->enc16 + b * n, n, s->st);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+namespace whi {
+DecodeBuffers decode_buffers(wh_session* s, int batch) {
+    const wh_model* m = s->m;
+    DecodeBuffers db{};
+    db.batch = batch; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
+    db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
+    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_kv = s->cross_kv; db.xa = s->xa; db.xb = s->xb; db.q = s->q; db.hbuf = s->hbuf;
+    db.partial = s->partial; db.logits = s->logits; db.seq = s->seq;
+    db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
+    return db;
+}
+}  // namespace whi
+
+static int ensure_align(wh_session* s) {
+    if (!s->align && s->m->n_align > 0) {
+        size_t n = (size_t)s->B * kMaxTok * s->m->n_align * kCtx;
+        WH_HIP(hipMalloc((void**)&s->align, n * sizeof(float)));
+        WH_HIP(hipMemsetAsync(s->align, 0, n * sizeof(float), s->st));
+    }
+    return WH_OK;
+}
+
+extern "C" int wh_reset_decoder_inputs(wh_session* s, int batch) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    WH_HIP(hipMemsetAsync(s->seq, 0, sizeof(SeqState) * batch, s->st));
+    if (s->align) WH_HIP(hipMemsetAsync(s->align, 0, (size_t)batch * kMaxTok * s->m->n_align * kCtx * sizeof(float), s->st));
+    return WH_OK;
+}
+
+extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    const wh_model* m = s->m;
+    const int d = m->dims.n_text_state, L = m->dims.n_text_layer;
+    GemmArgs g{};
+    g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
+    g.ldc = L * 2 * d; g.out16 = s->cross_kv;
+    launch_gemm(EPI_F16, g, s->st);
+    WH_CHECK_LAUNCH();
+    return wh_reset_decoder_inputs(s, batch);
+}
+
+extern "C" int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens, const int32_t* positions, float* logits_out) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    if (!tokens || !positions) return set_error(WH_ERR_DECODING_LOGITS_FAILED, "wh_predict_logits: null tokens/positions");
+    const int V = s->m->dims.n_vocab;
+    int r = ensure_align(s);
+    if (r) return r;
+    s->align_enabled = s->align != nullptr;
+    for (int b = 0; b < batch; ++b) {
+        if (tokens[b] < 0 || tokens[b] >= V || positions[b] < 0 || positions[b] >= kMaxTok)
+            return set_error(WH_ERR_DECODING_LOGITS_FAILED, "wh_predict_logits: token %d / position %d out of range", tokens[b], positions[b]);
+        SeqState& q = s->seq_host[b];
+        memset(&q, 0, sizeof(q));
+        q.next_token = tokens[b]; q.token_index = positions[b]; q.active = 1; q.done = 0;
+    }
+    // only the control fields are refreshed; token history on the device is not used by the bare step
+    WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
+    DecodeBuffers db = whi::decode_buffers(s, batch);
+    launch_decoder_step(db, nullptr, nullptr, false, s->st);
+    WH_CHECK_LAUNCH();
+    if (logits_out) WH_HIP(hipMemcpyAsync(logits_out, s->logits, sizeof(float) * (size_t)batch * V, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+extern "C" int wh_get_alignment_weights(wh_session* s, int b, float* out) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_alignment_weights: null output");
+    if (!s->align) return set_error(WH_ERR_SEGMENTING_FAILED, "no alignment weights recorded (run a decode with word timestamps / the step API first)");
+    launch_alignment_mean(s->align, s->B, s->m->n_align, s->align_mean, s->st);
+    WH_CHECK_LAUNCH();
+    size_t n = (size_t)kMaxTok * kCtx;
+    WH_HIP(hipMemcpyAsync(out, s->align_mean + b * n, n * 4, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+// ---- filter / sampler KAT entry points ----------------------------------------------------------
+static int upload_cfg(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, int prefilled_index,
+                      int initial_prompt_index, int language_filter, int n_vocab, uint64_t seed) {
+    SamplerCfg c{};
+    c.n_vocab = n_vocab;
+    c.end_token = st->end_token; c.no_timestamps_token = st->no_timestamps_token; c.time_token_begin = st->time_token_begin;
+    c.transcribe_token = st->transcribe_token; c.translate_token = st->translate_token; c.whitespace_token = st->whitespace_token;
+    c.is_multilingual = wh_is_model_multilingual(s->m);
+    c.suppress_blank = opt ? opt->suppress_blank : 0; c.prefilled_index = prefilled_index;
+    c.timestamp_rules = opt ? !opt->without_timestamps : 0; c.initial_prompt_index = initial_prompt_index;
+    c.language_filter = language_filter; c.language_token_begin = st->language_token_begin; c.n_language_tokens = st->n_language_tokens;
+    c.top_k = opt ? opt->top_k : 5;
+    int sample_length = opt ? opt->sample_length : WH_MAX_TOKEN_CONTEXT;
+    c.loop_count = std::min(sample_length, kMaxTok - 1);
+    c.has_first_token_threshold = opt && !isnan(opt->first_token_log_prob_threshold);
+    c.first_token_log_prob_threshold = opt ? opt->first_token_log_prob_threshold : 0.f;
+    c.seed = seed;
+    // createLogitsFilters: suppressTokens filtered to ids < specialTokenBegin (TextDecoder.swift:876-879)
+    std::vector<int> sup;
+    if (opt && opt->suppress_tokens)
+        for (int i = 0; i < opt->n_suppress_tokens; ++i)
+            if (opt->suppress_tokens[i] < st->special_token_begin && opt->suppress_tokens[i] >= 0) sup.push_back(opt->suppress_tokens[i]);
+    if ((int)sup.size() > kMaxSuppress) return set_error(WH_ERR_INVALID_ARGUMENT, "more than %d suppress tokens", kMaxSuppress);
+    c.n_suppress = (int)sup.size();
+    if (!sup.empty()) WH_HIP(hipMemcpyAsync(s->suppress_dev, sup.data(), sizeof(int) * sup.size(), hipMemcpyHostToDevice, s->st));
+    WH_HIP(hipMemcpyAsync(s->cfg_dev, &c, sizeof(c), hipMemcpyHostToDevice, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));   // c / sup are stack temporaries
+    return WH_OK;
+}
+
+namespace whi { int upload_sampler_cfg(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, int prefilled_index,
+                                       int initial_prompt_index, int language_filter, uint64_t seed) {
+    return upload_cfg(s, opt, st, prefilled_index, initial_prompt_index, language_filter, s->m->dims.n_vocab, seed);
+} }
+
+extern "C" int wh_filter_logits(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* tokens,
+                                int n_tokens, int prefilled_index, int initial_prompt_index, int language_filter,
+                                float* logits, int n_logits) {
+    CHECK_SESSION(s);
+    if (!st || !logits || n_logits < 1 || n_logits > s->m->dims.n_vocab || n_tokens < 0 || n_tokens > kMaxTok || (n_tokens && !tokens))
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_filter_logits: invalid argument");
+    int r = upload_cfg(s, opt, st, prefilled_index, initial_prompt_index, language_filter, n_logits, 0);
+    if (r) return r;
+    SeqState& q = s->seq_host[0];
+    memset(&q, 0, sizeof(q));
+    for (int i = 0; i < n_tokens; ++i) q.tokens[i] = tokens[i];
+    q.n_tokens = n_tokens; q.active = 1;
+    WH_HIP(hipMemcpyAsync(s->seq, &q, sizeof(SeqState), hipMemcpyHostToDevice, s->st));
+    WH_HIP(hipMemcpyAsync(s->scratch_logits, logits, sizeof(float) * n_logits, hipMemcpyHostToDevice, s->st));
+    launch_filter_only(s->cfg_dev, s->suppress_dev, s->seq, s->scratch_logits, n_logits, s->st);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipMemcpyAsync(logits, s->scratch_logits, sizeof(float) * n_logits, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+extern "C" int wh_sample_token(wh_session* s, const float* logits, int n_logits, float temperature, int top_k, uint64_t seed,
+                               int counter, int32_t* token_out, float* logprob_out) {
+    CHECK_SESSION(s);
+    if (!logits || !token_out || !logprob_out || n_logits < 1 || n_logits > s->m->dims.n_vocab)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_sample_token: invalid argument");
+    wh_decoding_options o;
+    wh_decoding_options_default(&o);
+    o.top_k = top_k; o.without_timestamps = 1;
+    wh_special_tokens st{};
+    int r = upload_cfg(s, &o, &st, 0, 0, 0, n_logits, seed);
+    if (r) return r;
+    SeqState& q = s->seq_host[0];
+    memset(&q, 0, sizeof(q));
+    q.active = 1; q.temperature = temperature;
+    WH_HIP(hipMemcpyAsync(s->seq, &q, sizeof(SeqState), hipMemcpyHostToDevice, s->st));
+    WH_HIP(hipMemcpyAsync(s->scratch_logits, logits, sizeof(float) * n_logits, hipMemcpyHostToDevice, s->st));
+    launch_sample_only(s->cfg_dev, s->seq, s->scratch_logits, n_logits, counter, s->tok_out_dev, s->lp_out_dev, s->st);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipMemcpyAsync(token_out, s->tok_out_dev, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipMemcpyAsync(logprob_out, s->lp_out_dev, sizeof(float), hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}

@@ -1,0 +1,53 @@
+// Shared device/host helpers for the gfx950 Whisper kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WAVE 64
+
+namespace wh {
+
+constexpr int kWindowSamples = 480000;
+constexpr int kFrames = 3000;     // mel frames per window
+constexpr int kFramesPad = 3002;  // time-major mel / conv1 output carry one zero row before and after (conv padding=1)
+constexpr int kCtx = 1500;        // encoder positions
+constexpr int kCtxPad = 1536;     // V^T rows padded to a multiple of 64 keys
+constexpr int kMaxTok = 224;      // decoder positions (Constants.maxTokenContext)
+constexpr int kHeadDim = 64;
+constexpr int kNFFT = 400;
+constexpr int kHop = 160;
+constexpr int kBins = 201;
+constexpr int kBinsPad = 208;     // 13 MFMA column tiles of 16
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU, activation_function="gelu" in Whisper
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// monotone float <-> uint key for atomicMax on floats of either sign
+__device__ __forceinline__ unsigned float_key(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+}  // namespace wh

@@ -1,0 +1,711 @@
+// Host-side restatement (C++) of the reference's Swift orchestration around the model stages:
+//   TextDecoder.decodeText / detectLanguage / prefillDecoderInputs  (Core/TextDecoder.swift)
+//   TranscribeTask.run / decodeWithFallback                        (Core/TranscribeTask.swift)
+//   SegmentSeeker.findSeekPointAndSegments / dynamicTimeWarping    (Core/Text/SegmentSeeker.swift)
+//   DecodingFallback, TextUtilities.compressionRatio, EnergyVAD, VADAudioChunker, prepareSeekClips
+// The token loop itself runs on the device (decoder.hip); this file drives it with replayed hipGraphs
+// (one graph = kStepsPerGraph decoder steps, no host round trip inside) and turns the device-side
+// SeqState into the reference's DecodingResult / TranscriptionSegment values.
+#include <math.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <tuple>
+
+#include "internal.h"
+
+using namespace wh;
+using whi::set_error;
+
+namespace whi {
+int upload_sampler_cfg(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, int prefilled_index,
+                       int initial_prompt_index, int language_filter, uint64_t seed);
+}
+
+#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); } while (0)
+#define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
+
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static inline float f16_round(float v) { return (float)(_Float16)v; }   // FloatType == Float16 on arm64 (ArgmaxCore/FloatType.swift:9-13)
+
+// ------------------------------------------------------------------------------------------------ small utilities
+extern "C" float wh_compression_ratio(const int32_t* tokens, int n) {
+    // TextUtilities.compressionRatio(of: [Int]): bytes of the Int32 array / bytes of NSData.compressed(using: .zlib)
+    // (raw DEFLATE, level 5).  Empty data -> compression throws -> +inf.
+    if (!tokens || n <= 0) return INFINITY;
+    uLong src_len = (uLong)n * 4;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 5, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return INFINITY;
+    std::vector<unsigned char> outb(deflateBound(&zs, src_len) + 16);
+    zs.next_in = (Bytef*)tokens; zs.avail_in = src_len; zs.next_out = outb.data(); zs.avail_out = (uInt)outb.size();
+    int rc = deflate(&zs, Z_FINISH);
+    uLong clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen == 0) return INFINITY;
+    return (float)src_len / (float)clen;
+}
+
+extern "C" int wh_decoding_fallback(const wh_decoding_options* opt, int first_token_too_low, float no_speech_prob, float compression_ratio,
+                                    float avg_logprob, int32_t* needs_fallback) {
+    // DecodingFallback.init? - NOTE: order matters (Core/Models.swift:365)
+    int reason = WH_FALLBACK_NONE, need = 0;
+    if (first_token_too_low) { reason = WH_FALLBACK_FIRST_TOKEN_LOGPROB; need = 1; }
+    else if (opt && !isnan(opt->no_speech_threshold) && no_speech_prob > opt->no_speech_threshold) { reason = WH_FALLBACK_SILENCE; need = 0; }
+    else if (opt && !isnan(opt->compression_ratio_threshold) && compression_ratio > opt->compression_ratio_threshold) { reason = WH_FALLBACK_COMPRESSION_RATIO; need = 1; }
+    else if (opt && !isnan(opt->log_prob_threshold) && avg_logprob < opt->log_prob_threshold) { reason = WH_FALLBACK_LOGPROB; need = 1; }
+    if (needs_fallback) *needs_fallback = need;
+    return reason;
+}
+
+extern "C" int wh_dynamic_time_warping(const float* matrix, int rows, int cols, int32_t* text_idx, int32_t* time_idx, int capacity) {
+    // SegmentSeeker.dynamicTimeWarping: cost in Double over -matrix, strict-less tie-breaking (diag, up, else left), backtrace.
+    if (!matrix || rows < 1 || cols < 1) return -1;
+    const size_t W = (size_t)cols + 1;
+    std::vector<double> cost((size_t)(rows + 1) * W, INFINITY);
+    std::vector<signed char> trace((size_t)(rows + 1) * W, -1);
+    cost[0] = 0;
+    for (int j = 1; j <= cols; ++j) trace[j] = 2;
+    for (int i = 1; i <= rows; ++i) trace[(size_t)i * W] = 1;
+    for (int r = 1; r <= rows; ++r) {
+        const double* cp = &cost[(size_t)(r - 1) * W];
+        double* cc = &cost[(size_t)r * W];
+        signed char* tr = &trace[(size_t)r * W];
+        const float* mv = matrix + (size_t)(r - 1) * cols;
+        for (int c = 1; c <= cols; ++c) {
+            double v = -(double)mv[c - 1];
+            double c0 = cp[c - 1] + v, c1 = cp[c] + v, c2 = cc[c - 1] + v;
+            if (c0 < c1 && c0 < c2) { cc[c] = c0; tr[c] = 0; }
+            else if (c1 < c0 && c1 < c2) { cc[c] = c1; tr[c] = 1; }
+            else { cc[c] = c2; tr[c] = 2; }
+        }
+    }
+    std::vector<int> ti, tj;
+    int i = rows, j = cols;
+    while (i > 0 || j > 0) {
+        ti.push_back(i - 1); tj.push_back(j - 1);
+        int t = trace[(size_t)i * W + j];
+        if (t == 0) { --i; --j; } else if (t == 1) --i; else if (t == 2) --j; else break;
+    }
+    int n = (int)ti.size();
+    if (text_idx && time_idx) {
+        if (n > capacity) return -n;
+        for (int k = 0; k < n; ++k) { text_idx[k] = ti[n - 1 - k]; time_idx[k] = tj[n - 1 - k]; }
+    }
+    return n;
+}
+
+extern "C" int wh_vad_voice_activity(const float* pcm, int n, int frame_len, int frame_overlap, float thr, uint8_t* out, int capacity) {
+    // EnergyVAD.voiceActivity -> AudioProcessor.calculateVoiceActivityInChunks (vDSP_rmsqv per frame > threshold)
+    if (n < 0 || frame_len <= 0 || (n > 0 && !pcm)) return -1;
+    int count = (int)((n + (long long)frame_len - 1) / frame_len);
+    if (!out) return count;
+    if (count > capacity) return -count;
+    for (int i = 0; i < count; ++i) {
+        long long s0 = (long long)i * frame_len, e0 = std::min<long long>(s0 + frame_len + frame_overlap, n);
+        double acc = 0;
+        for (long long k = s0; k < e0; ++k) acc += (double)pcm[k] * pcm[k];
+        float rms = e0 > s0 ? (float)sqrt(acc / (double)(e0 - s0)) : 0.0f;
+        out[i] = rms > thr ? 1 : 0;
+    }
+    return count;
+}
+
+static std::vector<std::pair<int, int>> prepare_seek_clips(const wh_decoding_options* opt, int content_frames) {
+    // DecodingOptions.prepareSeekClips (Utilities/Extensions+Internal.swift:112-130)
+    std::vector<int> pts;
+    if (opt && opt->clip_timestamps)
+        for (int i = 0; i < opt->n_clip_timestamps; ++i) pts.push_back((int)roundf(opt->clip_timestamps[i] * (float)WH_SAMPLE_RATE));
+    if (pts.empty()) pts.push_back(0);
+    if (pts.size() % 2 == 1) pts.push_back(content_frames);
+    std::vector<std::pair<int, int>> clips;
+    for (size_t i = 0; i < pts.size(); i += 2) clips.push_back({pts[i], i + 1 < pts.size() ? pts[i + 1] : content_frames});
+    return clips;
+}
+
+static bool longest_silence(const std::vector<uint8_t>& v, int* s0, int* e0) {   // VoiceActivityDetector.findLongestSilence
+    int best = 0;
+    bool found = false;
+    size_t i = 0;
+    while (i < v.size()) {
+        if (v[i]) { ++i; continue; }
+        size_t e = i;
+        while (e < v.size() && !v[e]) ++e;
+        if ((int)(e - i) > best) { best = (int)(e - i); *s0 = (int)i; *e0 = (int)e; found = true; }
+        i = e;
+    }
+    return found;
+}
+
+extern "C" int wh_vad_chunk_all(const float* pcm, int n, int max_chunk, const wh_decoding_options* opt, int32_t* cs, int32_t* ce, int capacity) {
+    // VADAudioChunker.chunkAll (Core/Audio/AudioChunker.swift:66-107), EnergyVAD() defaults, windowPadding 16000
+    if (n < 0 || max_chunk <= 0 || (n > 0 && !pcm)) return -1;
+    std::vector<std::pair<int, int>> out;
+    const int frame = (int)(0.1f * (float)WH_SAMPLE_RATE), window_padding = 16000;
+    if (n <= max_chunk) out.push_back({0, n});
+    else {
+        for (auto clip : prepare_seek_clips(opt, n)) {
+            int start = clip.first;
+            while (start < clip.second - window_padding) {
+                if (start < 0 || start >= n) return -1;
+                int end = clip.second;
+                if ((long long)start + max_chunk < end) {
+                    int e = std::min(n, start + max_chunk);
+                    int mid = start + (e - start) / 2;
+                    int cnt = wh_vad_voice_activity(pcm + mid, e - mid, frame, 0, 0.02f, nullptr, 0);
+                    std::vector<uint8_t> va(cnt);
+                    wh_vad_voice_activity(pcm + mid, e - mid, frame, 0, 0.02f, va.data(), cnt);
+                    int s0, e0;
+                    if (longest_silence(va, &s0, &e0)) end = mid + (s0 + (e0 - s0) / 2) * frame;
+                    else end = e;
+                }
+                if (!(end > start)) break;
+                out.push_back({start, end});
+                start = end;
+            }
+        }
+    }
+    if (cs && ce) {
+        if ((int)out.size() > capacity) return -(int)out.size();
+        for (size_t i = 0; i < out.size(); ++i) { cs[i] = out[i].first; ce[i] = out[i].second; }
+    }
+    return (int)out.size();
+}
+
+// ------------------------------------------------------------------------------------------------ prompt
+extern "C" int wh_prefill_prompt(const wh_model* m, const wh_decoding_options* opt, const wh_special_tokens* st, int32_t language_token,
+                                 int32_t* out, int capacity) {
+    // prefillDecoderInputs (Core/TextDecoder.swift:163-216)
+    if (!m || !st || !out) return -1;
+    std::vector<int> p{st->start_of_transcript_token};
+    if (opt) {
+        if (wh_is_model_multilingual(m)) {
+            p.push_back(language_token >= 0 ? language_token : st->english_token);
+            p.push_back(opt->task == 1 ? st->translate_token : st->transcribe_token);
+        }
+        p.push_back(opt->without_timestamps ? st->no_timestamps_token : st->time_token_begin);
+        if (opt->prompt_tokens) {
+            const int maxPromptLen = (WH_MAX_TOKEN_CONTEXT / 2) - 1;
+            int n = opt->n_prompt_tokens, from = std::max(0, n - maxPromptLen);
+            std::vector<int> t{st->start_of_previous_token};
+            for (int i = from; i < n; ++i) if (opt->prompt_tokens[i] < st->special_token_begin) t.push_back(opt->prompt_tokens[i]);
+            t.insert(t.end(), p.begin(), p.end());
+            p.swap(t);
+        }
+        if (opt->prefix_tokens) {
+            int n = opt->n_prefix_tokens, from = std::max(0, n - WH_MAX_TOKEN_CONTEXT / 2);
+            for (int i = from; i < n; ++i) if (opt->prefix_tokens[i] < st->special_token_begin) p.push_back(opt->prefix_tokens[i]);
+        }
+    }
+    if ((int)p.size() > capacity) return -(int)p.size();
+    for (size_t i = 0; i < p.size(); ++i) out[i] = p[i];
+    return (int)p.size();
+}
+
+// ------------------------------------------------------------------------------------------------ decodeText
+namespace whi {
+void finalize_decoding_result(const SeqState& sq, const wh_decoding_options* opt, const wh_special_tokens* st, float temperature,
+                              wh_decoding_result* out) {
+    // TextDecoder.swift:776-854: finalize (append EOT), slice SOT...EOT, avg log prob, compression ratio, fallback
+    memset(out, 0, sizeof(*out));
+    std::vector<int> tok(sq.tokens, sq.tokens + sq.n_tokens);
+    std::vector<float> lp(sq.logprobs, sq.logprobs + sq.n_tokens);
+    if (tok.empty() || tok.back() != st->end_token) { tok.push_back(st->end_token); lp.push_back(0.0f); }
+    int start = 0, end = (int)tok.size();
+    for (int i = 0; i < (int)tok.size(); ++i) if (tok[i] == st->start_of_transcript_token) { start = i; break; }
+    for (int i = 0; i < (int)tok.size(); ++i) if (tok[i] == st->end_token) { end = i; break; }
+    if (end < start) end = (int)tok.size() - 1;
+    int n = std::min(end - start + 1, WH_MAX_RESULT_TOKENS);
+    float sum = 0.0f;
+    std::vector<int32_t> words;
+    out->language_token = -1;
+    for (int i = 0; i < n; ++i) {
+        out->tokens[i] = tok[start + i];
+        out->token_logprobs[i] = lp[start + i];
+        sum += lp[start + i];
+        if (tok[start + i] < st->special_token_begin) words.push_back(tok[start + i]);
+        if (out->language_token < 0 && tok[start + i] >= st->language_token_begin && tok[start + i] < st->language_token_begin + st->n_language_tokens)
+            out->language_token = tok[start + i];
+    }
+    out->n_tokens = n;
+    out->avg_logprob = sum / (float)n;
+    out->compression_ratio = wh_compression_ratio(words.data(), (int)words.size());
+    out->no_speech_prob = 0.0f;   // TextDecoder.swift:802 (TODO in the reference)
+    out->temperature = roundf(f16_round(temperature) * 1000.0f) / 1000.0f;   // Float(sampler.temperature).rounded(3)
+    out->is_first_token_logprob_too_low = sq.first_token_too_low;
+    out->steps = sq.steps;
+    out->fallback_reason = wh_decoding_fallback(opt, sq.first_token_too_low, out->no_speech_prob, out->compression_ratio, out->avg_logprob,
+                                                &out->needs_fallback);
+}
+}  // namespace whi
+
+constexpr int kStepsPerGraph = 8;
+
+struct GraphKey {
+    int batch, align;
+    bool operator<(const GraphKey& o) const { return std::tie(batch, align) < std::tie(o.batch, o.align); }
+};
+struct SessionGraphs { std::map<GraphKey, hipGraphExec_t> g; };
+static std::map<wh_session*, SessionGraphs>& graph_cache() { static std::map<wh_session*, SessionGraphs> c; return c; }
+
+static bool use_graphs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("WH_NO_GRAPH"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+
+static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
+    GraphKey key{batch, s->align_enabled ? 1 : 0};
+    auto& cache = graph_cache()[s].g;
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = it->second; return WH_OK; }
+    DecodeBuffers db = whi::decode_buffers(s, batch);
+    hipGraph_t graph;
+    WH_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < kStepsPerGraph; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
+    WH_HIP(hipStreamEndCapture(s->st, &graph));
+    hipGraphExec_t exec;
+    WH_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    cache[key] = exec;
+    *out = exec;
+    return WH_OK;
+}
+
+namespace whi {
+void drop_session_graphs(wh_session* s) {
+    auto it = graph_cache().find(s);
+    if (it == graph_cache().end()) return;
+    for (auto& kv : it->second.g) hipGraphExecDestroy(kv.second);
+    graph_cache().erase(it);
+}
+}
+
+static int run_token_loop(wh_session* s, int batch, int loop_count) {
+    // every slot's state lives on the device; the host only replays step graphs and polls the done flags
+    const size_t bytes = sizeof(SeqState) * batch;
+    auto all_done = [&]() { for (int b = 0; b < batch; ++b) if (s->seq_host[b].active && !s->seq_host[b].done) return false; return true; };
+    if (use_graphs()) {
+        hipGraphExec_t exec;
+        int r = get_step_graph(s, batch, &exec);
+        if (r) return r;
+        const int n_graphs = (loop_count + kStepsPerGraph - 1) / kStepsPerGraph;
+        for (int g = 0; g < n_graphs; ++g) {
+            WH_HIP(hipGraphLaunch(exec, s->st));
+            // snapshot the slot states behind graph g; while it runs, look at the snapshot behind graph g-1
+            // (at most one graph of run-ahead; `done` is monotonic, so a torn snapshot is harmless)
+            WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
+            WH_HIP(hipEventRecord(s->ev[g & 1], s->st));
+            if (g >= 1) {
+                WH_HIP(hipEventSynchronize(s->ev[(g - 1) & 1]));
+                if (all_done()) break;
+            }
+        }
+    } else {
+        DecodeBuffers db = whi::decode_buffers(s, batch);
+        for (int step = 0; step < loop_count; ++step) {
+            launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
+            WH_CHECK_LAUNCH();
+            if ((step & 7) == 7 && step + 1 < loop_count) {
+                WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
+                WH_HIP(hipStreamSynchronize(s->st));
+                if (all_done()) break;
+            }
+        }
+    }
+    WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+extern "C" int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                              int n_prompt, const float* temperatures, const int32_t* active, uint64_t seed, wh_decoding_result* out) {
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    if (!opt || !st || !prompt || !out) return set_error(WH_ERR_DECODING_FAILED, "wh_decode_text: null argument");
+    if (n_prompt < 1 || n_prompt >= kMaxTok) return set_error(WH_ERR_PREFILL_FAILED, "wh_decode_text: prompt length %d out of range [1,%d)", n_prompt, kMaxTok);
+    const int V = s->m->dims.n_vocab;
+    for (int i = 0; i < n_prompt; ++i)
+        if (prompt[i] < 0 || prompt[i] >= V) return set_error(WH_ERR_PREFILL_FAILED, "wh_decode_text: prompt token %d out of vocabulary", prompt[i]);
+    const int prefilled_index = 0;   // decoderInputs.cacheLength after reset (Core/Models.swift:313)
+    int r = whi::upload_sampler_cfg(s, opt, st, prefilled_index, n_prompt, 0, seed);
+    if (r) return r;
+    if (opt->word_timestamps && s->m->n_align > 0 && !s->align) {
+        size_t n = (size_t)s->B * kMaxTok * s->m->n_align * kCtx;
+        WH_HIP(hipMalloc((void**)&s->align, n * sizeof(float)));
+        WH_HIP(hipMemsetAsync(s->align, 0, n * sizeof(float), s->st));
+    }
+    s->align_enabled = opt->word_timestamps && s->align;
+    for (int b = 0; b < batch; ++b) {
+        SeqState& q = s->seq_host[b];
+        memset(&q, 0, sizeof(q));
+        for (int i = 0; i < n_prompt; ++i) q.tokens[i] = prompt[i];
+        q.n_tokens = n_prompt; q.token_index = prefilled_index; q.next_token = prompt[0]; q.prompt_len = n_prompt;
+        q.active = active ? (active[b] != 0) : 1;
+        q.temperature = f16_round(temperatures ? temperatures[b] : opt->temperature);
+    }
+    WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
+    const int loop_count = std::min(opt->sample_length, kMaxTok - 1);
+    r = run_token_loop(s, batch, std::max(loop_count, 0));
+    if (r) return r;
+    for (int b = 0; b < batch; ++b) {
+        if (!s->seq_host[b].active) { memset(&out[b], 0, sizeof(out[b])); continue; }
+        whi::finalize_decoding_result(s->seq_host[b], opt, st, s->seq_host[b].temperature, &out[b]);
+    }
+    return WH_OK;
+}
+
+extern "C" int wh_detect_language(wh_session* s, int batch, const wh_special_tokens* st, int32_t* lang_out, float* lp_out) {
+    // TextDecoder.detectLanguage: one step on SOT at position 0, LanguageLogitsFilter, greedy sample (no KV/state update)
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    if (!st || !lang_out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_detect_language: null argument");
+    wh_decoding_options o;
+    wh_decoding_options_default(&o);
+    int r = whi::upload_sampler_cfg(s, &o, st, 0, 0, 1, 0);
+    if (r) return r;
+    for (int b = 0; b < batch; ++b) {
+        SeqState& q = s->seq_host[b];
+        memset(&q, 0, sizeof(q));
+        q.tokens[0] = st->start_of_transcript_token; q.n_tokens = 1; q.next_token = st->start_of_transcript_token; q.active = 1;
+    }
+    WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
+    bool keep = s->align_enabled;
+    s->align_enabled = false;
+    DecodeBuffers db = whi::decode_buffers(s, batch);
+    s->align_enabled = keep;
+    launch_decoder_step(db, nullptr, nullptr, false, s->st);
+    launch_filter_sample(s->cfg_dev, s->suppress_dev, s->seq, s->logits, batch, s->tok_out_dev, s->lp_out_dev, s->st);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipMemcpyAsync(lang_out, s->tok_out_dev, sizeof(int) * batch, hipMemcpyDeviceToHost, s->st));
+    std::vector<float> lp(batch);
+    WH_HIP(hipMemcpyAsync(lp.data(), s->lp_out_dev, sizeof(float) * batch, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    if (lp_out) for (int b = 0; b < batch; ++b) lp_out[b] = lp[b];
+    return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ segments
+extern "C" int wh_find_seek_point_and_segments(const wh_decoding_result* res, const wh_decoding_options* opt, const wh_special_tokens* st,
+                                               int all_segments_count, int current_seek, int segment_size, int32_t* new_seek,
+                                               wh_segment* segs, int capacity) {
+    // SegmentSeeker.findSeekPointAndSegments (Core/Text/SegmentSeeker.swift:41-189); token_offset indexes res->tokens
+    if (!res || !opt || !st || !new_seek) return -2;
+    const int timeToken = st->time_token_begin;
+    const float spt = 0.02f;   // WhisperKit.secondsPerTimeToken
+    int seek = current_seek;
+    const float timeOffset = (float)seek / (float)WH_SAMPLE_RATE;
+    if (!isnan(opt->no_speech_threshold)) {
+        bool skip = res->no_speech_prob > opt->no_speech_threshold;
+        if (!isnan(opt->log_prob_threshold) && res->avg_logprob > opt->log_prob_threshold) skip = false;
+        if (skip) { *new_seek = seek + segment_size; return -1; }
+    }
+    const int n = res->n_tokens;
+    std::vector<char> isTs(n);
+    for (int i = 0; i < n; ++i) isTs[i] = res->tokens[i] >= timeToken;
+    auto last3 = [&](bool a, bool b, bool c) { return n >= 3 && isTs[n - 3] == a && isTs[n - 2] == b && isTs[n - 1] == c; };
+    const bool single = last3(false, true, false), none = last3(false, false, false);
+    std::vector<int> slices;
+    bool prev = false;
+    for (int i = 0; i < n; ++i) { if (prev && isTs[i]) slices.push_back(i); prev = isTs[i]; }
+    std::vector<wh_segment> out;
+    auto mk = [&](int off, int cnt, float start, float end) {
+        wh_segment g{};
+        g.id = all_segments_count + (int)out.size(); g.seek = current_seek; g.start = start; g.end = end; g.token_offset = off; g.n_tokens = cnt;
+        g.temperature = res->temperature; g.avg_logprob = res->avg_logprob; g.compression_ratio = res->compression_ratio; g.no_speech_prob = res->no_speech_prob;
+        out.push_back(g);
+    };
+    if (!slices.empty()) {
+        if (single) { int li = 0; for (int i = 0; i < n; ++i) if (isTs[i]) li = i; slices.push_back(li + 1); }
+        else if (none) slices.push_back(n);
+        int lastStart = 0;
+        for (int e : slices) {
+            int first = -1, last = -1;
+            for (int i = lastStart; i < e; ++i) if (res->tokens[i] >= timeToken) { if (first < 0) first = res->tokens[i]; last = res->tokens[i]; }
+            mk(lastStart, e - lastStart, timeOffset + (float)(first - timeToken) * spt, timeOffset + (float)(last - timeToken) * spt);
+            lastStart = e;
+        }
+        if (!none) {
+            int lt = res->tokens[lastStart - (single ? 1 : 0)] - timeToken;
+            seek += (int)((float)lt * spt * (float)WH_SAMPLE_RATE);
+        } else seek += segment_size;
+    } else {
+        float dur = (float)segment_size / (float)WH_SAMPLE_RATE;
+        for (int i = 0; i < n; ++i) if (res->tokens[i] > timeToken) dur = (float)(res->tokens[i] - timeToken) * spt;
+        mk(0, n, timeOffset, timeOffset + dur);
+        seek += segment_size;
+    }
+    *new_seek = seek;
+    if (segs) {
+        if ((int)out.size() > capacity) return -2;
+        for (size_t i = 0; i < out.size(); ++i) segs[i] = out[i];
+    }
+    return (int)out.size();
+}
+
+// ------------------------------------------------------------------------------------------------ TranscribeTask.run
+struct wh_transcription {
+    std::vector<wh_segment> segments;
+    std::vector<wh_word_timing> words;
+    std::vector<int32_t> tokens;
+    std::vector<float> logprobs;
+    std::vector<int32_t> seeks;
+    int language_token = -1;
+    wh_timings timings{};
+};
+
+struct AudioJob {
+    const float* pcm; int n;
+    std::vector<std::pair<int, int>> clips;
+    size_t clip = 0; int seek = 0; bool started = false; bool finished = false;
+    int windows = 0;
+    wh_transcription* tr;
+    int cur_seek = 0, cur_size = 0;   // window in flight
+};
+
+static bool job_next_window(AudioJob& j, const wh_decoding_options* opt) {
+    // advance to the next (clip, seek) that satisfies `seek < clipEnd - windowPadding` (TranscribeTask.swift:105-116)
+    const int windowPadding = (int)(opt->window_clip_time * (float)WH_SAMPLE_RATE);
+    while (j.clip < j.clips.size()) {
+        if (!j.started) { j.seek = j.clips[j.clip].first; j.started = true; }
+        if (j.seek < j.clips[j.clip].second - windowPadding) {
+            j.cur_seek = j.seek;
+            j.cur_size = std::min({kWindowSamples, j.n - j.seek, j.clips[j.clip].second - j.seek});
+            return true;
+        }
+        ++j.clip; j.started = false;
+    }
+    j.finished = true;
+    return false;
+}
+
+static void add_word_timestamps(wh_session* s, int slot, const wh_decoding_result& res, const wh_special_tokens* st, wh_transcription* tr,
+                                size_t seg_begin, int seek) {
+    // SegmentSeeker.addWordTimestamps (:410-496) with the token-per-word splitter: the image has no tokenizer.json, so words
+    // cannot be grouped by text; each text token becomes one word timed by DTW over its alignment row (findAlignment :340-408).
+    std::vector<float> full((size_t)kMaxTok * kCtx);
+    if (wh_get_alignment_weights(s, slot, full.data()) != WH_OK) return;
+    const int n = res.n_tokens;
+    std::vector<float> mat((size_t)n * kCtx);
+    for (int i = 0; i < n; ++i) memcpy(&mat[(size_t)i * kCtx], &full[(size_t)i * kCtx], sizeof(float) * kCtx);   // rows of the result tokens
+    int cap = n + kCtx + 8;
+    std::vector<int32_t> ti(cap), tj(cap);
+    int len = wh_dynamic_time_warping(mat.data(), n, kCtx, ti.data(), tj.data(), cap);
+    if (len <= 0) return;
+    std::vector<float> startT{0.0f}, endT;
+    int cur = ti[0];
+    for (int k = 0; k < len; ++k)
+        if (ti[k] != cur) { cur = ti[k]; float t = (float)tj[k] * 0.02f; startT.push_back(t); endT.push_back(t); }
+    endT.push_back((float)tj[len - 1] * 0.02f);
+    const float timeOffset = (float)seek / (float)WH_SAMPLE_RATE;
+    for (size_t si = seg_begin; si < tr->segments.size(); ++si) {
+        wh_segment& g = tr->segments[si];
+        g.word_offset = (int)tr->words.size();
+        for (int k = 0; k < g.n_tokens; ++k) {
+            int ri = (g.token_offset - (int)(tr->tokens.size() - res.n_tokens)) + k;   // index into the window's token list
+            if (ri < 0 || ri >= n || ri >= (int)startT.size() || ri >= (int)endT.size()) continue;
+            if (res.tokens[ri] >= st->special_token_begin) continue;
+            wh_word_timing w{};
+            w.token_offset = g.token_offset + k; w.n_tokens = 1;
+            w.start = roundf((timeOffset + startT[ri]) * 100.0f) / 100.0f;
+            w.end = roundf((timeOffset + endT[ri]) * 100.0f) / 100.0f;
+            w.probability = roundf(expf(res.token_logprobs[ri]) * 100.0f) / 100.0f;
+            tr->words.push_back(w);
+        }
+        g.n_words = (int)tr->words.size() - g.word_offset;
+    }
+}
+
+static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_decoding_options* opt, const wh_special_tokens* st) {
+    const wh_model* m = s->m;
+    const bool multilingual = wh_is_model_multilingual(m) != 0;
+    const int detect = opt->detect_language < 0 ? !opt->use_prefill_prompt : opt->detect_language;
+    const double t_start = now_s();
+    for (auto& j : jobs) { j.clips = prepare_seek_clips(opt, j.n); j.tr->timings.input_audio_seconds = (double)j.n / WH_SAMPLE_RATE; }
+    // temperature ladder in FloatType (TranscribeTask.swift:327)
+    std::vector<float> temps;
+    for (int i = 0; i <= opt->temperature_fallback_count; ++i)
+        temps.push_back(f16_round(f16_round(opt->temperature) + f16_round(f16_round((float)i) * f16_round(opt->temperature_increment_on_fallback))));
+
+    std::vector<int> slot_job;   // job index per slot for the current round
+    while (true) {
+        // gather up to B jobs that still have a window (each job contributes one window per round: windows of one audio are sequential)
+        slot_job.clear();
+        for (size_t ji = 0; ji < jobs.size() && (int)slot_job.size() < s->B; ++ji)
+            if (!jobs[ji].finished && job_next_window(jobs[ji], opt)) slot_job.push_back((int)ji);
+        if (slot_job.empty()) break;
+        const int nb = (int)slot_job.size();
+        double t0 = now_s();
+        for (int b = 0; b < nb; ++b) {
+            AudioJob& j = jobs[slot_job[b]];
+            int r = wh_set_audio(s, b, j.pcm + j.cur_seek, j.cur_size);   // padOrTrim (TranscribeTask.swift:126-127)
+            if (r) return r;
+            j.tr->seeks.push_back(j.cur_seek);
+        }
+        double t1 = now_s();
+        int r = wh_log_mel_spectrogram(s, nb); if (r) return r;
+        hipStreamSynchronize(s->st);
+        double t2 = now_s();
+        r = wh_encode_features(s, nb); if (r) return r;
+        r = wh_prepare_decoder_inputs(s, nb); if (r) return r;
+        hipStreamSynchronize(s->st);
+        double t3 = now_s();
+        // ---- decodeWithFallback (TranscribeTask.swift:316-411), all slots in lock step per temperature
+        std::vector<wh_decoding_result> res(nb), tmp(nb);
+        std::vector<int32_t> active(nb, 1);
+        std::vector<int32_t> prompt(kMaxPrompt);
+        int n_prompt = 1;
+        prompt[0] = st->start_of_transcript_token;
+        int lang_tok = opt->language_token;
+        for (size_t ti = 0; ti < temps.size(); ++ti) {
+            std::vector<float> tv(nb, temps[ti]);
+            if (multilingual && opt->language_token < 0 && detect) {
+                // detectLanguage runs once per window on slot order; the prompt is shared by the lock-stepped slots, so the
+                // language of the first active slot is used for this round (single-audio calls: exact reference behaviour)
+                std::vector<int32_t> lt(nb); std::vector<float> ll(nb);
+                r = wh_detect_language(s, nb, st, lt.data(), ll.data()); if (r) return r;
+                for (int b = 0; b < nb; ++b) if (active[b]) { lang_tok = lt[b]; break; }
+                for (int b = 0; b < nb; ++b) if (jobs[slot_job[b]].tr->language_token < 0) jobs[slot_job[b]].tr->language_token = lt[b];
+            }
+            if (opt->use_prefill_prompt) {
+                n_prompt = wh_prefill_prompt(m, opt, st, lang_tok, prompt.data(), (int)prompt.size());
+                if (n_prompt <= 0) return set_error(WH_ERR_PREFILL_FAILED, "prefill prompt does not fit");
+            }
+            r = wh_reset_decoder_inputs(s, nb); if (r) return r;
+            uint64_t seed = opt->seed + 1000003ull * (uint64_t)jobs[slot_job[0]].windows + ti;
+            r = wh_decode_text(s, nb, opt, st, prompt.data(), n_prompt, tv.data(), active.data(), seed, tmp.data()); if (r) return r;
+            bool any = false;
+            for (int b = 0; b < nb; ++b) {
+                if (!active[b]) continue;
+                res[b] = tmp[b];
+                AudioJob& j = jobs[slot_job[b]];
+                j.tr->timings.total_decoding_loops += tmp[b].steps;
+                if (tmp[b].needs_fallback && ti + 1 < temps.size()) { any = true; j.tr->timings.total_decoding_fallbacks += 1; }
+                else active[b] = 0;
+            }
+            if (!any) break;
+        }
+        double t4 = now_s();
+        // ---- windowing (TranscribeTask.swift:175-278)
+        for (int b = 0; b < nb; ++b) {
+            AudioJob& j = jobs[slot_job[b]];
+            wh_transcription* tr = j.tr;
+            if (tr->language_token < 0 && res[b].language_token >= 0) tr->language_token = res[b].language_token;
+            wh_segment segs[WH_MAX_RESULT_TOKENS];
+            int new_seek = j.seek;
+            int ns = wh_find_seek_point_and_segments(&res[b], opt, st, (int)tr->segments.size(), j.seek, j.cur_size, &new_seek, segs, WH_MAX_RESULT_TOKENS);
+            const int prev_seek = j.seek;
+            j.seek = std::max(j.seek, new_seek);
+            const size_t seg_begin = tr->segments.size();
+            if (ns >= 0) {
+                const int base = (int)tr->tokens.size();
+                for (int i = 0; i < res[b].n_tokens; ++i) { tr->tokens.push_back(res[b].tokens[i]); tr->logprobs.push_back(res[b].token_logprobs[i]); }
+                for (int i = 0; i < ns; ++i) { segs[i].token_offset += base; tr->segments.push_back(segs[i]); }
+                if (opt->word_timestamps && s->align) {
+                    add_word_timestamps(s, b, res[b], st, tr, seg_begin, prev_seek);
+                    // TranscribeTask.swift:217-223: drop zero-length segments, refine the seek with the last word end
+                }
+                tr->timings.total_decoding_windows += 1;
+                j.windows += 1;
+            }
+            if (opt->max_window_seek >= 0) j.seek = std::min(j.seek, prev_seek + opt->max_window_seek);
+            tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
+            tr->timings.decoding_loop += (t4 - t3) / nb; tr->timings.total_logmel_runs += 1; tr->timings.total_encoding_runs += 1;
+        }
+    }
+    for (auto& j : jobs) j.tr->timings.full_pipeline = now_s() - t_start;
+    return WH_OK;
+}
+
+extern "C" int wh_transcribe_batch(wh_session* s, const float* const* pcm, const int32_t* n_samples, int n_audio,
+                                   const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out) {
+    CHECK_SESSION(s);
+    if (!pcm || !n_samples || n_audio < 1 || !opt || !st || !out) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcribe_batch: null argument");
+    std::vector<AudioJob> jobs(n_audio);
+    for (int i = 0; i < n_audio; ++i) {
+        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "audio %d: invalid buffer", i);
+        jobs[i].pcm = pcm[i]; jobs[i].n = n_samples[i]; jobs[i].tr = new wh_transcription();
+    }
+    int r = transcribe_jobs(s, jobs, opt, st);
+    for (int i = 0; i < n_audio; ++i) {
+        if (r) { delete jobs[i].tr; out[i] = nullptr; } else out[i] = jobs[i].tr;
+    }
+    return r;
+}
+
+extern "C" int wh_transcribe(wh_session* s, const float* pcm, int n, const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out) {
+    const float* p[1] = {pcm};
+    int32_t nn[1] = {n};
+    return wh_transcribe_batch(s, p, nn, 1, opt, st, out);
+}
+
+extern "C" void wh_transcription_free(wh_transcription* t) { delete t; }
+extern "C" int wh_transcription_n_segments(const wh_transcription* t) { return t ? (int)t->segments.size() : -1; }
+extern "C" int wh_transcription_segment(const wh_transcription* t, int i, wh_segment* out) {
+    if (!t || !out || i < 0 || i >= (int)t->segments.size()) return set_error(WH_ERR_INVALID_ARGUMENT, "segment index out of range");
+    *out = t->segments[i];
+    return WH_OK;
+}
+extern "C" int wh_transcription_n_words(const wh_transcription* t) { return t ? (int)t->words.size() : -1; }
+extern "C" int wh_transcription_word(const wh_transcription* t, int i, wh_word_timing* out) {
+    if (!t || !out || i < 0 || i >= (int)t->words.size()) return set_error(WH_ERR_INVALID_ARGUMENT, "word index out of range");
+    *out = t->words[i];
+    return WH_OK;
+}
+extern "C" int wh_transcription_tokens(const wh_transcription* t, const int32_t** tokens, const float** logprobs, int* n) {
+    if (!t || !n) return set_error(WH_ERR_INVALID_ARGUMENT, "null transcription");
+    if (tokens) *tokens = t->tokens.data();
+    if (logprobs) *logprobs = t->logprobs.data();
+    *n = (int)t->tokens.size();
+    return WH_OK;
+}
+extern "C" int wh_transcription_language_token(const wh_transcription* t) { return t ? t->language_token : -1; }
+extern "C" int wh_transcription_timings(const wh_transcription* t, wh_timings* out) {
+    if (!t || !out) return set_error(WH_ERR_INVALID_ARGUMENT, "null transcription");
+    *out = t->timings;
+    return WH_OK;
+}
+extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const int32_t** seeks, int* n) {
+    if (!t || !n) return set_error(WH_ERR_INVALID_ARGUMENT, "null transcription");
+    if (seeks) *seeks = t->seeks.data();
+    *n = (int)t->seeks.size();
+    return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement hook
+extern "C" int wh_measure_decoder_kernels(wh_session* s, int batch, int n_steps, double* avg_us /* [8] */, int32_t* launches /* [8] */) {
+    // Runs `n_steps` decoder steps eagerly on the session stream (state as left by the last wh_decode_text setup, re-armed here)
+    // with a HIP event pair around every kernel launch, and reports the average duration per kernel kind:
+    // 0 gemv_qkv 1 self_attn 2 gemv_cq 3 cross_attn 4 gemv_fc1 5 gemv_fc2 6 gemv_logits 7 sampler.
+    CHECK_SESSION(s); CHECK_BATCH(s, batch);
+    if (!avg_us || !launches || n_steps < 1 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_decoder_kernels: invalid argument");
+    const int L = s->m->dims.n_text_layer;
+    const int per_step = 6 * L + 2, cap = per_step * n_steps;
+    std::vector<hipEvent_t> ev(2 * (size_t)cap);
+    std::vector<int> kind(cap);
+    for (auto& e : ev) WH_HIP(hipEventCreate(&e));
+    // re-arm the slots: keep prompt/config, restart the loop at position 0
+    WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, sizeof(SeqState) * batch, hipMemcpyDeviceToHost, s->st));
+    WH_HIP(hipStreamSynchronize(s->st));
+    for (int b = 0; b < batch; ++b) {
+        SeqState& q = s->seq_host[b];
+        int pl = std::max(q.prompt_len, 1);
+        q.n_tokens = pl; q.token_index = 0; q.next_token = q.tokens[0]; q.done = 0; q.active = 1; q.steps = 0; q.first_token_too_low = 0;
+    }
+    WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
+    DecodeBuffers db = whi::decode_buffers(s, batch);
+    StepProfiler prof{ev.data(), kind.data(), cap, 0};
+    for (int i = 0; i < n_steps; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st, &prof);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipStreamSynchronize(s->st));
+    double tot[SK_COUNT] = {0};
+    int cnt[SK_COUNT] = {0};
+    for (int i = 0; i < prof.n; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { tot[kind[i]] += ms * 1000.0; cnt[kind[i]]++; }
+    }
+    for (int k = 0; k < SK_COUNT; ++k) { avg_us[k] = cnt[k] ? tot[k] / cnt[k] : 0.0; launches[k] = cnt[k]; }
+    for (auto& e : ev) hipEventDestroy(e);
+    return WH_OK;
+}

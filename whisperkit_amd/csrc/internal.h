@@ -1,0 +1,79 @@
+// Internal model / session structures behind the opaque C-ABI handles.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+#include "whisperhip.h"
+
+struct WhTensor {
+    void* dev = nullptr;
+    int dtype = 0, ndim = 0;
+    long long shape[4] = {1, 1, 1, 1};
+    size_t nbytes = 0;
+};
+
+struct EncLayerW {
+    const float *ln1_g, *ln1_b; const f16* qkv_w; const float* qkv_b;
+    const f16* o_w; const float* o_b;
+    const float *ln2_g, *ln2_b; const f16* fc1_w; const float* fc1_b; const f16* fc2_w; const float* fc2_b;
+};
+
+struct wh_model {
+    wh_dims dims{};
+    int device = 0;
+    void* blob_dev = nullptr;
+    size_t blob_bytes = 0;
+    std::unordered_map<std::string, WhTensor> t;
+    wh::MelTables mel{};
+    void* mel_tables_dev = nullptr;
+    std::vector<EncLayerW> enc;
+    std::vector<wh::DecLayerW> dec;
+    const f16 *conv1_w, *conv2_w, *emb, *ckv_w;
+    const float *conv1_b, *conv2_b, *enc_pos, *lnp_g, *lnp_b, *dec_pos, *ckv_b, *lnf_g, *lnf_b;
+    std::vector<int> align_slot;   // [L*H] -> slot or -1
+    int n_align = 0;
+    int* align_slot_dev = nullptr;
+};
+
+struct wh_session {
+    wh_model* m = nullptr;
+    int B = 0;
+    hipStream_t st = nullptr;
+    // stage buffers
+    float* pcm = nullptr; int* n_valid = nullptr;
+    float* logspec = nullptr; unsigned* maxkey = nullptr; f16* mel_t = nullptr; float* mel_f32 = nullptr;
+    f16* h1 = nullptr; float* x = nullptr; f16* xn = nullptr; f16 *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *att16 = nullptr;
+    f16* hmlp = nullptr; f16* enc16 = nullptr; float* enc32 = nullptr;
+    // decoder
+    f16* cross_kv = nullptr; f16 *self_k = nullptr, *self_v = nullptr;
+    float *xa = nullptr, *xb = nullptr, *q = nullptr, *partial = nullptr, *logits = nullptr;
+    f16* hbuf = nullptr;
+    float *align = nullptr, *align_mean = nullptr;
+    wh::SeqState* seq = nullptr;
+    wh::SeqState* seq_host = nullptr;     // pinned
+    wh::SamplerCfg* cfg_dev = nullptr;
+    int* suppress_dev = nullptr;
+    int *tok_out_dev = nullptr; float* lp_out_dev = nullptr;
+    float* scratch_logits = nullptr;       // [V] for the filter / sample KAT entry points
+    hipEvent_t ev[8]{};
+    bool align_enabled = false;
+    wh_timings last_timings{};
+};
+
+namespace whi {
+int set_error(int code, const char* fmt, ...);
+#define WH_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return whi::set_error(WH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define WH_CHECK_LAUNCH() WH_HIP(hipGetLastError())
+
+wh::DecodeBuffers decode_buffers(wh_session* s, int batch);
+void drop_session_graphs(wh_session* s);
+// host logic shared by wh_decode_text / wh_transcribe (host.hip)
+void finalize_decoding_result(const wh::SeqState& sq, const wh_decoding_options* opt, const wh_special_tokens* st,
+                              float temperature, wh_decoding_result* out);
+}  // namespace whi

@@ -1,0 +1,146 @@
+// Launcher declarations shared between the .hip kernel files and the C-ABI implementation.
+#pragma once
+#include "common.h"
+
+namespace wh {
+
+struct MelTables {
+    const float* basis_c;   // [200][208] w[n] cos(2 pi n k / 400), n = 1..200
+    const float* basis_s;   // [200][208] w[n] sin(2 pi n k / 400)
+    const float* filt;      // [201][n_mels] slaney mel filterbank
+    const int2* filt_range; // [n_mels] first / last non-zero bin
+    int n_mels;
+};
+
+void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, int batch, float* logspec, unsigned* maxkey,
+                    f16* mel_t, float* mel_f32, hipStream_t st);
+void launch_mel_import(const float* mel_f32, int n_mels, int batch, f16* mel_t, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------- GEMM
+// C[M][N] = A[M][K] * W[N][K]^T (+ bias[N]) with fused epilogues.  A rows may be an overlapping-row view:
+// address(m, k) = A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda + k.
+enum GemmEpi {
+    EPI_F16 = 0,        // out16[m*ldc + n] = v
+    EPI_GELU_F16 = 1,   // out16 = gelu(v)
+    EPI_RESID_F32 = 2,  // x32[m*ldc + n] += v                        (fp32 residual stream)
+    EPI_QKV_ENC = 3,    // n<d: q16[m*d+n]; n<2d: k16[m*d+n-d]; else V^T[(b*H+h)*64+c][t]   (encoder attention operands)
+    EPI_CONV1 = 4,      // out16[(b*3002 + t + 1)*ldc + n] = gelu(v)  (padded time-major input of conv2)
+    EPI_CONV2 = 5,      // x32[m*ldc + n] = gelu(v) + pos[t*ldc + n]
+    EPI_F32 = 6,        // out32[m*ldc + n] = v
+};
+
+struct GemmArgs {
+    const f16* A;
+    const f16* W;
+    const float* bias;   // may be null
+    int M, N, K;
+    int lda;
+    int a_rows_per_batch;      // = M for a plain matrix
+    long long a_batch_stride;  // elements
+    int ldc;
+    f16* out16;
+    float* out32;
+    // EPI_QKV_ENC
+    f16* k16;
+    f16* vt16;
+    int d_model;
+    // EPI_CONV2
+    const float* pos;
+    int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
+};
+
+void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// y = LN(x) * g + b over rows of length d; x fp32 [rows][d]; writes f16 and/or f32
+void launch_layernorm(const float* x, const float* g, const float* b, int rows, int d, f16* y16, float* y32, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------- encoder attention
+// q16,k16: [B*1500][d] (q pre-scaled), vt16: [B][H][64][1536]; out16: [B*1500][d]
+void launch_encoder_attention(const f16* q16, const f16* k16, const f16* vt16, f16* out16, int batch, int n_head, int d, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------- decoder
+struct DecLayerW {
+    const float *ln1_g, *ln1_b; const f16* qkv_w; const float* qkv_b;
+    const f16* o_w; const float* o_b;
+    const float *ln2_g, *ln2_b; const f16* cq_w; const float* cq_b;
+    const f16* co_w; const float* co_b;
+    const float *ln3_g, *ln3_b; const f16* fc1_w; const float* fc1_b; const f16* fc2_w; const float* fc2_b;
+};
+
+// filter / sampler configuration resident on the device for a decode_text call
+struct SamplerCfg {
+    int n_vocab;
+    int end_token, no_timestamps_token, time_token_begin, transcribe_token, translate_token, whitespace_token;
+    int is_multilingual;
+    int suppress_blank, prefilled_index;     // SuppressBlankFilter(sampleBegin = prefilledIndex)
+    int timestamp_rules, initial_prompt_index;
+    int language_filter, language_token_begin, n_language_tokens;
+    int n_suppress;                          // ids in SeqState-independent list `suppress`
+    int top_k;
+    int loop_count;                          // min(sampleLength, 223)
+    int has_first_token_threshold; float first_token_log_prob_threshold;
+    unsigned long long seed;
+};
+
+constexpr int kMaxSuppress = 256;
+constexpr int kMaxPrompt = 232;
+
+// per-slot decode state (device memory)
+struct SeqState {
+    int tokens[kMaxTok + 8];      // currentTokens
+    float logprobs[kMaxTok + 8];
+    int n_tokens;                 // currentTokens.count
+    int token_index;              // tokenIndex = cacheLength of the next decoder call
+    int next_token;               // input id of the next decoder call
+    int done;                     // loop left (EOT / length / first-token threshold / loopCount)
+    int first_token_too_low;
+    int steps;
+    int active;
+    float temperature;
+    int prompt_len;               // initialPromptIndex
+    int pad[7];
+};
+
+struct DecodeBuffers {
+    int batch, d, n_head, n_layer, n_vocab;
+    const f16* emb;          // [V][d]
+    const float* pos;        // [448][d]
+    const DecLayerW* layers_host; // host array [L] of device pointers
+    const float *lnf_g, *lnf_b;
+    f16* self_k;             // [L][B][224][d]
+    f16* self_v;
+    const f16* cross_kv;     // [B*1500][L*2d]  (K_l at col l*2d, V_l at col l*2d + d)
+    float* xa;               // [B][d] residual ping
+    float* xb;               // [B][d] residual pong
+    float* q;                // [B][d] f32 query
+    f16* hbuf;               // [B][4d]
+    float* partial;          // [B][H][d]
+    float* logits;           // [B][V]
+    float* align;            // [B][224][n_align][1500] per-head cross-attention rows (or null)
+    const int* align_slot;   // [L*H] -> slot index or -1
+    int n_align;
+    SeqState* seq;           // [B]
+};
+
+// optional per-launch instrumentation: an event pair around every kernel of the step (bench roofline leg)
+enum StepKernel { SK_QKV = 0, SK_SELF_ATTN, SK_CQ, SK_CROSS_ATTN, SK_FC1, SK_FC2, SK_LOGITS, SK_SAMPLER, SK_COUNT };
+struct StepProfiler {
+    hipEvent_t* ev;      // 2 * capacity events
+    int* kind;           // capacity
+    int capacity, n;
+};
+// one decoder forward + (optionally) fused filter/sample/state-advance for all slots
+void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st,
+                         StepProfiler* prof = nullptr);
+// standalone filter / sampler entry points (KAT surface of the C ABI)
+void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int n_vocab, hipStream_t st);
+void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits, int n_vocab, int counter, int* token_out, float* logprob_out, hipStream_t st);
+// filter + sample without advancing the decode state (detectLanguage)
+void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st);
+// mean over alignment heads -> [B][224][1500]
+void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st);
+void launch_f32_to_f16(const float* in, f16* out, size_t n, hipStream_t st);
+void launch_f16_to_f32(const f16* in, float* out, size_t n, hipStream_t st);
+
+}  // namespace wh

@@ -1,0 +1,170 @@
+// Log-mel spectrogram for gfx950: replaces the CoreML MelSpectrogram call of
+// Sources/WhisperKit/Core/FeatureExtractor.swift:40-56 (+ padOrTrim, AudioProcessor.swift:151-174).
+//
+// Algorithm (openai/whisper audio.py): reflect pad 200, hann(400) STFT hop 160 -> |X|^2 (201 bins)
+// -> slaney mel filterbank -> log10(max(.,1e-10)) -> max(., global_max - 8) -> (x + 4) / 4.
+//
+// Kernel 1 (mel_power_kernel): one workgroup = 16 frames.  The 400-point real DFT is evaluated as two
+// K=200 real GEMMs on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chain):
+//     Re X[k] = sum_{n=1..200} (x[n] + x[400-n]) * w[n] cos(2 pi n k / 400)      (x[200] counted once)
+//     Im X[k] = sum_{n=1..199} (x[n] - x[400-n]) * w[n] sin(2 pi n k / 400)
+// (the periodic Hann window is symmetric about n = 200 and w[0] = 0, so the window folds into the
+// basis and the even/odd fold halves the MFMA work).  The folded frames live in LDS (bank-conflict-free
+// stride 202), the windowed basis (2 x 200 x 208 f32 = 333 KB) streams from L2.  Power -> LDS ->
+// sparse triangular mel filters -> log10 -> f32 scratch [n_mels][3000] + per-chunk atomic max.
+// Kernel 2 (mel_finalize_kernel): clamp to max-8, scale, emit the time-major f16 [3002][n_mels]
+// operand of the conv1 GEMM (and the reference-layout f32 [n_mels][3000] copy for the C ABI).
+#include "common.h"
+#include "kernels.h"
+
+namespace wh {
+
+constexpr int LDA = 202;   // folded-frame row stride (floats): 202 % 32 = 10 -> conflict-free MFMA A reads
+constexpr int LDP = 209;   // power row stride
+
+__device__ __forceinline__ float load_padded(const float* __restrict__ pcm, int n_valid, int j) {
+    // index into the reflect-padded, zero-extended 480000-sample window
+    int p = j - kNFFT / 2;
+    if (p < 0) p = -p;
+    if (p >= kWindowSamples) p = 2 * (kWindowSamples - 1) - p;
+    return p < n_valid ? pcm[p] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ pcm_all, const int* __restrict__ n_valid_all,
+                                                        const float* __restrict__ basis_c, const float* __restrict__ basis_s,
+                                                        const float* __restrict__ filt, const int2* __restrict__ filt_range,
+                                                        int n_mels, float* __restrict__ logspec, unsigned* __restrict__ maxkey) {
+    __shared__ float fe[16 * LDA];
+    __shared__ float fo[16 * LDA];
+    __shared__ float pw[16 * LDP];
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pcm = pcm_all + (size_t)b * kWindowSamples;
+    const int n_valid = n_valid_all[b];
+
+    // fold the 16 frames: fe[i][m] = x[n] + x[400-n], fo[i][m] = x[n] - x[400-n], n = m + 1
+    for (int idx = tid; idx < 16 * 200; idx += 256) {
+        int i = idx / 200, m = idx - i * 200;
+        int n = m + 1;
+        int base = (f0 + i) * kHop;
+        float x1 = load_padded(pcm, n_valid, base + n);
+        float x2 = load_padded(pcm, n_valid, base + kNFFT - n);
+        bool mid = (n == 200);
+        fe[i * LDA + m] = mid ? x1 : x1 + x2;
+        fo[i * LDA + m] = mid ? 0.0f : x1 - x2;
+    }
+    __syncthreads();
+
+    f32x4 acc_re[4], acc_im[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc_re[t] = f32x4{0, 0, 0, 0}; acc_im[t] = f32x4{0, 0, 0, 0}; }
+    const int ai = lane & 15, ak = lane >> 4;
+    // wave w owns bin tiles w, w+4, w+8, w+12 (13 tiles of 16 bins)
+#pragma unroll 2
+    for (int ks = 0; ks < 50; ++ks) {
+        int k = ks * 4 + ak;
+        float a_e = fe[ai * LDA + k];
+        float a_o = fo[ai * LDA + k];
+        const float* bc = basis_c + (size_t)k * kBinsPad + ai;
+        const float* bs = basis_s + (size_t)k * kBinsPad + ai;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int tile = wave + 4 * t;
+            if (tile < 13) {
+                float b_c = bc[tile * 16];
+                float b_s = bs[tile * 16];
+                acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, b_c, acc_re[t], 0, 0, 0);
+                acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, b_s, acc_im[t], 0, 0, 0);
+            }
+        }
+    }
+    // C layout 16x16: col = lane & 15 (bin), row = (lane >> 4) * 4 + r (frame)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int tile = wave + 4 * t;
+        if (tile < 13) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = ak * 4 + r;
+                float re = acc_re[t][r], im = acc_im[t][r];
+                pw[i * LDP + tile * 16 + ai] = re * re + im * im;
+            }
+        }
+    }
+    __syncthreads();
+
+    float lmax = -INFINITY;
+    for (int idx = tid; idx < 16 * n_mels; idx += 256) {
+        int i = idx & 15, m = idx >> 4;
+        int f = f0 + i;
+        int2 rg = filt_range[m];
+        float v = 0.0f;
+        for (int bin = rg.x; bin <= rg.y; ++bin) v = fmaf(pw[i * LDP + bin], filt[bin * n_mels + m], v);
+        float lg = log10f(fmaxf(v, 1e-10f));
+        if (f < kFrames) {
+            logspec[((size_t)b * n_mels + m) * kFrames + f] = lg;
+            lmax = fmaxf(lmax, lg);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(maxkey + b, float_key(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void mel_finalize_kernel(const float* __restrict__ logspec, const unsigned* __restrict__ maxkey,
+                                                           int n_mels, f16* __restrict__ mel_t /* [B][3002][n_mels] */,
+                                                           float* __restrict__ mel_f32 /* [B][n_mels][3000] or null */) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [n_mels][65]
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const float floor_v = key_float(maxkey[b]) - 8.0f;
+    for (int idx = tid; idx < n_mels * 64; idx += 256) {
+        int m = idx >> 6, i = idx & 63;
+        int f = f0 + i;
+        float v = 0.0f;
+        if (f < kFrames) {
+            size_t o = ((size_t)b * n_mels + m) * kFrames + f;
+            v = (fmaxf(logspec[o], floor_v) + 4.0f) * 0.25f;
+            if (mel_f32) mel_f32[o] = v;
+        }
+        tile[m * 65 + i] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n_mels * 64; idx += 256) {
+        int i = idx / n_mels, m = idx - i * n_mels;
+        int f = f0 + i;
+        if (f < kFrames) mel_t[((size_t)b * kFramesPad + f + 1) * n_mels + m] = (f16)tile[m * 65 + i];
+    }
+}
+
+// [n_mels][3000] f32 (reference layout) -> time-major f16 operand; used by wh_set_mel
+__global__ void mel_import_kernel(const float* __restrict__ mel_f32, int n_mels, f16* __restrict__ mel_t) {
+    int b = blockIdx.y;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_mels * kFrames) return;
+    int f = idx / n_mels, m = idx - f * n_mels;
+    mel_t[((size_t)b * kFramesPad + f + 1) * n_mels + m] = (f16)mel_f32[((size_t)b * n_mels + m) * kFrames + f];
+}
+
+void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, int batch, float* logspec, unsigned* maxkey,
+                    f16* mel_t, float* mel_f32, hipStream_t st) {
+    hipMemsetAsync(maxkey, 0, sizeof(unsigned) * batch, st);
+    dim3 g1((kFrames + 15) / 16, batch);
+    mel_power_kernel<<<g1, 256, 0, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt, t.filt_range, t.n_mels, logspec, maxkey);
+    dim3 g2((kFrames + 63) / 64, batch);
+    mel_finalize_kernel<<<g2, 256, t.n_mels * 65 * sizeof(float), st>>>(logspec, maxkey, t.n_mels, mel_t, mel_f32);
+}
+
+void launch_mel_import(const float* mel_f32, int n_mels, int batch, f16* mel_t, hipStream_t st) {
+    dim3 g((n_mels * kFrames + 255) / 256, batch);
+    mel_import_kernel<<<g, 256, 0, st>>>(mel_f32, n_mels, mel_t);
+}
+
+}  // namespace wh
