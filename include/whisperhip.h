@@ -264,10 +264,13 @@ int wh_vad_chunk_all(const float* pcm, int n, int max_chunk_length, const wh_dec
                      int32_t* chunk_start, int32_t* chunk_end, int capacity);
 
 /* ---- measurement (bench.py roofline leg; no reference analogue) --------------------------------------
- * n_steps eager decoder steps with a HIP event pair around every kernel launch on the session stream; average
- * microseconds and launch counts per kernel kind: 0 gemv_qkv 1 self_attn 2 gemv_cq 3 cross_attn 4 gemv_fc1
- * 5 gemv_fc2 6 gemv_logits 7 sampler.  Uses the prompt / sampler configuration of the last wh_decode_text call. */
-int wh_measure_decoder_kernels(wh_session* s, int batch, int n_steps, double* avg_us, int32_t* launches);
+ * One eager pass of the hot path on the session stream - log-mel, encoder, cross-K/V projection, then n_steps decoder
+ * steps - with a HIP event pair around every kernel launch.  avg_us / launches are indexed by kernel kind
+ * [0, wh_kernel_kind_count()); wh_kernel_kind_name(k) names kind k.  Uses the prompt / sampler configuration of the last
+ * wh_decode_text call on the session and the audio currently in its slots. */
+int wh_kernel_kind_count(void);
+const char* wh_kernel_kind_name(int kind);
+int wh_measure_kernels(wh_session* s, int batch, int n_steps, double* avg_us, int32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -127,7 +127,9 @@ SYMBOLS = {
     "wh_find_seek_point_and_segments": (I, [C.POINTER(WhDecodingResult), POPT, PST, I, I, I, PI32, C.POINTER(WhSegment), I]),
     "wh_vad_voice_activity": (I, [PF, I, I, I, F, PU8, I]),
     "wh_vad_chunk_all": (I, [PF, I, I, POPT, PI32, PI32, I]),
-    "wh_measure_decoder_kernels": (I, [VP, I, I, C.POINTER(C.c_double), PI32]),
+    "wh_kernel_kind_count": (I, []),
+    "wh_kernel_kind_name": (C.c_char_p, [I]),
+    "wh_measure_kernels": (I, [VP, I, I, C.POINTER(C.c_double), PI32]),
 }
 
 _lib = None

@@ -174,8 +174,8 @@ class Model:
         if blob is None:
             blob = pack_blob(dims, state_dict)
         self.handle = C.c_void_p()
-        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _check(self.lib.wh_model_create(buf, len(blob), device, C.byref(self.handle)))
+        arr = np.frombuffer(blob, dtype=np.uint8)      # zero-copy view of bytes / bytearray / uint8 ndarray
+        _check(self.lib.wh_model_create(C.c_void_p(arr.ctypes.data), arr.nbytes, device, C.byref(self.handle)))
         st = L.WhSpecialTokens()
         _check(self.lib.wh_special_tokens_default(self.handle, C.byref(st)))
         self.specialTokens = st

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const f16* __res
 
 void launch_encoder_attention(const f16* q16, const f16* k16, const f16* vt16, f16* out16, int batch, int n_head, int d, hipStream_t st) {
     dim3 g((kCtx + 127) / 128, n_head, batch);
+    ProfScope ps_(KK_ENC_ATTN, st);
     encoder_attention_kernel<<<g, 256, 0, st>>>(q16, k16, vt16, out16, n_head, d);
 }
 

@@ -13,6 +13,8 @@
 
 using namespace wh;
 
+namespace wh { thread_local KernelProfiler* g_prof = nullptr; }
+
 namespace whi {
 static thread_local char g_err[512] = "";
 int set_error(int code, const char* fmt, ...) {
@@ -384,11 +386,13 @@ extern "C" int wh_encode_features(wh_session* s, int batch) {
     // conv1 (k3 s1 p1) + GELU as a GEMM over 3 consecutive rows of the padded time-major mel
     g.A = s->mel_t; g.W = m->conv1_w; g.bias = m->conv1_b; g.M = batch * kFrames; g.N = d; g.K = 3 * nm; g.lda = nm;
     g.a_rows_per_batch = kFrames; g.a_batch_stride = (long long)kFramesPad * nm; g.ldc = d; g.out16 = s->h1; g.rows_per_batch_out = kFrames;
+    g.prof_kind = KK_CONV1;
     launch_gemm(EPI_CONV1, g, st);
     // conv2 (k3 s2 p1) + GELU + positional embedding -> fp32 residual stream
     g = GemmArgs{};
     g.A = s->h1; g.W = m->conv2_w; g.bias = m->conv2_b; g.M = M; g.N = d; g.K = 3 * d; g.lda = 2 * d;
     g.a_rows_per_batch = kCtx; g.a_batch_stride = (long long)kFramesPad * d; g.ldc = d; g.out32 = s->x; g.pos = m->enc_pos; g.rows_per_batch_out = kCtx;
+    g.prof_kind = KK_CONV2;
     launch_gemm(EPI_CONV2, g, st);
     for (int l = 0; l < D.n_audio_layer; ++l) {
         const EncLayerW& w = m->enc[l];
@@ -396,17 +400,21 @@ extern "C" int wh_encode_features(wh_session* s, int batch) {
         g = GemmArgs{};
         g.A = s->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.M = M; g.N = 3 * d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = d;
         g.out16 = s->q16; g.k16 = s->k16; g.vt16 = s->vt16; g.d_model = d; g.rows_per_batch_out = kCtx;
+        g.prof_kind = KK_ENC_QKV;
         launch_gemm(EPI_QKV_ENC, g, st);
         launch_encoder_attention(s->q16, s->k16, s->vt16, s->att16, batch, D.n_audio_head, d, st);
         g = GemmArgs{};
         g.A = s->att16; g.W = w.o_w; g.bias = w.o_b; g.M = M; g.N = d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = d; g.out32 = s->x;
+        g.prof_kind = KK_ENC_O;
         launch_gemm(EPI_RESID_F32, g, st);
         launch_layernorm(s->x, w.ln2_g, w.ln2_b, M, d, s->xn, nullptr, st);
         g = GemmArgs{};
         g.A = s->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.M = M; g.N = 4 * d; g.K = d; g.lda = d; g.a_rows_per_batch = M; g.ldc = 4 * d; g.out16 = s->hmlp;
+        g.prof_kind = KK_ENC_FC1;
         launch_gemm(EPI_GELU_F16, g, st);
         g = GemmArgs{};
         g.A = s->hmlp; g.W = w.fc2_w; g.bias = w.fc2_b; g.M = M; g.N = d; g.K = 4 * d; g.lda = 4 * d; g.a_rows_per_batch = M; g.ldc = d; g.out32 = s->x;
+        g.prof_kind = KK_ENC_FC2;
         launch_gemm(EPI_RESID_F32, g, st);
     }
     launch_layernorm(s->x, m->lnp_g, m->lnp_b, M, d, s->enc16, s->enc32, st);
@@ -469,6 +477,7 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     GemmArgs g{};
     g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
     g.ldc = L * 2 * d; g.out16 = s->cross_kv;
+    g.prof_kind = KK_CROSS_KV;
     launch_gemm(EPI_F16, g, s->st);
     WH_CHECK_LAUNCH();
     return wh_reset_decoder_inputs(s, batch);
@@ -579,7 +588,7 @@ extern "C" int wh_sample_token(wh_session* s, const float* logits, int n_logits,
     if (r) return r;
     SeqState& q = s->seq_host[0];
     memset(&q, 0, sizeof(q));
-    q.active = 1; q.temperature = temperature;
+    q.active = 1; q.temperature = (float)(_Float16)temperature;   // GreedyTokenSampler.temperature is FloatType (TokenSampler.swift:30)
     WH_HIP(hipMemcpyAsync(s->seq, &q, sizeof(SeqState), hipMemcpyHostToDevice, s->st));
     WH_HIP(hipMemcpyAsync(s->scratch_logits, logits, sizeof(float) * n_logits, hipMemcpyHostToDevice, s->st));
     launch_sample_only(s->cfg_dev, s->seq, s->scratch_logits, n_logits, counter, s->tok_out_dev, s->lp_out_dev, s->st);

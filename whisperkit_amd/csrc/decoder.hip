@@ -592,6 +592,13 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
     if (bt == 3) bt = 4;
     dim3 g((a.N + a.rows_per_block - 1) / a.rows_per_block, (a.batch + bt - 1) / bt);
     size_t smem = (MODE == MODE_FC2) ? (size_t)bt * a.K * sizeof(f16) : (size_t)bt * a.K * sizeof(float);
+    if (smem > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation (160 KB per CU on gfx950)
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv_kernel<MODE, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
     switch (bt) {
         case 1: dec_gemv_kernel<MODE, 1><<<g, 256, smem, st>>>(a); break;
         case 2: dec_gemv_kernel<MODE, 2><<<g, 256, smem, st>>>(a); break;
@@ -600,10 +607,8 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
     }
 }
 
-#define PROF_BEGIN(k) do { if (prof && prof->n < prof->capacity) { prof->kind[prof->n] = (k); (void)hipEventRecord(prof->ev[2 * prof->n], st); } } while (0)
-#define PROF_END() do { if (prof && prof->n < prof->capacity) { (void)hipEventRecord(prof->ev[2 * prof->n + 1], st); prof->n++; } } while (0)
 
-void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st, StepProfiler* prof) {
+void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st) {
     const int d = db.d, B = db.batch, H = db.n_head, L = db.n_layer;
     float* xcur = db.xa;
     float* xalt = db.xb;
@@ -615,32 +620,32 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         g.N = 3 * d; g.K = d; g.rows_per_block = 16; g.W = w.qkv_w; g.bias = w.qkv_b; g.ln_g = w.ln1_g; g.ln_b = w.ln1_b;
         g.xin = xcur; g.xout = xcur; g.emb = db.emb; g.pos = db.pos; g.q = db.q;
         g.self_k = db.self_k + (size_t)l * B * kMaxTok * d; g.self_v = db.self_v + (size_t)l * B * kMaxTok * d;
-        PROF_BEGIN(SK_QKV); launch_gemv<MODE_QKV>(g, st); PROF_END();
+        { ProfScope ps_(KK_DEC_QKV, st); launch_gemv<MODE_QKV>(g, st); }
         AttnArgs at{};
         at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.q = db.q; at.self_k = g.self_k; at.self_v = g.self_v;
         at.cross_kv = db.cross_kv; at.o_w = w.o_w; at.partial = db.partial; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
-        PROF_BEGIN(SK_SELF_ATTN); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); PROF_END();
+        { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
         // cross query: x' = x + b_o + sum partial
         g.N = d; g.K = d; g.rows_per_block = 16; g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
         g.xin = xcur; g.xout = xalt; g.comb_bias = w.o_b; g.partial = db.partial;
-        PROF_BEGIN(SK_CQ); launch_gemv<MODE_CQ>(g, st); PROF_END();
+        { ProfScope ps_(KK_DEC_CQ, st); launch_gemv<MODE_CQ>(g, st); }
         at.o_w = w.co_w;
-        PROF_BEGIN(SK_CROSS_ATTN); dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); PROF_END();
+        { ProfScope ps_(KK_DEC_CROSS_ATTN, st); dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
         // fc1: x'' = x' + b_co + sum partial
         g.N = 4 * d; g.K = d; g.rows_per_block = 16; g.W = w.fc1_w; g.bias = w.fc1_b; g.ln_g = w.ln3_g; g.ln_b = w.ln3_b;
         g.xin = xalt; g.xout = xcur; g.comb_bias = w.co_b; g.hbuf = db.hbuf;
-        PROF_BEGIN(SK_FC1); launch_gemv<MODE_FC1>(g, st); PROF_END();
+        { ProfScope ps_(KK_DEC_FC1, st); launch_gemv<MODE_FC1>(g, st); }
         // fc2: x''' = x'' + b_2 + W_2 h   (in place on xcur)
         g.N = d; g.K = 4 * d; g.rows_per_block = 16; g.W = w.fc2_w; g.bias = w.fc2_b; g.xin = xcur; g.xout = xcur;
-        PROF_BEGIN(SK_FC2); launch_gemv<MODE_FC2>(g, st); PROF_END();
+        { ProfScope ps_(KK_DEC_FC2, st); launch_gemv<MODE_FC2>(g, st); }
     }
     GemvArgs g{};
     g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = -1; g.n_vocab = db.n_vocab;
     g.N = db.n_vocab; g.K = d; g.rows_per_block = 64; g.W = db.emb; g.bias = nullptr; g.ln_g = db.lnf_g; g.ln_b = db.lnf_b;
     g.xin = xcur; g.logits = db.logits;
-    PROF_BEGIN(SK_LOGITS); launch_gemv<MODE_LOGITS>(g, st); PROF_END();
-    if (sample) { PROF_BEGIN(SK_SAMPLER); sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr); PROF_END(); }
+    { ProfScope ps_(KK_DEC_LOGITS, st); launch_gemv<MODE_LOGITS>(g, st); }
+    if (sample) { { ProfScope ps_(KK_SAMPLER, st); sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr); } }
 }
 
 void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int n_vocab, hipStream_t st) {

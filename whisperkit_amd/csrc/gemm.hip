@@ -171,6 +171,7 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
 }
 
 void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st) {
+    ProfScope ps_(a.prof_kind, st);
     switch (epi) {
         case EPI_F16: launch_epi<EPI_F16>(a, st); break;
         case EPI_GELU_F16: launch_epi<EPI_GELU_F16>(a, st); break;

@@ -674,38 +674,55 @@ extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const in
 }
 
 // ------------------------------------------------------------------------------------------------ measurement hook
-extern "C" int wh_measure_decoder_kernels(wh_session* s, int batch, int n_steps, double* avg_us /* [8] */, int32_t* launches /* [8] */) {
-    // Runs `n_steps` decoder steps eagerly on the session stream (state as left by the last wh_decode_text setup, re-armed here)
-    // with a HIP event pair around every kernel launch, and reports the average duration per kernel kind:
-    // 0 gemv_qkv 1 self_attn 2 gemv_cq 3 cross_attn 4 gemv_fc1 5 gemv_fc2 6 gemv_logits 7 sampler.
+static const char* kKindNames[KK_COUNT] = {
+    "mel_power", "mel_finalize", "gemm_conv1", "gemm_conv2", "layernorm", "gemm_enc_qkv", "enc_attention", "gemm_enc_o", "gemm_enc_fc1",
+    "gemm_enc_fc2", "gemm_cross_kv", "dec_gemv_qkv", "dec_self_attn", "dec_gemv_cq", "dec_cross_attn", "dec_gemv_fc1", "dec_gemv_fc2",
+    "dec_gemv_logits", "sampler"};
+extern "C" int wh_kernel_kind_count(void) { return KK_COUNT; }
+extern "C" const char* wh_kernel_kind_name(int kind) { return (kind >= 0 && kind < KK_COUNT) ? kKindNames[kind] : nullptr; }
+
+extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double* avg_us, int32_t* launches) {
+    // One eager pass of the hot path on the session stream - log-mel, encoder, cross-K/V projection, then `n_steps` decoder
+    // steps (state as left by the last wh_decode_text setup, re-armed at position 0) - with a HIP event pair around every
+    // kernel launch; reports the average duration and the launch count per KernelKind (wh_kernel_kind_name).
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
-    if (!avg_us || !launches || n_steps < 1 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_decoder_kernels: invalid argument");
-    const int L = s->m->dims.n_text_layer;
-    const int per_step = 6 * L + 2, cap = per_step * n_steps;
-    std::vector<hipEvent_t> ev(2 * (size_t)cap);
-    std::vector<int> kind(cap);
-    for (auto& e : ev) WH_HIP(hipEventCreate(&e));
-    // re-arm the slots: keep prompt/config, restart the loop at position 0
+    if (!avg_us || !launches || n_steps < 0 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_kernels: invalid argument");
+    const int L = s->m->dims.n_text_layer, Le = s->m->dims.n_audio_layer;
+    const size_t cap = (size_t)(6 * L + 2) * n_steps + 7 * Le + 16;
+    KernelProfiler prof;
+    prof.ev.resize(2 * cap); prof.kind.resize(cap); prof.capacity = cap;
+    for (auto& e : prof.ev) WH_HIP(hipEventCreate(&e));
     WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, sizeof(SeqState) * batch, hipMemcpyDeviceToHost, s->st));
     WH_HIP(hipStreamSynchronize(s->st));
-    for (int b = 0; b < batch; ++b) {
-        SeqState& q = s->seq_host[b];
-        int pl = std::max(q.prompt_len, 1);
-        q.n_tokens = pl; q.token_index = 0; q.next_token = q.tokens[0]; q.done = 0; q.active = 1; q.steps = 0; q.first_token_too_low = 0;
+    std::vector<SeqState> saved(s->seq_host, s->seq_host + batch);
+    g_prof = &prof;
+    int r = wh_log_mel_spectrogram(s, batch);
+    if (!r) r = wh_encode_features(s, batch);
+    if (!r) r = wh_prepare_decoder_inputs(s, batch);
+    if (!r && n_steps > 0) {
+        // re-arm the slots: keep prompt/config, restart the loop at position 0
+        for (int b = 0; b < batch; ++b) {
+            SeqState& q = s->seq_host[b];
+            q = saved[b];
+            int pl = std::max(q.prompt_len, 1);
+            q.n_tokens = pl; q.token_index = 0; q.next_token = q.tokens[0]; q.done = 0; q.active = 1; q.steps = 0; q.first_token_too_low = 0;
+        }
+        hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st);
+        DecodeBuffers db = whi::decode_buffers(s, batch);
+        for (int i = 0; i < n_steps; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
     }
-    WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
-    DecodeBuffers db = whi::decode_buffers(s, batch);
-    StepProfiler prof{ev.data(), kind.data(), cap, 0};
-    for (int i = 0; i < n_steps; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st, &prof);
-    WH_CHECK_LAUNCH();
-    WH_HIP(hipStreamSynchronize(s->st));
-    double tot[SK_COUNT] = {0};
-    int cnt[SK_COUNT] = {0};
-    for (int i = 0; i < prof.n; ++i) {
+    g_prof = nullptr;
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(s->st);
+    double tot[KK_COUNT] = {0};
+    int cnt[KK_COUNT] = {0};
+    for (size_t i = 0; i < prof.n; ++i) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { tot[kind[i]] += ms * 1000.0; cnt[kind[i]]++; }
+        if (hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]) == hipSuccess) { tot[prof.kind[i]] += ms * 1000.0; cnt[prof.kind[i]]++; }
     }
-    for (int k = 0; k < SK_COUNT; ++k) { avg_us[k] = cnt[k] ? tot[k] / cnt[k] : 0.0; launches[k] = cnt[k]; }
-    for (auto& e : ev) hipEventDestroy(e);
+    for (int k = 0; k < KK_COUNT; ++k) { avg_us[k] = cnt[k] ? tot[k] / cnt[k] : 0.0; launches[k] = cnt[k]; }
+    for (auto& e : prof.ev) hipEventDestroy(e);
+    if (r) return r;
+    if (le != hipSuccess || se != hipSuccess) return set_error(WH_ERR_HIP, "wh_measure_kernels: %s", hipGetErrorString(le != hipSuccess ? le : se));
     return WH_OK;
 }

@@ -2,7 +2,32 @@
 #pragma once
 #include "common.h"
 
+#include <vector>
+
 namespace wh {
+
+// ---------------------------------------------------------------------------------------------- measurement
+// Every kernel launch of the hot path is tagged with a kind; when a KernelProfiler is armed on the calling thread
+// (wh_measure_kernels) each launch is bracketed by a HIP event pair on the launch stream.
+enum KernelKind {
+    KK_MEL_POWER = 0, KK_MEL_FINALIZE, KK_CONV1, KK_CONV2, KK_LAYERNORM, KK_ENC_QKV, KK_ENC_ATTN, KK_ENC_O, KK_ENC_FC1, KK_ENC_FC2,
+    KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS, KK_SAMPLER,
+    KK_COUNT
+};
+struct KernelProfiler {
+    std::vector<hipEvent_t> ev;   // 2 per recorded launch
+    std::vector<int> kind;
+    size_t n = 0, capacity = 0;
+};
+extern thread_local KernelProfiler* g_prof;
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(int kind, hipStream_t s) : st(s), on(false) {
+        KernelProfiler* p = g_prof;
+        if (p && kind >= 0 && p->n < p->capacity) { on = true; p->kind[p->n] = kind; (void)hipEventRecord(p->ev[2 * p->n], st); }
+    }
+    ~ProfScope() { if (on) { KernelProfiler* p = g_prof; (void)hipEventRecord(p->ev[2 * p->n + 1], st); p->n++; } }
+};
 
 struct MelTables {
     const float* basis_c;   // [200][208] w[n] cos(2 pi n k / 400), n = 1..200
@@ -47,6 +72,7 @@ struct GemmArgs {
     // EPI_CONV2
     const float* pos;
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
+    int prof_kind = -1;        // KernelKind of this launch (measurement only)
 };
 
 void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st);
@@ -123,16 +149,8 @@ struct DecodeBuffers {
     SeqState* seq;           // [B]
 };
 
-// optional per-launch instrumentation: an event pair around every kernel of the step (bench roofline leg)
-enum StepKernel { SK_QKV = 0, SK_SELF_ATTN, SK_CQ, SK_CROSS_ATTN, SK_FC1, SK_FC2, SK_LOGITS, SK_SAMPLER, SK_COUNT };
-struct StepProfiler {
-    hipEvent_t* ev;      // 2 * capacity events
-    int* kind;           // capacity
-    int capacity, n;
-};
 // one decoder forward + (optionally) fused filter/sample/state-advance for all slots
-void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st,
-                         StepProfiler* prof = nullptr);
+void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st);
 // standalone filter / sampler entry points (KAT surface of the C ABI)
 void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int n_vocab, hipStream_t st);
 void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits, int n_vocab, int counter, int* token_out, float* logprob_out, hipStream_t st);

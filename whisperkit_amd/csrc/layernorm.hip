@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 void launch_layernorm(const float* x, const float* g, const float* b, int rows, int d, f16* y16, float* y32, hipStream_t st) {
+    ProfScope ps_(KK_LAYERNORM, st);
     layernorm_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, g, b, rows, d, y16, y32);
 }
 

@@ -157,9 +157,9 @@ void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, in
                     f16* mel_t, float* mel_f32, hipStream_t st) {
     hipMemsetAsync(maxkey, 0, sizeof(unsigned) * batch, st);
     dim3 g1((kFrames + 15) / 16, batch);
-    mel_power_kernel<<<g1, 256, 0, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt, t.filt_range, t.n_mels, logspec, maxkey);
+    { ProfScope ps_(KK_MEL_POWER, st); mel_power_kernel<<<g1, 256, 0, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt, t.filt_range, t.n_mels, logspec, maxkey); }
     dim3 g2((kFrames + 63) / 64, batch);
-    mel_finalize_kernel<<<g2, 256, t.n_mels * 65 * sizeof(float), st>>>(logspec, maxkey, t.n_mels, mel_t, mel_f32);
+    { ProfScope ps_(KK_MEL_FINALIZE, st); mel_finalize_kernel<<<g2, 256, t.n_mels * 65 * sizeof(float), st>>>(logspec, maxkey, t.n_mels, mel_t, mel_f32); }
 }
 
 void launch_mel_import(const float* mel_f32, int n_mels, int batch, f16* mel_t, hipStream_t st) {

@@ -86,50 +86,43 @@ def _f16_round(a: np.ndarray) -> np.ndarray:
     return a.astype(np.float16).astype(np.float32)
 
 
-def synthetic_state_dict(dims: WhisperDims, seed: int = 0, std: float = 0.02,
-                         embed_std: Optional[float] = None) -> Dict[str, np.ndarray]:
-    """Deterministic random-init weights in openai/whisper naming, fp32 values that are
-    exactly representable in fp16 (so the oracle and the HIP path see identical weights).
-
-    N(0, std) matrices, LayerNorm gamma ~ 1 + N(0, 0.1), beta/bias ~ N(0, std): non-trivial
-    LN/bias params make the parity tests sensitive to every term (SURVEY.md section 8d
-    uses gamma=1/beta=0, which would hide a swapped or missing bias).
-    """
-    rng = np.random.default_rng(seed)
+def _synthetic_specs(dims: WhisperDims, std: float, embed_std: Optional[float]):
+    """(name, shape, kind, scale) in generation order.  kind: 'mat' N(0, s) rounded to fp16; 'vec' N(0, s) fp32;
+    'gamma' 1 + N(0, 0.1); 'sin' the fixed encoder positional embedding."""
     d, dt = dims.n_audio_state, dims.n_text_state
-    sd: Dict[str, np.ndarray] = {}
+    specs = []
 
-    def mat(*shape, s=std):
-        return _f16_round(rng.standard_normal(shape, dtype=np.float32) * s)
+    def mat(name, *shape, s=std):
+        specs.append((name, shape, "mat", s))
 
-    def vec(n, s=std):
-        return (rng.standard_normal(n, dtype=np.float32) * s).astype(np.float32)
+    def vec(name, *shape, s=std):
+        specs.append((name, shape, "vec", s))
 
     def ln(prefix, n):
-        sd[prefix + ".weight"] = (1.0 + 0.1 * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
-        sd[prefix + ".bias"] = vec(n)
+        specs.append((prefix + ".weight", (n,), "gamma", 0.1))
+        vec(prefix + ".bias", n)
 
-    def attn(prefix, n, cross=False):
-        sd[prefix + ".query.weight"] = mat(n, n)
-        sd[prefix + ".query.bias"] = vec(n)
-        sd[prefix + ".key.weight"] = mat(n, n)  # no bias (openai/whisper MultiHeadAttention)
-        sd[prefix + ".value.weight"] = mat(n, n)
-        sd[prefix + ".value.bias"] = vec(n)
-        sd[prefix + ".out.weight"] = mat(n, n)
-        sd[prefix + ".out.bias"] = vec(n)
+    def attn(prefix, n):
+        mat(prefix + ".query.weight", n, n)
+        vec(prefix + ".query.bias", n)
+        mat(prefix + ".key.weight", n, n)  # no bias (openai/whisper MultiHeadAttention)
+        mat(prefix + ".value.weight", n, n)
+        vec(prefix + ".value.bias", n)
+        mat(prefix + ".out.weight", n, n)
+        vec(prefix + ".out.bias", n)
 
     def mlp(prefix, n):
-        sd[prefix + ".0.weight"] = mat(4 * n, n)
-        sd[prefix + ".0.bias"] = vec(4 * n)
-        sd[prefix + ".2.weight"] = mat(n, 4 * n)
-        sd[prefix + ".2.bias"] = vec(n)
+        mat(prefix + ".0.weight", 4 * n, n)
+        vec(prefix + ".0.bias", 4 * n)
+        mat(prefix + ".2.weight", n, 4 * n)
+        vec(prefix + ".2.bias", n)
 
     # conv stem: a larger std keeps the activations O(1) like a trained model
-    sd["encoder.conv1.weight"] = mat(d, dims.n_mels, 3, s=std * 4)
-    sd["encoder.conv1.bias"] = vec(d)
-    sd["encoder.conv2.weight"] = mat(d, d, 3, s=std * 2)
-    sd["encoder.conv2.bias"] = vec(d)
-    sd["encoder.positional_embedding"] = sinusoids(dims.n_audio_ctx, d)
+    mat("encoder.conv1.weight", d, dims.n_mels, 3, s=std * 4)
+    vec("encoder.conv1.bias", d)
+    mat("encoder.conv2.weight", d, d, 3, s=std * 2)
+    vec("encoder.conv2.bias", d)
+    specs.append(("encoder.positional_embedding", (dims.n_audio_ctx, d), "sin", 0.0))
     for i in range(dims.n_audio_layer):
         p = f"encoder.blocks.{i}"
         ln(p + ".attn_ln", d)
@@ -137,19 +130,62 @@ def synthetic_state_dict(dims: WhisperDims, seed: int = 0, std: float = 0.02,
         ln(p + ".mlp_ln", d)
         mlp(p + ".mlp", d)
     ln("encoder.ln_post", d)
-
-    sd["decoder.token_embedding.weight"] = mat(dims.n_vocab, dt, s=embed_std if embed_std else std)
-    sd["decoder.positional_embedding"] = vec(dims.n_text_ctx * dt).reshape(dims.n_text_ctx, dt)
+    mat("decoder.token_embedding.weight", dims.n_vocab, dt, s=embed_std if embed_std else std)
+    vec("decoder.positional_embedding", dims.n_text_ctx, dt)
     for i in range(dims.n_text_layer):
         p = f"decoder.blocks.{i}"
         ln(p + ".attn_ln", dt)
         attn(p + ".attn", dt)
         ln(p + ".cross_attn_ln", dt)
-        attn(p + ".cross_attn", dt, cross=True)
+        attn(p + ".cross_attn", dt)
         ln(p + ".mlp_ln", dt)
         mlp(p + ".mlp", dt)
     ln("decoder.ln", dt)
-    return sd
+    return specs
+
+
+def _draw(rng, shape, kind, s, dims):
+    if kind == "sin":
+        return sinusoids(shape[0], shape[1])
+    n = int(np.prod(shape))
+    x = rng.standard_normal(shape if kind == "mat" else n, dtype=np.float32)
+    if kind == "mat":
+        x *= np.float32(s)
+        return _f16_round(x)
+    if kind == "gamma":
+        return (1.0 + 0.1 * x).astype(np.float32)
+    return (x * s).astype(np.float32).reshape(shape)
+
+
+def synthetic_state_dict(dims: WhisperDims, seed: int = 0, std: float = 0.02,
+                         embed_std: Optional[float] = None, parallel: Optional[bool] = None) -> Dict[str, np.ndarray]:
+    """Deterministic random-init weights in openai/whisper naming, fp32 values that are
+    exactly representable in fp16 (so the oracle and the HIP path see identical weights).
+
+    N(0, std) matrices, LayerNorm gamma ~ 1 + N(0, 0.1), beta/bias ~ N(0, std): non-trivial
+    LN/bias params make the parity tests sensitive to every term (SURVEY.md section 8d
+    uses gamma=1/beta=0, which would hide a swapped or missing bias).
+
+    parallel=False draws every tensor from one generator in sequence (the stream the committed golden
+    fixtures were made with); parallel=True gives every tensor its own `default_rng([seed, index])` stream
+    and draws them on a thread pool (large-v3 = 1.5 G parameters: ~10x faster).  Default: parallel for
+    models above 200 M parameters.  Both are deterministic in (dims, seed).
+    """
+    specs = _synthetic_specs(dims, std, embed_std)
+    if parallel is None:
+        parallel = sum(int(np.prod(sh)) for _, sh, _, _ in specs) > 200_000_000
+    if not parallel:
+        rng = np.random.default_rng(seed)
+        return {name: _draw(rng, sh, kind, s, dims) for name, sh, kind, s in specs}
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    def job(i):
+        name, sh, kind, s = specs[i]
+        return _draw(np.random.default_rng([seed, i]), sh, kind, s, dims)
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        arrs = list(ex.map(job, range(len(specs))))
+    return {specs[i][0]: arrs[i] for i in range(len(specs))}
 
 
 _HF_MAP = [
@@ -219,18 +255,29 @@ def kernel_tensors(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> List[Tuple[s
     hd = d // dims.n_audio_head
     assert hd == 64 and dt // dims.n_text_head == 64, "Whisper head_dim is 64 for every size"
     scale = np.float32(hd ** -0.5)  # 0.125: exact in fp16
-    out: List[Tuple[str, np.ndarray]] = []
+    jobs: List[Tuple[str, object, object]] = []   # (name, dtype, thunk or array): evaluated on a thread pool below
 
     def f16(name, a):
-        out.append((name, np.ascontiguousarray(a, dtype=np.float32).astype(np.float16)))
+        jobs.append((name, np.float16, a))
 
     def f32(name, a):
-        out.append((name, np.ascontiguousarray(a, dtype=np.float32)))
+        jobs.append((name, np.float32, a))
+
+    def cat16(parts, scales=None):
+        # concatenate along axis 0 straight into an fp16 buffer (no fp32 temporary of the fused matrix)
+        def run():
+            o = np.empty((sum(p.shape[0] for p in parts),) + parts[0].shape[1:], np.float16)
+            r = 0
+            for k, p_ in enumerate(parts):
+                np.multiply(p_, scales[k] if scales else np.float32(1), out=o[r:r + p_.shape[0]], casting="unsafe")
+                r += p_.shape[0]
+            return o
+        return run
 
     def qkv(prefix, src, n):
-        w = np.concatenate([sd[src + ".query.weight"] * scale, sd[src + ".key.weight"], sd[src + ".value.weight"]], 0)
+        f16(prefix + ".qkv.w", cat16([sd[src + ".query.weight"], sd[src + ".key.weight"], sd[src + ".value.weight"]],
+                                     [scale, np.float32(1), np.float32(1)]))
         b = np.concatenate([sd[src + ".query.bias"] * scale, np.zeros(n, np.float32), sd[src + ".value.bias"]], 0)
-        f16(prefix + ".qkv.w", w)
         f32(prefix + ".qkv.b", b)
 
     # conv taps: W[co][ci][kk] -> [co][kk][ci]
@@ -266,14 +313,25 @@ def kernel_tensors(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> List[Tuple[s
         f32(p + ".ln3.g", sd[s + ".mlp_ln.weight"]); f32(p + ".ln3.b", sd[s + ".mlp_ln.bias"])
         f16(p + ".fc1.w", sd[s + ".mlp.0.weight"]); f32(p + ".fc1.b", sd[s + ".mlp.0.bias"])
         f16(p + ".fc2.w", sd[s + ".mlp.2.weight"]); f32(p + ".fc2.b", sd[s + ".mlp.2.bias"])
-    f16("dec.ckv.w", np.concatenate(ckv_w, 0))   # [L*2d][d]: (K_0, V_0, K_1, V_1, ...)
+    f16("dec.ckv.w", cat16(ckv_w))   # [L*2d][d]: (K_0, V_0, K_1, V_1, ...)
     f32("dec.ckv.b", np.concatenate(ckv_b, 0))
     f32("dec.ln.g", sd["decoder.ln.weight"]); f32("dec.ln.b", sd["decoder.ln.bias"])
-    return out
+
+    def realise(job):
+        name, dt, a = job
+        a = a() if callable(a) else a
+        return name, np.ascontiguousarray(a if a.dtype == dt else np.asarray(a, dtype=np.float32).astype(dt))
+    if sum(int(np.prod(v.shape)) for v in sd.values()) < 50_000_000:
+        return [realise(j_) for j_ in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        return list(ex.map(realise, jobs))
 
 
-def pack_blob(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> bytes:
-    """Serialise to the `WHIPW001` container read by `wh_model_create` (include/whisperhip.h)."""
+def pack_blob(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> np.ndarray:
+    """Serialise to the `WHIPW001` container read by `wh_model_create` (include/whisperhip.h).
+    Returns a uint8 array (buffer protocol; `bytes(blob)` / `blob.tofile(path)` for a file)."""
     tensors = kernel_tensors(dims, sd)
     n = len(tensors)
     entry = struct.Struct("<64sii4qqq")  # name, dtype, ndim, shape[4], offset, nbytes
@@ -286,16 +344,26 @@ def pack_blob(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> bytes:
         table.append(entry.pack(name.encode(), dt, a.ndim, *shape, off, a.nbytes))
         payload_offsets.append(off)
         off = (off + a.nbytes + ALIGN - 1) // ALIGN * ALIGN
-    buf = bytearray(off)
+    buf = np.zeros(off, dtype=np.uint8)
     head = MAGIC + struct.pack("<10i", *dims.as_tuple()) + struct.pack("<ii", n, 0) + b"".join(table)
-    buf[: len(head)] = head
-    for (name, a), o in zip(tensors, payload_offsets):
-        buf[o: o + a.nbytes] = a.tobytes()
-    return bytes(buf)
+    buf[: len(head)] = np.frombuffer(head, dtype=np.uint8)
+    def put(k):
+        a, o = tensors[k][1], payload_offsets[k]
+        buf[o: o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    if off < 200_000_000:
+        for k in range(n):
+            put(k)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(put, range(n)))
+    return buf
 
 
-def unpack_blob(blob: bytes) -> Tuple[WhisperDims, Dict[str, np.ndarray]]:
+def unpack_blob(blob) -> Tuple[WhisperDims, Dict[str, np.ndarray]]:
     """Parse a blob back (host-side sanity checks and tests)."""
+    blob = bytes(blob) if not isinstance(blob, (bytes, bytearray)) else blob
     assert blob[:8] == MAGIC
     dims = WhisperDims(*struct.unpack_from("<10i", blob, 8))
     n, _ = struct.unpack_from("<ii", blob, 48)
