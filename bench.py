@@ -67,16 +67,18 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float):
         return gemm(B * T, 4 * d, d)
     if kind == "gemm_cross_kv":
         return gemm(B * T, 2 * L * d, d)
-    if kind == "dec_gemv_qkv":   # LN1 + QKV: W[3d][d] + x in, q/k/v out
+    if kind == "dec_gemv_qkv":   # LN1 + QKV: W[3d][d] + x in, q / k / v out
         return "hbm", 3 * d * d * 2 + 3 * d * 4 + act + B * 3 * d * 2
-    if kind == "dec_self_attn":  # K,V rows of <= len positions + W_o + partial out
-        return "hbm", B * 2 * avg_len * d * 2 + d * d * 2 + act + B * H * d * 4
-    if kind == "dec_gemv_cq":    # combine + LN2 + cross query
-        return "hbm", d * d * 2 + B * H * d * 4 + 2 * act
-    if kind == "dec_cross_attn":  # 1500 K and V rows per slot + W_o + partial out
-        return "hbm", B * 2 * T * d * 2 + d * d * 2 + act + B * H * d * 4
+    if kind == "dec_self_attn":  # K,V rows of <= len cached positions, q in, att out
+        return "hbm", B * 2 * avg_len * d * 2 + 2 * act
+    if kind in ("dec_gemv_oproj", "dec_gemv_coproj"):   # x += W att + b
+        return "hbm", d * d * 2 + 3 * act
+    if kind == "dec_gemv_cq":    # LN2 + cross query
+        return "hbm", d * d * 2 + 2 * act
+    if kind == "dec_cross_attn":  # 1500 K and V rows per slot, q in, att out
+        return "hbm", B * 2 * T * d * 2 + 2 * act
     if kind == "dec_gemv_fc1":
-        return "hbm", 4 * d * d * 2 + B * H * d * 4 + act + B * 4 * d * 2
+        return "hbm", 4 * d * d * 2 + act + B * 4 * d * 2
     if kind == "dec_gemv_fc2":
         return "hbm", 4 * d * d * 2 + B * 4 * d * 2 + 2 * act
     if kind == "dec_gemv_logits":  # final LN + tied-embedding logits

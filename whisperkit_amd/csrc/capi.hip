@@ -13,7 +13,7 @@
 
 using namespace wh;
 
-namespace wh { thread_local KernelProfiler* g_prof = nullptr; }
+namespace wh { thread_local KernelProfiler* g_prof = nullptr; unsigned long long* debug_buffer(); }
 
 namespace whi {
 static thread_local char g_err[512] = "";
@@ -297,14 +297,16 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->h1, B * kFramesPad * d); DALLOC(s->x, B * kCtx * d); DALLOC(s->xn, B * kCtx * d);
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
-    DALLOC(s->cross_kv, B * kCtx * L * 2 * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
-    DALLOC(s->xa, B * d); DALLOC(s->xb, B * d); DALLOC(s->q, B * d); DALLOC(s->partial, B * H * d); DALLOC(s->logits, B * V);
+    DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
+    DALLOC(s->xa, B * d); DALLOC(s->q, B * d); DALLOC(s->att, B * d); DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
+    DALLOC(s->logits, B * V);
     DALLOC(s->hbuf, B * 4 * d);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
     DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress);
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
+    (void)wh::debug_buffer();   // WH_DBG=1 probe buffer must exist before any stream capture
     *out = s;
     return WH_OK;
 }
@@ -314,7 +316,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->st) hipStreamSynchronize(s->st);
     whi::drop_session_graphs(s);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
-                    s->hmlp, s->enc16, s->enc32, s->cross_kv, s->self_k, s->self_v, s->xa, s->xb, s->q, s->partial, s->logits, s->hbuf,
+                    s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->xa, s->q, s->att, s->part, s->ticket, s->logits, s->hbuf,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->seq_host) hipHostFree(s->seq_host);
@@ -445,10 +447,10 @@ namespace whi {
 DecodeBuffers decode_buffers(wh_session* s, int batch) {
     const wh_model* m = s->m;
     DecodeBuffers db{};
-    db.batch = batch; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
+    db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
-    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_kv = s->cross_kv; db.xa = s->xa; db.xb = s->xb; db.q = s->q; db.hbuf = s->hbuf;
-    db.partial = s->partial; db.logits = s->logits; db.seq = s->seq;
+    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v; db.x = s->xa; db.q = s->q; db.att = s->att;
+    db.hbuf = s->hbuf; db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
     return db;
 }
@@ -476,9 +478,9 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     const int d = m->dims.n_text_state, L = m->dims.n_text_layer;
     GemmArgs g{};
     g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
-    g.ldc = L * 2 * d; g.out16 = s->cross_kv;
+    g.ldc = L * 2 * d; g.k16 = s->cross_k; g.vt16 = s->cross_v; g.d_model = d; g.max_batch = s->B;
     g.prof_kind = KK_CROSS_KV;
-    launch_gemm(EPI_F16, g, s->st);
+    launch_gemm(EPI_CROSS_KV, g, s->st);
     WH_CHECK_LAUNCH();
     return wh_reset_decoder_inputs(s, batch);
 }

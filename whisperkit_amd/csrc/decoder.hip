@@ -5,270 +5,450 @@
 // memory (SeqState), so a step is a fixed kernel chain with no host round trip: the next input token,
 // the cache position and the stop flag are read from / written to SeqState by the kernels themselves.
 //
-// This path is HBM/L2-bandwidth and launch-latency bound (GEMV over fp16 weights, M = batch <= 8 rows):
-// no MFMA.  Per layer the chain is 6 kernels; the two attention out-projections are folded into the
-// attention kernels as per-head slabs (y = sum_h W_o[:, h] a_h) whose partial sums are combined, in a
-// fixed order, in the prologue of the next kernel - that removes two launches per layer and keeps the
-// result bit-deterministic (no float atomics).
+// This path is HBM-bandwidth and launch-latency bound (fp16 weight / KV streaming against <= 8 activation
+// rows per batch tile): no MFMA.  Every grid-wide dependency of a decoder layer is one kernel boundary
+// (cheaper on gfx950 than an in-kernel grid barrier, MI355X_MICROARCH.md "boundary" vs "barrier-xcd"):
 //
-//   gemv<QKV>    LN1(x) -> q (f32), k/v straight into the self-attention KV cache at position `pos`
-//   self_attn    one workgroup per (head, slot): softmax(q K^T) V over <= 224 cached positions, W_o slab
-//   gemv<CQ>     x += b_o + sum_h partial_h ; LN2 -> cross-attention query
-//   cross_attn   one workgroup per (head, slot): 1500 cached cross K/V rows, alignment-head row, W_o slab
-//   gemv<FC1>    x += b_co + sum_h partial_h ; LN3 -> GELU(fc1)
-//   gemv<FC2>    x += b_2 + W_2 h
-//   gemv<LOGITS> LN_f(x) . E^T  (tied embedding)
-//   sampler      logits filters + greedy/top-k sample + decodeText state advance
+//   gemv<QKV>     LN1(x) -> q (f32); k, v straight into the head-major self-attention cache at `pos`
+//   self_attn     one workgroup per (head, slot): softmax(q K^T) V over <= 224 cached positions -> att
+//   gemv<RESID>   x += W_o att + b_o
+//   gemv<Q>       LN2(x) -> cross-attention query
+//   cross_attn    workgroups per (key split, head, slot) over the 1500 cached cross K/V rows (flash-decoding
+//                 split; the last-arriving split combines the partials in a fixed order -> att); alignment heads
+//                 also store their raw score row (DecodingCache.alignmentWeights row tokenIndex + 1)
+//   gemv<RESID>   x += W_co att + b_co
+//   gemv<FC1>     LN3(x) -> GELU(fc1) (f16)
+//   gemv<FC2>     x += W_2 h + b_2
+//   ... per layer, then
+//   gemv<LOGITS>  LN_f(x) . E^T  (tied embedding)
+//   sampler       logits filters + greedy/top-k sample + decodeText state advance
+//
+// GEMV kernels: the LN prologue runs in registers (a row is spread over 256/BT lanes), the normalised
+// activations of the batch tile sit in LDS as f32, weights stream as 16-byte loads with the next
+// K-slice prefetched under the current one's FMAs (first slice issued before the prologue), a wave owns
+// R rows x BT slots = 32 accumulators and finishes with a transposing butterfly (31 shuffles).
+// All results are bit-deterministic (fixed summation orders, no float atomics).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace wh {
 
-enum { MODE_QKV = 0, MODE_CQ = 1, MODE_FC1 = 2, MODE_FC2 = 3, MODE_LOGITS = 4 };
+enum { MODE_QKV = 0, MODE_Q = 1, MODE_RESID = 2, MODE_FC1 = 3, MODE_FC2 = 4, MODE_LOGITS = 5 };
 
 struct GemvArgs {
-    int batch, d, n_head, N, K, rows_per_block, n_vocab;
-    int layer;                 // MODE_QKV: layer index (0 -> embed)
+    int batch, d, n_head, N, K, rows_per_block, k_split, n_vocab;
+    int layer;                 // MODE_QKV: layer index (0 -> token + position embedding prologue)
     const f16* W;              // [N][K]
     const float* bias;         // [N] or null
-    const float *ln_g, *ln_b;  // prologue LayerNorm
-    const float* xin;          // residual in  [B][d]
-    float* xout;               // residual out [B][d] (written by block 0 when the prologue changes x)
-    const float* comb_bias;    // out-proj bias added in the combine prologue
-    const float* partial;      // [B][H][d]
+    const float *ln_g, *ln_b;  // prologue LayerNorm (QKV, Q, FC1, LOGITS)
+    float* x;                  // residual stream [B][d]
+    const float* ain;          // MODE_RESID input [B][d] f32 (attention output)
     const f16* emb; const float* pos;   // layer-0 embedding
-    float* q;                  // [B][d] f32 query out (QKV / CQ)
-    f16* self_k; f16* self_v;  // this layer's cache base [B][224][d]
+    float* q;                  // [B][d] f32 query out (QKV / Q)
+    f16* self_k; f16* self_v;  // this layer's cache base [Bmax][H][224][64]
     f16* hbuf;                 // [B][4d]
     float* logits;             // [B][V]
     SeqState* seq;
+    unsigned long long* dbg;   // optional timeline probe (WH_DBG=1): 8 timestamps per workgroup
+    int xflags;                // experiment knobs (WH_XFLAGS): 1 no weight loads, 2 no gamma/beta loads, 4 no FMA loop, 8 no LDS x reads
 };
+
+#define DBG_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = ((i) == 6) ? (unsigned long long)clock64() : ((i) == 7 ? (unsigned long long)clock64() : (unsigned long long)wall_clock64()); } while (0)
 
 __device__ __forceinline__ bool slot_live(const SeqState* s) { return s->active && !s->done; }
 
 // Sum 64 lanes of N values each; afterwards lane L holds the total of value index L >> (6 - log2 N)
-// (N = 4, 8, 16, 32).  Costs N-1 + (6 - log2 N) shuffles instead of 6 N.
-template <int N>
-__device__ __forceinline__ float reduce_transpose(float (&v)[N], int lane) {
-    int off = 32;
+// (N = 4, 8, 16, 32).  Costs N-1 + (6 - log2 N) shuffles instead of 6 N.  Template recursion keeps every
+// register-array index a compile-time constant (a runtime-bounded loop here turns into v_cndmask chains).
+template <int N, int OFF>
+struct ReduceTranspose {
+    static __device__ __forceinline__ float run(float* v, int lane) {
+        const bool upper = (lane & OFF) != 0;
 #pragma unroll
-    for (int n = N; n > 1; n >>= 1, off >>= 1) {
-        const bool upper = (lane & off) != 0;
-#pragma unroll
-        for (int i = 0; i < n / 2; ++i) {
-            float send = upper ? v[i] : v[i + n / 2];
-            float keep = upper ? v[i + n / 2] : v[i];
-            v[i] = keep + __shfl_xor(send, off, 64);
+        for (int i = 0; i < N / 2; ++i) {
+            float send = upper ? v[i] : v[i + N / 2];
+            float keep = upper ? v[i + N / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, OFF, 64);
         }
+        return ReduceTranspose<N / 2, OFF / 2>::run(v, lane);
     }
-    float r = v[0];
-    for (; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-    return r;
+};
+template <int OFF>
+struct ReduceTranspose<1, OFF> {
+    static __device__ __forceinline__ float run(float* v, int lane) {
+        float r = v[0];
+#pragma unroll
+        for (int o = OFF; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        return r;
+    }
+};
+template <int N>
+__device__ __forceinline__ float reduce_transpose(float (&v)[N], int lane) { return ReduceTranspose<N, 32>::run(v, lane); }
+
+// sum over the TPR consecutive threads that share one activation row (TPR a power of two; rows never straddle a
+// wave when TPR <= 64, otherwise a row is TPR/64 whole waves and the wave totals meet in LDS)
+template <int TPR, int NT>
+__device__ __forceinline__ float row_sum(float v, float* red) {
+    if constexpr (TPR <= 64) {
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    } else {
+        constexpr int WPR = TPR / 64;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const int w0 = (wave / WPR) * WPR;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < WPR; ++i) s += red[w0 + i];
+        return s;
+    }
 }
 
-template <int MODE, int BT>
-__global__ __launch_bounds__(256) void dec_gemv_kernel(const GemvArgs a) {
+// Workgroup = 4 waves arranged as KS K-splits x RG = 4 / KS row groups.  A wave owns R weight rows and the K range
+// [ks * K / KS, (ks + 1) * K / KS) of them (<= 1536 columns = 3 slices of 512 = 64 lanes x 8 halves), and issues ALL of its
+// weight loads before touching them: these matrices are a few MB spread over 256 CUs, so the only way to reach the
+// HBM rate is to have every byte of the matrix in flight at once (the first row group's loads are issued before the
+// prologue; in multi-pass launches - the logits - the next pass is prefetched under the current one's FMAs).
+template <int MODE, int BT, int R>
+__global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
+    constexpr int NT = 256, NW = 4, KI = 3;
+    constexpr int NV = R * BT;                              // accumulators per lane (<= 32)
+    constexpr bool kPrefetchNextPass = (MODE == MODE_LOGITS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);   // [BT][K] f32   (MODE_FC2: f16 [BT][K])
     f16* xh = reinterpret_cast<f16*>(smem_raw);
+    __shared__ float red[NW];
+    __shared__ float kred[NW][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.y * BT;
     const int K = a.K, d = a.d;
-
+    const int KS = a.k_split, RG = NW / KS;
+    const int ks = wave % KS, rg = wave / KS;
+    const int KC = K / KS, kbase = ks * KC;
     bool any_live = false;
 #pragma unroll
     for (int i = 0; i < BT; ++i)
         if (b0 + i < a.batch) any_live |= slot_live(&a.seq[b0 + i]);
     if (!any_live) return;
+    DBG_STAMP(6);
 
-    // ------------------------------------------------------------------ prologue -> xs
-    if constexpr (MODE == MODE_FC2) {
-        for (int idx = tid; idx < BT * K / 8; idx += 256) {
-            int b = idx / (K / 8), c = idx - b * (K / 8);
-            uint4 v = (b0 + b < a.batch) ? reinterpret_cast<const uint4*>(a.hbuf + (size_t)(b0 + b) * K)[c] : uint4{0, 0, 0, 0};
-            reinterpret_cast<uint4*>(xh + (size_t)b * K)[c] = v;
-        }
-        __syncthreads();
-    } else {
-        for (int idx = tid; idx < BT * d; idx += 256) {
-            int b = idx / d, c = idx - b * d;
-            int gb = b0 + b;
-            float x = 0.0f;
-            if (gb < a.batch) {
-                if (MODE == MODE_QKV && a.layer == 0) {
-                    int tok = min(max(a.seq[gb].next_token, 0), a.n_vocab - 1);
-                    int pos = min(max(a.seq[gb].token_index, 0), kMaxTok - 1);
-                    x = (float)a.emb[(size_t)tok * d + c] + a.pos[(size_t)pos * d + c];
-                } else if (MODE == MODE_CQ || MODE == MODE_FC1) {
-                    x = a.xin[(size_t)gb * d + c] + a.comb_bias[c];
-                    const float* pp = a.partial + (size_t)gb * a.n_head * d + c;
-                    for (int h = 0; h < a.n_head; ++h) x += pp[(size_t)h * d];
-                } else {
-                    x = a.xin[(size_t)gb * d + c];
-                }
-                if (blockIdx.x == 0 && (MODE == MODE_CQ || MODE == MODE_FC1 || (MODE == MODE_QKV && a.layer == 0)))
-                    a.xout[(size_t)gb * d + c] = x;
-            }
-            xs[b * d + c] = x;
-        }
-        __syncthreads();
-        // LayerNorm in place, one wave per slot (two-pass, same arithmetic as layernorm_kernel)
-        for (int b = wave; b < BT; b += 4) {
-            float s = 0.0f;
-            for (int c = lane; c < d; c += 64) s += xs[b * d + c];
-            const float mean = wave_sum(s) / (float)d;
-            float qv = 0.0f;
-            for (int c = lane; c < d; c += 64) { float t = xs[b * d + c] - mean; qv += t * t; }
-            const float rstd = rsqrtf(wave_sum(qv) / (float)d + 1e-5f);
-            for (int c = lane; c < d; c += 64) xs[b * d + c] = (xs[b * d + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
-        }
-        __syncthreads();
-    }
-
-    // ------------------------------------------------------------------ GEMV: 4 rows per wave pass
     const int n_begin = blockIdx.x * a.rows_per_block;
     const int n_end = min(a.N, n_begin + a.rows_per_block);
-    for (int n4 = n_begin + wave * 4; n4 < n_end; n4 += 16) {
-        float acc[4 * BT];
+    const int rows_per_pass = RG * R;
+    const int n_pass = (n_end - n_begin + rows_per_pass - 1) / rows_per_pass;
+
+    uint4 cur[R][KI];
+    auto load_group = [&](uint4 (&dst)[R][KI], int n0) {
 #pragma unroll
-        for (int i = 0; i < 4 * BT; ++i) acc[i] = 0.0f;
-        const f16* wrow[4];
+        for (int r = 0; r < R; ++r) {
+            const f16* wr = a.W + (size_t)min(n0 + r, a.N - 1) * K + kbase + lane * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wrow[r] = a.W + (size_t)min(n4 + r, a.N - 1) * K;
-        for (int k = lane * 8; k < K; k += 512) {
-            uint4 wv[4];
+            for (int i = 0; i < KI; ++i)
+                dst[r][i] = (lane * 8 + 512 * i < KC && !(a.xflags & 1)) ? *reinterpret_cast<const uint4*>(wr + 512 * i) : uint4{0, 0, 0, 0};
+        }
+    };
+
+    // ------------------------------------------------------------------ prologue -> LDS
+    // Issue order matters: memory returns are in order per wave, so the (small, L2-resident) activation loads go out
+    // first and the weight stream (HBM) second - the LayerNorm then runs while the weights are still in flight.
+    if constexpr (MODE == MODE_FC2) {
+        constexpr int HV = (BT * 640 + NT - 1) / NT;    // uint4 per thread, K <= 5120
+        uint4 hreg[HV];
+        const int per_row = K / 8;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wv[r] = *reinterpret_cast<const uint4*>(wrow[r] + k);
-            float xk[BT][8];
+        for (int i = 0; i < HV; ++i) {
+            const int idx = tid + i * NT;
+            const int b = idx / per_row, c = idx - b * per_row;
+            hreg[i] = (idx < BT * per_row && b0 + b < a.batch) ? reinterpret_cast<const uint4*>(a.hbuf + (size_t)(b0 + b) * K)[c] : uint4{0, 0, 0, 0};
+        }
+        load_group(cur, n_begin + rg * R);
+        DBG_STAMP(1);
 #pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                if constexpr (MODE == MODE_FC2) {
-                    f16x8 hv = *reinterpret_cast<const f16x8*>(xh + (size_t)b * K + k);
+        for (int i = 0; i < HV; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < BT * per_row) reinterpret_cast<uint4*>(xh)[idx] = hreg[i];
+        }
+    } else if constexpr (MODE == MODE_RESID) {
+        constexpr int AV = (BT * 320 + NT - 1) / NT;    // float4 per thread, d <= 1280
+        float4 areg[AV];
+        const int per_row = d / 4;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xk[b][j] = (float)hv[j];
-                } else {
-                    float4 x0 = *reinterpret_cast<const float4*>(xs + b * K + k);
-                    float4 x1 = *reinterpret_cast<const float4*>(xs + b * K + k + 4);
-                    xk[b][0] = x0.x; xk[b][1] = x0.y; xk[b][2] = x0.z; xk[b][3] = x0.w;
-                    xk[b][4] = x1.x; xk[b][5] = x1.y; xk[b][6] = x1.z; xk[b][7] = x1.w;
-                }
+        for (int i = 0; i < AV; ++i) {
+            const int idx = tid + i * NT;
+            const int b = idx / per_row, c = idx - b * per_row;
+            areg[i] = (idx < BT * per_row && b0 + b < a.batch) ? reinterpret_cast<const float4*>(a.ain + (size_t)(b0 + b) * d)[c] : float4{0, 0, 0, 0};
+        }
+        load_group(cur, n_begin + rg * R);
+        DBG_STAMP(1);
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < BT * per_row) reinterpret_cast<float4*>(xs)[idx] = areg[i];
+        }
+    } else {
+        // LayerNorm in registers: row = tid / TPR, the row's d/4 float4 are dealt round-robin to its TPR threads
+        constexpr int TPR = NT / BT;
+        constexpr int MAXV = (320 + TPR - 1) / TPR;     // d <= 1280
+        const int row = tid / TPR, li = tid - row * TPR;
+        const int gb = b0 + row;
+        const bool rok = gb < a.batch;
+        const int nv4 = d / 4;
+        float4 v[MAXV];
+        // gamma / beta: issued first (they depend on nothing), parked in LDS behind the activations, read back after the
+        // row statistics - a dependent global load after the statistics would put a second L2 round trip on the critical path
+        float* gb_l = xs + (size_t)BT * K;      // [2][d]
+        constexpr int GV = (2 * 320 + NT - 1) / NT;
+        float4 g_reg[GV];
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int idx = tid + i * NT;       // float4 index into gamma (first d/4) then beta
+            g_reg[i] = idx < 2 * nv4 ? *reinterpret_cast<const float4*>((idx < nv4 ? a.ln_g : a.ln_b - d) + (size_t)idx * 4) : float4{0, 0, 0, 0};
+        }
+        const bool embed = (MODE == MODE_QKV) && a.layer == 0;
+        if (embed) {
+            int tok = 0, pos = 0;
+            if (rok) {
+                tok = min(max(a.seq[gb].next_token, 0), a.n_vocab - 1);
+                pos = min(max(a.seq[gb].token_index, 0), kMaxTok - 1);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f16x8 wh8 = *reinterpret_cast<f16x8*>(&wv[r]);
+            for (int i = 0; i < MAXV; ++i) {
+                const int c4 = li + i * TPR;
+                float4 t = float4{0, 0, 0, 0};
+                if (rok && c4 < nv4) {
+                    f16x4 e = *reinterpret_cast<const f16x4*>(a.emb + (size_t)tok * d + c4 * 4);
+                    float4 p = *reinterpret_cast<const float4*>(a.pos + (size_t)pos * d + c4 * 4);
+                    t = float4{(float)e[0] + p.x, (float)e[1] + p.y, (float)e[2] + p.z, (float)e[3] + p.w};
+                    if (blockIdx.x == 0) *reinterpret_cast<float4*>(a.x + (size_t)gb * d + c4 * 4) = t;
+                }
+                v[i] = t;
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float wf = (float)wh8[j];
+            for (int i = 0; i < MAXV; ++i) {
+                const int c4 = li + i * TPR;
+                v[i] = (rok && c4 < nv4) ? *reinterpret_cast<const float4*>(a.x + (size_t)gb * d + c4 * 4) : float4{0, 0, 0, 0};
+            }
+        }
+        load_group(cur, n_begin + rg * R);
+        DBG_STAMP(1);
 #pragma unroll
-                    for (int b = 0; b < BT; ++b) acc[r * BT + b] = fmaf(wf, xk[b][j], acc[r * BT + b]);
+        for (int i = 0; i < GV; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < 2 * nv4) reinterpret_cast<float4*>(gb_l)[idx] = g_reg[i];
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = row_sum<TPR, NT>(s, red) / (float)d;
+        float qv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (li + i * TPR < nv4) {
+                float ax = v[i].x - mean, ay = v[i].y - mean, az = v[i].z - mean, aw = v[i].w - mean;
+                qv += (ax * ax + ay * ay) + (az * az + aw * aw);
+            }
+        }
+        const float rstd = rsqrtf(row_sum<TPR, NT>(qv, red) / (float)d + 1e-5f);
+        __syncthreads();    // gamma / beta visible
+        DBG_STAMP(0);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = li + i * TPR;
+            if (c4 < nv4) {
+                const float4 g = reinterpret_cast<const float4*>(gb_l)[c4];
+                const float4 be = reinterpret_cast<const float4*>(gb_l)[nv4 + c4];
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * g.x + be.x; o.y = (v[i].y - mean) * rstd * g.y + be.y;
+                o.z = (v[i].z - mean) * rstd * g.z + be.z; o.w = (v[i].w - mean) * rstd * g.w + be.w;
+                if (!rok) o = float4{0, 0, 0, 0};
+                *reinterpret_cast<float4*>(xs + (size_t)row * d + c4 * 4) = o;
+            }
+        }
+    }
+    __syncthreads();
+    DBG_STAMP(2);
+
+    // ------------------------------------------------------------------ GEMV passes
+#pragma unroll 1
+    for (int p = 0; p < n_pass; ++p) {
+        const int n0 = n_begin + (p * RG + rg) * R;
+        uint4 nxt[kPrefetchNextPass ? R : 1][kPrefetchNextPass ? KI : 1];
+        if constexpr (kPrefetchNextPass) {
+            if (p + 1 < n_pass) load_group(nxt, n_begin + ((p + 1) * RG + rg) * R);
+        }
+        float acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int kl = lane * 8 + 512 * i;     // column inside this wave's K range
+            if (kl < KC && !(a.xflags & 4)) {
+                const int k = kbase + kl;
+                // activations in chunks of <= 4 slots: bounds the live x registers (accumulation order per output unchanged)
+                constexpr int BC = BT < 4 ? BT : 4;
+#pragma unroll
+                for (int bc = 0; bc < BT; bc += BC) {
+                    float xk[BC][8];
+#pragma unroll
+                    for (int b = 0; b < BC; ++b) {
+                        if constexpr (MODE == MODE_FC2) {
+                            f16x8 hv = *reinterpret_cast<const f16x8*>(xh + (size_t)(bc + b) * K + k);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xk[b][j] = (float)hv[j];
+                        } else {
+                            float4 x0 = float4{1, 2, 3, 4}, x1 = float4{5, 6, 7, 8};
+                            if (!(a.xflags & 8)) { x0 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k); x1 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k + 4); }
+                            xk[b][0] = x0.x; xk[b][1] = x0.y; xk[b][2] = x0.z; xk[b][3] = x0.w;
+                            xk[b][4] = x1.x; xk[b][5] = x1.y; xk[b][6] = x1.z; xk[b][7] = x1.w;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        f16x8 wh8 = *reinterpret_cast<f16x8*>(&cur[r][i]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float wf = (float)wh8[j];
+#pragma unroll
+                            for (int b = 0; b < BC; ++b) acc[r * BT + bc + b] = fmaf(wf, xk[b][j], acc[r * BT + bc + b]);
+                        }
+                    }
                 }
             }
         }
-        float tot = reduce_transpose<4 * BT>(acc, lane);
-        constexpr int SH = (BT == 1) ? 4 : (BT == 2) ? 3 : (BT == 4) ? 2 : 1;   // 6 - log2(4*BT)
-        if ((lane & ((1 << SH) - 1)) == 0) {
-            int idx = lane >> SH, r = idx / BT, b = idx - r * BT;
-            int n = n4 + r, gb = b0 + b;
+        DBG_STAMP(3);
+        float tot = reduce_transpose<NV>(acc, lane);
+        constexpr int SH = (NV == 32) ? 1 : (NV == 16) ? 2 : (NV == 8) ? 3 : (NV == 4) ? 4 : (NV == 2) ? 5 : 6;   // 6 - log2(NV)
+        const bool holder = (lane & ((1 << SH) - 1)) == 0;
+        const int idx = lane >> SH;
+        if (KS > 1) {   // K-split: the partial sums of a row group meet in LDS and are added in split order by split 0
+            if (holder) kred[wave][idx] = tot;
+            __syncthreads();
+            if (ks == 0 && holder) {
+                tot = kred[wave][idx];
+                for (int j = 1; j < KS; ++j) tot += kred[wave + j][idx];
+            }
+        }
+        if (ks == 0 && holder) {
+            const int r = idx / BT, b = idx - r * BT;
+            const int n = n0 + r, gb = b0 + b;
             if (n < n_end && gb < a.batch) {
                 float v = tot + (a.bias ? a.bias[n] : 0.0f);
                 if constexpr (MODE == MODE_QKV) {
                     int pos = min(max(a.seq[gb].token_index, 0), kMaxTok - 1);
                     if (n < d) a.q[(size_t)gb * d + n] = v;
-                    else if (n < 2 * d) a.self_k[((size_t)gb * kMaxTok + pos) * d + (n - d)] = (f16)v;
-                    else a.self_v[((size_t)gb * kMaxTok + pos) * d + (n - 2 * d)] = (f16)v;
-                } else if constexpr (MODE == MODE_CQ) {
+                    else {
+                        int c = n - d;
+                        f16* dst = a.self_k;
+                        if (c >= d) { c -= d; dst = a.self_v; }
+                        dst[(((size_t)gb * a.n_head + (c >> 6)) * kMaxTok + pos) * kHeadDim + (c & 63)] = (f16)v;
+                    }
+                } else if constexpr (MODE == MODE_Q) {
                     a.q[(size_t)gb * d + n] = v;
                 } else if constexpr (MODE == MODE_FC1) {
                     a.hbuf[(size_t)gb * a.N + n] = (f16)gelu_erf(v);
-                } else if constexpr (MODE == MODE_FC2) {
-                    a.xout[(size_t)gb * d + n] = a.xin[(size_t)gb * d + n] + v;
+                } else if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) {
+                    a.x[(size_t)gb * d + n] += v;
                 } else {
                     a.logits[(size_t)gb * a.N + n] = v;
                 }
             }
         }
+        DBG_STAMP(4);
+        if (KS > 1 && p + 1 < n_pass) __syncthreads();   // kred is reused by the next pass
+        if constexpr (kPrefetchNextPass) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < KI; ++i) cur[r][i] = nxt[r][i];
+        } else if (p + 1 < n_pass) {
+            load_group(cur, n_begin + ((p + 1) * RG + rg) * R);
+        }
     }
+    DBG_STAMP(5); DBG_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------- attention
 struct AttnArgs {
-    int batch, d, n_head, layer, n_layer;
+    int batch, d, n_head, layer, n_layer, n_split;
     const float* q;          // [B][d]
-    const f16* self_k; const f16* self_v;   // layer base [B][224][d]
-    const f16* cross_kv;     // [B*1500][L*2d]
-    const f16* o_w;          // [d][d] out projection
-    float* partial;          // [B][H][d]
-    float* align; const int* align_slot; int n_align;
+    const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
+    const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
+    float* att;              // [B][d] attention output (before the out projection)
+    float* part;             // [B][H][n_split][kPartStride]: (m, l, o[64]) of every key split, one 128-byte-aligned slot each
+    int* ticket;             // [B][H] arrival counters (zero between launches)
+    float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
 };
 
-// W_o slab: partial[n] = sum_c W_o[n][h*64 + c] * a[c]   (a in LDS)
-__device__ __forceinline__ void out_proj_slab(const f16* __restrict__ o_w, int d, int h, const float* a_lds,
-                                              float* __restrict__ partial_row) {
-    for (int n = threadIdx.x; n < d; n += blockDim.x) {
-        const uint4* wp = reinterpret_cast<const uint4*>(o_w + (size_t)n * d + h * kHeadDim);
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint4 wv = wp[i];
-            f16x8 w8 = *reinterpret_cast<f16x8*>(&wv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf((float)w8[j], a_lds[i * 8 + j], acc);
-        }
-        partial_row[n] = acc;
-    }
-}
-
-// attention of one query against `len` rows of K/V (row stride `ld` halves); result a[64] in LDS
-template <int MAXLEN>
-__device__ __forceinline__ void attend(const float* q_lds, const f16* __restrict__ kb, const f16* __restrict__ vb, size_t ld,
-                                       int len, float* sc /* [MAXLEN] */, float* red /* [>=16] */, float* a_out /* [64] */,
-                                       float* acc4 /* [4][64] */) {
+// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 halves).  Thread layout: 8 lanes per
+// key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
+// before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
+// o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
+template <int PASSES>
+__device__ __forceinline__ void attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n,
+                                             float* __restrict__ raw_scores, float* red /* [16] */, float* osum /* [4][64] */,
+                                             float* o_out /* [64] */, float* m_out, float* l_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = tid & 7, kg = tid >> 3;
+    uint4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int key = kg + 32 * i;
+        kreg[i] = key < n ? *reinterpret_cast<const uint4*>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int key = kg + 32 * i;
+        vreg[i] = key < n ? *reinterpret_cast<const uint4*>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+    }
+    float qv[8];
+    {
+        float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
+        float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
+        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    }
+    float s[PASSES];
     float lmax = -INFINITY;
-    for (int t = tid; t < len; t += 256) {
-        const uint4* kp = reinterpret_cast<const uint4*>(kb + (size_t)t * ld);
-        float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint4 kv = kp[i];
-            f16x8 k8 = *reinterpret_cast<f16x8*>(&kv);
+    for (int i = 0; i < PASSES; ++i) {
+        f16x8 k8 = *reinterpret_cast<f16x8*>(&kreg[i]);
+        float t = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s = fmaf((float)k8[j], q_lds[i * 8 + j], s);
-        }
-        sc[t] = s;
-        lmax = fmaxf(lmax, s);
+        for (int j = 0; j < 8; ++j) t = fmaf((float)k8[j], qv[j], t);
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        const int key = kg + 32 * i;
+        if (key < n) {
+            if (raw_scores && part == 0) raw_scores[key] = t;
+            lmax = fmaxf(lmax, t);
+        } else t = -INFINITY;
+        s[i] = t;
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float lsum = 0.0f;
-    for (int t = tid; t < len; t += 256) {
-        float p = expf(sc[t] - m);
-        sc[t] = p;
-        lsum += p;
-    }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red[4 + wave] = lsum;
-    __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    for (int t = tid; t < len; t += 256) sc[t] *= inv;
-    __syncthreads();
-    // O[c] = sum_t p[t] V[t][c]: lane = (t_sub = lane >> 3, 8 channels at (lane & 7) * 8); a wave covers 8 rows per load
-    const int ts = lane >> 3, c8 = (lane & 7) * 8;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-    for (int t0 = wave * 8; t0 < len; t0 += 32) {
-        int t = t0 + ts;
-        if (t < len) {
-            uint4 vv = *reinterpret_cast<const uint4*>(vb + (size_t)t * ld + c8);
-            f16x8 v8 = *reinterpret_cast<f16x8*>(&vv);
-            float p = sc[t];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
-        }
+    for (int i = 0; i < PASSES; ++i) {
+        const float p = (kg + 32 * i < n) ? __expf(s[i] - m) : 0.0f;
+        if (part == 0) lsum += p;
+        f16x8 v8 = *reinterpret_cast<f16x8*>(&vreg[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
     }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = o[j];
@@ -277,50 +457,83 @@ __device__ __forceinline__ void attend(const float* q_lds, const f16* __restrict
         v += __shfl_xor(v, 32, 64);
         o[j] = v;
     }
-    if (ts == 0) {
+    if (lane < 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc4[wave * 64 + c8 + j] = o[j];
+        for (int j = 0; j < 8; ++j) osum[wave * 64 + lane * 8 + j] = o[j];
     }
     __syncthreads();
-    if (tid < 64) a_out[tid] = acc4[tid] + acc4[64 + tid] + acc4[128 + tid] + acc4[192 + tid];
-    __syncthreads();
+    if (tid < 64) o_out[tid] = (osum[tid] + osum[64 + tid]) + (osum[128 + tid] + osum[192 + tid]);
+    *m_out = m;
+    *l_out = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
-    __shared__ float q_l[64], a_l[64], sc[kMaxTok], red[16], acc4[256];
+    __shared__ float red[16], osum[256], o_l[64];
     const int h = blockIdx.x, b = blockIdx.y;
     if (!slot_live(&a.seq[b])) return;
     const int pos = min(max(a.seq[b].token_index, 0), kMaxTok - 1);
     const int d = a.d;
-    if (threadIdx.x < 64) q_l[threadIdx.x] = a.q[(size_t)b * d + h * kHeadDim + threadIdx.x];
-    __syncthreads();
-    const f16* kb = a.self_k + (size_t)b * kMaxTok * d + h * kHeadDim;
-    const f16* vb = a.self_v + (size_t)b * kMaxTok * d + h * kHeadDim;
-    attend<kMaxTok>(q_l, kb, vb, (size_t)d, pos + 1, sc, red, a_l, acc4);
-    out_proj_slab(a.o_w, d, h, a_l, a.partial + ((size_t)b * a.n_head + h) * d);
+    const size_t base = ((size_t)b * a.n_head + h) * kMaxTok * kHeadDim;
+    float m, l;
+    attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, pos + 1, nullptr, red, osum, o_l, &m, &l);
+    if (threadIdx.x < 64) a.att[(size_t)b * d + h * kHeadDim + threadIdx.x] = o_l[threadIdx.x] / l;
 }
 
+template <int PASSES>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
-    __shared__ float q_l[64], a_l[64], sc[kCtx + 4], red[16], acc4[256];
-    const int h = blockIdx.x, b = blockIdx.y;
+    constexpr int KPB = PASSES * 32;
+    __shared__ float red[16], osum[256], o_l[64];
+    __shared__ int last_flag;
+    const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     if (!slot_live(&a.seq[b])) return;
     const int pos = min(max(a.seq[b].token_index, 0), kMaxTok - 1);
-    const int d = a.d;
-    if (threadIdx.x < 64) q_l[threadIdx.x] = a.q[(size_t)b * d + h * kHeadDim + threadIdx.x];
-    __syncthreads();
-    const size_t ld = (size_t)a.n_layer * 2 * d;
-    const f16* kb = a.cross_kv + (size_t)b * kCtx * ld + (size_t)a.layer * 2 * d + h * kHeadDim;
-    const f16* vb = kb + d;
-    attend<kCtx>(q_l, kb, vb, ld, kCtx, sc, red, a_l, acc4);
-    // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296)
+    const int d = a.d, S = a.n_split;
+    const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
+    const size_t base = (((size_t)b * a.n_head + h) * kCtx + t0) * kHeadDim;
+    // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296), raw scores here,
+    // softmax + head mean in alignment_mean_kernel
+    float* raw = nullptr;
     if (a.align) {
         int slot = a.align_slot[a.layer * a.n_head + h];
-        if (slot >= 0 && pos + 1 < kMaxTok) {
-            float* dst = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx;
-            for (int t = threadIdx.x; t < kCtx; t += 256) dst[t] = sc[t];
-        }
+        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
     }
-    out_proj_slab(a.o_w, d, h, a_l, a.partial + ((size_t)b * a.n_head + h) * d);
+    float m, l;
+    attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, raw, red, osum, o_l, &m, &l);
+    // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
+    const int tid = threadIdx.x;
+    float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
+    // write-through (sc1) stores + drained ticket: no per-workgroup L2 write-back (MI355X_MICROARCH.md "publish-large")
+    if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 64) {
+        __hip_atomic_store(mine, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int* cnt = a.ticket + b * a.n_head + h;
+        int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = (t == S - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (last_flag && tid < 64) {
+        const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
+        float mg = -INFINITY;
+        auto ld = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // sc1: L1 bypass
+        for (int i = 0; i < S; ++i) mg = fmaxf(mg, ld(p0 + i * kPartStride));
+        float lg = 0.0f, og = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            const float w = __expf(ld(p0 + i * kPartStride) - mg);
+            lg = fmaf(w, ld(p0 + i * kPartStride + 1), lg);
+            og = fmaf(w, ld(p0 + i * kPartStride + 2 + tid), og);
+        }
+        a.att[(size_t)b * d + h * kHeadDim + tid] = og / lg;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- sampler
@@ -586,66 +799,115 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-template <int MODE>
-static void launch_gemv(const GemvArgs& a, hipStream_t st) {
-    int bt = a.batch >= 8 ? 8 : a.batch >= 3 ? 4 : a.batch;   // 1, 2, 4, 8
-    if (bt == 3) bt = 4;
-    dim3 g((a.N + a.rows_per_block - 1) / a.rows_per_block, (a.batch + bt - 1) / bt);
-    size_t smem = (MODE == MODE_FC2) ? (size_t)bt * a.K * sizeof(f16) : (size_t)bt * a.K * sizeof(float);
+static unsigned long long* g_dbg_buf = nullptr;   // [KK_COUNT][4096][8]
+static int g_dbg_kind = 0;
+unsigned long long* debug_buffer() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("WH_DBG"); on = (e && e[0] == '1'); if (on) { (void)hipMalloc((void**)&g_dbg_buf, (size_t)KK_COUNT * 4096 * 8 * 8); (void)hipMemset(g_dbg_buf, 0, (size_t)KK_COUNT * 4096 * 8 * 8); } }
+    return g_dbg_buf;
+}
+
+template <int MODE, int BT, int R>
+static void launch_gemv_r(GemvArgs a, int passes, hipStream_t st) {
+    a.dbg = debug_buffer() ? debug_buffer() + (size_t)g_dbg_kind * 4096 * 8 : nullptr;
+    { static int xf = -1; if (xf < 0) { const char* e = getenv("WH_XFLAGS"); xf = e ? atoi(e) : 0; } a.xflags = xf; }
+    a.rows_per_block = (4 / a.k_split) * R * passes;
+    dim3 g((a.N + a.rows_per_block - 1) / a.rows_per_block, (a.batch + BT - 1) / BT);
+    const bool ln_mode = MODE == MODE_QKV || MODE == MODE_Q || MODE == MODE_FC1 || MODE == MODE_LOGITS;
+    const size_t smem = (MODE == MODE_FC2) ? (size_t)BT * a.K * sizeof(f16) : (size_t)(BT * a.K + (ln_mode ? 2 * a.d : 0)) * sizeof(float);
     if (smem > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation (160 KB per CU on gfx950)
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv_kernel<MODE, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv_kernel<MODE, BT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // + static LDS <= 160 KB
             raised = true;
         }
     }
-    switch (bt) {
-        case 1: dec_gemv_kernel<MODE, 1><<<g, 256, smem, st>>>(a); break;
-        case 2: dec_gemv_kernel<MODE, 2><<<g, 256, smem, st>>>(a); break;
-        case 4: dec_gemv_kernel<MODE, 4><<<g, 256, smem, st>>>(a); break;
-        default: dec_gemv_kernel<MODE, 8><<<g, 256, smem, st>>>(a); break;
-    }
+    dec_gemv_kernel<MODE, BT, R><<<g, 256, smem, st>>>(a);
 }
 
+template <int MODE, int BT>
+static void launch_gemv_bt(GemvArgs a, hipStream_t st) {
+    // K-split so that a wave's K range fits its 3 x 512-column register slices; rows per wave: the largest of 4 / 2 / 1 that
+    // still yields >= 256 workgroups (one per CU); the logits matrix runs 4 row passes per workgroup with prefetch
+    a.k_split = a.K <= 1536 ? 1 : a.K <= 3072 ? 2 : 4;
+    const int rg = 4 / a.k_split;
+    const int passes = (MODE == MODE_LOGITS) ? 4 : 1;
+    if ((a.N + rg * 4 - 1) / (rg * 4) >= 256) launch_gemv_r<MODE, BT, 4>(a, passes, st);
+    else if ((a.N + rg * 2 - 1) / (rg * 2) >= 256) launch_gemv_r<MODE, BT, 2>(a, passes, st);
+    else launch_gemv_r<MODE, BT, 1>(a, passes, st);
+}
+
+template <int MODE>
+static void launch_gemv(const GemvArgs& a, hipStream_t st) {
+    if (a.batch >= 5) launch_gemv_bt<MODE, 8>(a, st);
+    else if (a.batch >= 2) launch_gemv_bt<MODE, 4>(a, st);
+    else launch_gemv_bt<MODE, 1>(a, st);
+}
+
+int cross_attn_splits(int batch, int n_head) {
+    // keys per workgroup 256 / 128 / 64: the coarsest split that still gives >= 512 workgroups
+    for (int passes = 8; passes >= 4; passes >>= 1) {
+        int s = (kCtx + passes * 32 - 1) / (passes * 32);
+        if (s * n_head * batch >= 512) return s;
+    }
+    return (kCtx + 63) / 64;
+}
 
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st) {
     const int d = db.d, B = db.batch, H = db.n_head, L = db.n_layer;
-    float* xcur = db.xa;
-    float* xalt = db.xb;
+    const size_t self_stride = (size_t)db.max_batch * H * kMaxTok * kHeadDim;
+    const size_t cross_stride = (size_t)db.max_batch * H * kCtx * kHeadDim;
+    const int S = cross_attn_splits(B, H);
+    static int same_layer = -1;   // experiment knob: WH_SAME_LAYER=1 reuses layer 0's weights for every layer, =2 also its K/V
+    if (same_layer < 0) { const char* e = getenv("WH_SAME_LAYER"); same_layer = e ? atoi(e) : 0; }
     for (int l = 0; l < L; ++l) {
-        const DecLayerW& w = db.layers_host[l];
+        const DecLayerW& w = db.layers_host[same_layer ? 0 : l];
+        const int lkv = same_layer >= 2 ? 0 : l;
         GemvArgs g{};
-        g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = l; g.n_vocab = db.n_vocab;
-        // QKV
-        g.N = 3 * d; g.K = d; g.rows_per_block = 16; g.W = w.qkv_w; g.bias = w.qkv_b; g.ln_g = w.ln1_g; g.ln_b = w.ln1_b;
-        g.xin = xcur; g.xout = xcur; g.emb = db.emb; g.pos = db.pos; g.q = db.q;
-        g.self_k = db.self_k + (size_t)l * B * kMaxTok * d; g.self_v = db.self_v + (size_t)l * B * kMaxTok * d;
-        { ProfScope ps_(KK_DEC_QKV, st); launch_gemv<MODE_QKV>(g, st); }
+        g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = l; g.n_vocab = db.n_vocab; g.x = db.x;
+        // LN1 + QKV
+        g.N = 3 * d; g.K = d; g.W = w.qkv_w; g.bias = w.qkv_b; g.ln_g = w.ln1_g; g.ln_b = w.ln1_b;
+        g.emb = db.emb; g.pos = db.pos; g.q = db.q;
+        g.self_k = db.self_k + (size_t)lkv * self_stride; g.self_v = db.self_v + (size_t)lkv * self_stride;
+        { ProfScope ps_(KK_DEC_QKV, st); g_dbg_kind = KK_DEC_QKV; launch_gemv<MODE_QKV>(g, st); }
         AttnArgs at{};
-        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.q = db.q; at.self_k = g.self_k; at.self_v = g.self_v;
-        at.cross_kv = db.cross_kv; at.o_w = w.o_w; at.partial = db.partial; at.seq = db.seq;
+        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = db.q;
+        at.self_k = g.self_k; at.self_v = g.self_v;
+        at.cross_k = db.cross_k + (size_t)lkv * cross_stride; at.cross_v = db.cross_v + (size_t)lkv * cross_stride;
+        at.att = db.att; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
         { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
-        // cross query: x' = x + b_o + sum partial
-        g.N = d; g.K = d; g.rows_per_block = 16; g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
-        g.xin = xcur; g.xout = xalt; g.comb_bias = w.o_b; g.partial = db.partial;
-        { ProfScope ps_(KK_DEC_CQ, st); launch_gemv<MODE_CQ>(g, st); }
-        at.o_w = w.co_w;
-        { ProfScope ps_(KK_DEC_CROSS_ATTN, st); dec_cross_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
-        // fc1: x'' = x' + b_co + sum partial
-        g.N = 4 * d; g.K = d; g.rows_per_block = 16; g.W = w.fc1_w; g.bias = w.fc1_b; g.ln_g = w.ln3_g; g.ln_b = w.ln3_b;
-        g.xin = xalt; g.xout = xcur; g.comb_bias = w.co_b; g.hbuf = db.hbuf;
-        { ProfScope ps_(KK_DEC_FC1, st); launch_gemv<MODE_FC1>(g, st); }
-        // fc2: x''' = x'' + b_2 + W_2 h   (in place on xcur)
-        g.N = d; g.K = 4 * d; g.rows_per_block = 16; g.W = w.fc2_w; g.bias = w.fc2_b; g.xin = xcur; g.xout = xcur;
-        { ProfScope ps_(KK_DEC_FC2, st); launch_gemv<MODE_FC2>(g, st); }
+        // x += W_o att + b_o
+        g.N = d; g.K = d; g.W = w.o_w; g.bias = w.o_b; g.ain = db.att;
+        { ProfScope ps_(KK_DEC_OPROJ, st); g_dbg_kind = KK_DEC_OPROJ; launch_gemv<MODE_RESID>(g, st); }
+        // LN2 + cross query
+        g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
+        { ProfScope ps_(KK_DEC_CQ, st); g_dbg_kind = KK_DEC_CQ; launch_gemv<MODE_Q>(g, st); }
+        {
+            ProfScope ps_(KK_DEC_CROSS_ATTN, st);
+            const dim3 grid(S, H, B);
+            if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, 0, st>>>(at);
+            else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, 0, st>>>(at);
+            else dec_cross_attn_kernel<2><<<grid, 256, 0, st>>>(at);
+        }
+        // x += W_co att + b_co
+        g.W = w.co_w; g.bias = w.co_b;
+        { ProfScope ps_(KK_DEC_COPROJ, st); g_dbg_kind = KK_DEC_COPROJ; launch_gemv<MODE_RESID>(g, st); }
+        // LN3 + fc1 + GELU
+        g.N = 4 * d; g.K = d; g.W = w.fc1_w; g.bias = w.fc1_b; g.ln_g = w.ln3_g; g.ln_b = w.ln3_b; g.hbuf = db.hbuf;
+        { ProfScope ps_(KK_DEC_FC1, st); g_dbg_kind = KK_DEC_FC1; launch_gemv<MODE_FC1>(g, st); }
+        // x += W_2 h + b_2
+        g.N = d; g.K = 4 * d; g.W = w.fc2_w; g.bias = w.fc2_b;
+        { ProfScope ps_(KK_DEC_FC2, st); g_dbg_kind = KK_DEC_FC2; launch_gemv<MODE_FC2>(g, st); }
     }
     GemvArgs g{};
-    g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = -1; g.n_vocab = db.n_vocab;
-    g.N = db.n_vocab; g.K = d; g.rows_per_block = 64; g.W = db.emb; g.bias = nullptr; g.ln_g = db.lnf_g; g.ln_b = db.lnf_b;
-    g.xin = xcur; g.logits = db.logits;
-    { ProfScope ps_(KK_DEC_LOGITS, st); launch_gemv<MODE_LOGITS>(g, st); }
-    if (sample) { { ProfScope ps_(KK_SAMPLER, st); sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr); } }
+    g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = -1; g.n_vocab = db.n_vocab; g.x = db.x;
+    g.N = db.n_vocab; g.K = d; g.W = db.emb; g.bias = nullptr; g.ln_g = db.lnf_g; g.ln_b = db.lnf_b; g.logits = db.logits;
+    { ProfScope ps_(KK_DEC_LOGITS, st); g_dbg_kind = KK_DEC_LOGITS; launch_gemv<MODE_LOGITS>(g, st); }
+    if (sample) {
+        ProfScope ps_(KK_SAMPLER, st);
+        sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr);
+    }
 }
 
 void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int n_vocab, hipStream_t st) {
@@ -659,16 +921,43 @@ void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, Se
     sampler_kernel<1, 1, 0, 0><<<batch, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, seq, logits, 0, token_out, logprob_out);
 }
 
-__global__ void alignment_mean_kernel(const float* __restrict__ align, int n_align, float* __restrict__ out) {
-    // align [B][224][n_align][1500] -> out [B][224][1500]
-    size_t row = blockIdx.x;  // b * 224 + pos
+// align [B][224][n_align][1500] raw cross-attention score rows of the alignment heads -> out [B][224][1500]:
+// softmax over the 1500 positions per head, then the mean over heads (never-written rows are all-zero and stay zero).
+// One workgroup per (slot, row); wave w takes heads w, w + 4, ...
+__global__ __launch_bounds__(256) void alignment_mean_kernel(const float* __restrict__ align, int n_align, float* __restrict__ out) {
+    __shared__ float acc[4][kCtx];
+    const size_t row = blockIdx.x;  // b * 224 + pos
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* src = align + row * n_align * kCtx;
-    const float inv = 1.0f / (float)n_align;
-    for (int t = threadIdx.x; t < kCtx; t += blockDim.x) {
-        float s = 0.0f;
-        for (int j = 0; j < n_align; ++j) s += src[(size_t)j * kCtx + t];
-        out[row * kCtx + t] = s * inv;
+    for (int t = lane; t < kCtx; t += 64) acc[wave][t] = 0.0f;
+    for (int j = wave; j < n_align; j += 4) {
+        const float* sp = src + (size_t)j * kCtx;
+        float v[24];
+        float mx = -INFINITY, amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            int t = lane + 64 * i;
+            v[i] = t < kCtx ? sp[t] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+            if (t < kCtx) amax = fmaxf(amax, fabsf(v[i]));
+        }
+        mx = wave_max(mx);
+        amax = wave_max(amax);
+        if (amax == 0.0f) continue;   // row never written by a decode step
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            int t = lane + 64 * i;
+            if (t < kCtx) acc[wave][t] += v[i] * inv;
+        }
     }
+    __syncthreads();
+    const float invn = 1.0f / (float)n_align;
+    for (int t = threadIdx.x; t < kCtx; t += 256) out[row * kCtx + t] = ((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) * invn;
 }
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st) {
     alignment_mean_kernel<<<batch * kMaxTok, 256, 0, st>>>(align, n_align, out);

@@ -144,6 +144,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
                         const int d = a.d_model;
                         if (n < d) a.out16[(size_t)m * d + n] = (f16)x;
                         else a.k16[(size_t)m * d + (n - d)] = (f16)x;
+                    } else if constexpr (EPI == EPI_CROSS_KV) {
+                        const int d = a.d_model, H = d >> 6;
+                        const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
+                        const int bb = m / kCtx, t = m - bb * kCtx;
+                        f16* dst = kv ? a.vt16 : a.k16;
+                        dst[((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63)] = (f16)x;
                     } else if constexpr (EPI == EPI_CONV1) {
                         int bb = m / a.rows_per_batch_out, t = m - bb * a.rows_per_batch_out;
                         a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf(x);
@@ -180,6 +186,7 @@ void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st) {
         case EPI_CONV1: launch_epi<EPI_CONV1>(a, st); break;
         case EPI_CONV2: launch_epi<EPI_CONV2>(a, st); break;
         case EPI_F32: launch_epi<EPI_F32>(a, st); break;
+        case EPI_CROSS_KV: launch_epi<EPI_CROSS_KV>(a, st); break;
     }
 }
 

@@ -7,6 +7,7 @@
 // (one graph = kStepsPerGraph decoder steps, no host round trip inside) and turns the device-side
 // SeqState into the reference's DecodingResult / TranscriptionSegment values.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -676,8 +677,21 @@ extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const in
 // ------------------------------------------------------------------------------------------------ measurement hook
 static const char* kKindNames[KK_COUNT] = {
     "mel_power", "mel_finalize", "gemm_conv1", "gemm_conv2", "layernorm", "gemm_enc_qkv", "enc_attention", "gemm_enc_o", "gemm_enc_fc1",
-    "gemm_enc_fc2", "gemm_cross_kv", "dec_gemv_qkv", "dec_self_attn", "dec_gemv_cq", "dec_cross_attn", "dec_gemv_fc1", "dec_gemv_fc2",
-    "dec_gemv_logits", "sampler"};
+    "gemm_enc_fc2", "gemm_cross_kv", "dec_gemv_qkv", "dec_self_attn", "dec_gemv_oproj", "dec_gemv_cq", "dec_cross_attn", "dec_gemv_coproj",
+    "dec_gemv_fc1", "dec_gemv_fc2", "dec_gemv_logits", "sampler"};
+namespace wh { unsigned long long* debug_buffer(); }
+extern "C" int wh_debug_dump(const char* path) {
+    unsigned long long* b = wh::debug_buffer();
+    if (!b || !path) return -1;
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)KK_COUNT * 4096 * 8);
+    if (hipMemcpy(h.data(), b, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    FILE* f = fopen(path, "wb");
+    if (!f) return -3;
+    fwrite(h.data(), 8, h.size(), f);
+    fclose(f);
+    return 0;
+}
 extern "C" int wh_kernel_kind_count(void) { return KK_COUNT; }
 extern "C" const char* wh_kernel_kind_name(int kind) { return (kind >= 0 && kind < KK_COUNT) ? kKindNames[kind] : nullptr; }
 
@@ -688,7 +702,7 @@ extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double*
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
     if (!avg_us || !launches || n_steps < 0 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_kernels: invalid argument");
     const int L = s->m->dims.n_text_layer, Le = s->m->dims.n_audio_layer;
-    const size_t cap = (size_t)(6 * L + 2) * n_steps + 7 * Le + 16;
+    const size_t cap = (size_t)(8 * L + 2) * n_steps + 7 * Le + 16;
     KernelProfiler prof;
     prof.ev.resize(2 * cap); prof.kind.resize(cap); prof.capacity = cap;
     for (auto& e : prof.ev) WH_HIP(hipEventCreate(&e));

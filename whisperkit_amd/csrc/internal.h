@@ -47,8 +47,9 @@ struct wh_session {
     f16* h1 = nullptr; float* x = nullptr; f16* xn = nullptr; f16 *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *att16 = nullptr;
     f16* hmlp = nullptr; f16* enc16 = nullptr; float* enc32 = nullptr;
     // decoder
-    f16* cross_kv = nullptr; f16 *self_k = nullptr, *self_v = nullptr;
-    float *xa = nullptr, *xb = nullptr, *q = nullptr, *partial = nullptr, *logits = nullptr;
+    f16 *cross_k = nullptr, *cross_v = nullptr, *self_k = nullptr, *self_v = nullptr;
+    float *xa = nullptr, *q = nullptr, *att = nullptr, *part = nullptr, *logits = nullptr;
+    int* ticket = nullptr;
     f16* hbuf = nullptr;
     float *align = nullptr, *align_mean = nullptr;
     wh::SeqState* seq = nullptr;

@@ -11,7 +11,8 @@ namespace wh {
 // (wh_measure_kernels) each launch is bracketed by a HIP event pair on the launch stream.
 enum KernelKind {
     KK_MEL_POWER = 0, KK_MEL_FINALIZE, KK_CONV1, KK_CONV2, KK_LAYERNORM, KK_ENC_QKV, KK_ENC_ATTN, KK_ENC_O, KK_ENC_FC1, KK_ENC_FC2,
-    KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS, KK_SAMPLER,
+    KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_OPROJ, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_COPROJ, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS,
+    KK_SAMPLER,
     KK_COUNT
 };
 struct KernelProfiler {
@@ -52,6 +53,7 @@ enum GemmEpi {
     EPI_CONV1 = 4,      // out16[(b*3002 + t + 1)*ldc + n] = gelu(v)  (padded time-major input of conv2)
     EPI_CONV2 = 5,      // x32[m*ldc + n] = gelu(v) + pos[t*ldc + n]
     EPI_F32 = 6,        // out32[m*ldc + n] = v
+    EPI_CROSS_KV = 7,   // n = l*2d + kv*d + h*64 + c, m = b*1500 + t -> (kv ? vt16 : k16)[(((l*Bmax + b)*H + h)*1500 + t)*64 + c]
 };
 
 struct GemmArgs {
@@ -72,6 +74,7 @@ struct GemmArgs {
     // EPI_CONV2
     const float* pos;
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
+    int max_batch = 0;         // EPI_CROSS_KV: slot stride of the head-major cross K/V layout
     int prof_kind = -1;        // KernelKind of this launch (measurement only)
 };
 
@@ -129,25 +132,30 @@ struct SeqState {
 };
 
 struct DecodeBuffers {
-    int batch, d, n_head, n_layer, n_vocab;
+    int batch, max_batch, d, n_head, n_layer, n_vocab;
     const f16* emb;          // [V][d]
     const float* pos;        // [448][d]
     const DecLayerW* layers_host; // host array [L] of device pointers
     const float *lnf_g, *lnf_b;
-    f16* self_k;             // [L][B][224][d]
+    f16* self_k;             // [L][Bmax][H][224][64]  head-major self-attention cache
     f16* self_v;
-    const f16* cross_kv;     // [B*1500][L*2d]  (K_l at col l*2d, V_l at col l*2d + d)
-    float* xa;               // [B][d] residual ping
-    float* xb;               // [B][d] residual pong
+    const f16* cross_k;      // [L][Bmax][H][1500][64] head-major cross-attention K / V (written by the cross-K/V GEMM epilogue)
+    const f16* cross_v;
+    float* x;                // [B][d] residual stream
     float* q;                // [B][d] f32 query
+    float* att;              // [B][d] attention output before the out projection
     f16* hbuf;               // [B][4d]
-    float* partial;          // [B][H][d]
+    float* part;             // [B][H][kMaxSplit][kPartStride] cross-attention split partials
+    int* ticket;             // [B][H]
     float* logits;           // [B][V]
-    float* align;            // [B][224][n_align][1500] per-head cross-attention rows (or null)
+    float* align;            // [B][224][n_align][1500] raw score rows of the alignment heads (or null)
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
 };
+constexpr int kMaxSplit = 24;   // cross-attention key splits (64 keys per workgroup at the finest)
+constexpr int kPartStride = 96; // floats per split partial (m, l, o[64]) padded to 3 x 128 bytes: no cache line is shared between splits
+int cross_attn_splits(int batch, int n_head);
 
 // one decoder forward + (optionally) fused filter/sample/state-advance for all slots
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st);
