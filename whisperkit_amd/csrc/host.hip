@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <tuple>
 
 #include "internal.h"
@@ -251,6 +252,7 @@ struct GraphKey {
 };
 struct SessionGraphs { std::map<GraphKey, hipGraphExec_t> g; };
 static std::map<wh_session*, SessionGraphs>& graph_cache() { static std::map<wh_session*, SessionGraphs> c; return c; }
+static std::mutex g_graph_mu;   // sessions of one model decode concurrently from different host threads
 
 static bool use_graphs() {
     static int v = -1;
@@ -260,9 +262,12 @@ static bool use_graphs() {
 
 static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
     GraphKey key{batch, s->align_enabled ? 1 : 0};
-    auto& cache = graph_cache()[s].g;
-    auto it = cache.find(key);
-    if (it != cache.end()) { *out = it->second; return WH_OK; }
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        auto& cache = graph_cache()[s].g;
+        auto it = cache.find(key);
+        if (it != cache.end()) { *out = it->second; return WH_OK; }
+    }
     DecodeBuffers db = whi::decode_buffers(s, batch);
     hipGraph_t graph;
     WH_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
@@ -271,13 +276,17 @@ static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
     hipGraphExec_t exec;
     WH_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
-    cache[key] = exec;
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        graph_cache()[s].g[key] = exec;
+    }
     *out = exec;
     return WH_OK;
 }
 
 namespace whi {
 void drop_session_graphs(wh_session* s) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
     auto it = graph_cache().find(s);
     if (it == graph_cache().end()) return;
     for (auto& kv : it->second.g) hipGraphExecDestroy(kv.second);
