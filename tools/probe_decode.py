@@ -35,6 +35,12 @@ if os.environ.get("WH_DBG") == "1":
     a = np.fromfile(path, dtype=np.uint64).reshape(-1, 4096, 8)
     names = [lib.wh_kernel_kind_name(k).decode() for k in range(lib.wh_kernel_kind_count())]
     for k, nm in enumerate(names):
+        if nm == 'dec_cross_attn':
+            t = a[k]; t = t[t[:, 0] > 0].astype(np.int64)
+            t0 = t[:, 0].min(); r = (t - t0) * 10
+            last = t[:, 6] == 1
+            print(f'dec_cross_attn blocks {len(t)} (probe keeps <= 4096): start spread {r[:,0].max()} ns | med loads issued {np.median(r[:,1]):.0f}  K scored {np.median(r[:,2]):.0f}  PV done {np.median(r[:,3]):.0f}  ticket done {np.median(r[:,4]):.0f}  end {np.median(r[:,5]):.0f} | p10/p90 K scored {np.percentile(r[:,2],10):.0f}/{np.percentile(r[:,2],90):.0f} | last-arriver blocks end med {np.median(r[last][:,5]) if last.any() else -1:.0f} max {r[:,5].max()} ns')
+            continue
         t = a[k]; used = t[:, 0] > 0
         if not used.any():
             continue

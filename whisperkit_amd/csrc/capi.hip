@@ -302,7 +302,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->logits, B * V);
     DALLOC(s->hbuf, B * 4 * d);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
-    DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress);
+    DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress); DALLOC(s->sup_mask_dev, V); DALLOC(s->stats, B * kStatBlocks * 8);
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
@@ -317,7 +317,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     whi::drop_session_graphs(s);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->xa, s->q, s->att, s->part, s->ticket, s->logits, s->hbuf,
-                    s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
+                    s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->seq_host) hipHostFree(s->seq_host);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
@@ -451,6 +451,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch) {
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
     db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v; db.x = s->xa; db.q = s->q; db.att = s->att;
     db.hbuf = s->hbuf; db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
+    db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
     return db;
 }
@@ -545,6 +546,12 @@ static int upload_cfg(wh_session* s, const wh_decoding_options* opt, const wh_sp
             if (opt->suppress_tokens[i] < st->special_token_begin && opt->suppress_tokens[i] >= 0) sup.push_back(opt->suppress_tokens[i]);
     if ((int)sup.size() > kMaxSuppress) return set_error(WH_ERR_INVALID_ARGUMENT, "more than %d suppress tokens", kMaxSuppress);
     c.n_suppress = (int)sup.size();
+    {
+        std::vector<unsigned char> mask((size_t)s->m->dims.n_vocab, 0);
+        for (int t : sup) if (t < (int)mask.size()) mask[t] = 1;
+        WH_HIP(hipMemcpyAsync(s->sup_mask_dev, mask.data(), mask.size(), hipMemcpyHostToDevice, s->st));
+        WH_HIP(hipStreamSynchronize(s->st));   // mask is a stack temporary
+    }
     if (!sup.empty()) WH_HIP(hipMemcpyAsync(s->suppress_dev, sup.data(), sizeof(int) * sup.size(), hipMemcpyHostToDevice, s->st));
     WH_HIP(hipMemcpyAsync(s->cfg_dev, &c, sizeof(c), hipMemcpyHostToDevice, s->st));
     WH_HIP(hipStreamSynchronize(s->st));   // c / sup are stack temporaries

@@ -50,8 +50,8 @@ struct GemvArgs {
     f16* hbuf;                 // [B][4d]
     float* logits;             // [B][V]
     SeqState* seq;
+    float* stats; const unsigned char* sup_mask; const SamplerCfg* cfg;   // MODE_LOGITS fused greedy sampler (stats != null)
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1): 8 timestamps per workgroup
-    int xflags;                // experiment knobs (WH_XFLAGS): 1 no weight loads, 2 no gamma/beta loads, 4 no FMA loop, 8 no LDS x reads
 };
 
 #define DBG_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = ((i) == 6) ? (unsigned long long)clock64() : ((i) == 7 ? (unsigned long long)clock64() : (unsigned long long)wall_clock64()); } while (0)
@@ -109,6 +109,94 @@ __device__ __forceinline__ float row_sum(float v, float* red) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused greedy sampler, part 1
+// Filter rules of one sampling step as scalars (restating LogitsFilter.swift): r[0] SuppressBlank active,
+// r[1] TimestampRules active, [r2, r3) and [r4, r5) id ranges masked by the timestamp rules.
+__device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, const SeqState* sq, int n_tok, int V, int* r) {
+    const int tb = cfg.time_token_begin;
+    int blank = 0, ts_active = 0, r1lo = 0, r1hi = 0, r2lo = 0, r2hi = 0;
+    blank = cfg.suppress_blank && (n_tok == cfg.prefilled_index);            // SuppressBlankFilter :44-50
+    if (cfg.timestamp_rules) {                                               // TimestampRulesFilter :72-129
+        int sb = -1;
+        if (cfg.is_multilingual) {                                           // :131-142
+            for (int i = 0; i < 3 && i < n_tok; ++i)
+                if (sq->tokens[i] == cfg.transcribe_token || sq->tokens[i] == cfg.translate_token) { sb = max(i + 1, cfg.initial_prompt_index); break; }
+        } else sb = cfg.initial_prompt_index;
+        if (sb >= 0 && sb <= n_tok) {
+            ts_active = 1;
+            if (n_tok > sb) {
+                int cnt = n_tok - sb;
+                bool lastTs = sq->tokens[n_tok - 1] >= tb;
+                bool penTs = cnt < 2 || sq->tokens[n_tok - 2] >= tb;
+                if (lastTs) {
+                    if (penTs) { r1lo = tb; r1hi = V; }          // has to be non-timestamp
+                    else { r1lo = 0; r1hi = cfg.end_token; }     // cannot be normal text
+                }
+                int lastTimestamp = -1;
+                for (int i = n_tok - 1; i >= sb; --i)
+                    if (sq->tokens[i] >= tb) { lastTimestamp = sq->tokens[i]; break; }
+                if (lastTimestamp >= 0) {
+                    int tl = (lastTs && !penTs) ? lastTimestamp : lastTimestamp + 1;
+                    r2lo = tb; r2hi = tl;
+                }
+            }
+        }
+    }
+    r[0] = blank; r[1] = ts_active; r[2] = r1lo; r[3] = r1hi; r[4] = r2lo; r[5] = r2hi;
+}
+
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {   // ties -> smallest index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o, 64);
+        int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+struct GemvArgs;
+// Epilogue of the logits kernel when every live slot samples greedily: apply the index-predicate filters to this
+// workgroup's <= 64 logits per slot and reduce them to (max, argmax, sum exp) separately for text ids (< timeTokenBegin)
+// and timestamp ids; sampler_final_kernel merges the per-workgroup records.  One wave per slot, lane = row.
+template <int BT, typename Args>
+__device__ __forceinline__ void logits_block_stats(const Args& a, const float* lt, int b0, int n_begin, int n_end) {
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SamplerCfg cfg = *a.cfg;
+    const int tb = cfg.time_token_begin;
+    for (int b = wave; b < BT; b += 4) {
+        const int gb = b0 + b;
+        if (gb >= a.batch) continue;
+        const SeqState* sq = a.seq + gb;
+        if (!slot_live(sq)) continue;
+        const int n = n_begin + lane;
+        float v = -INFINITY;
+        if (n < n_end) {
+            v = lt[b * 64 + lane];
+            const int blank = sq->f_rules[0], ts_active = sq->f_rules[1];
+            bool masked = a.sup_mask[n] != 0;                                                    // SuppressTokensFilter
+            masked |= blank && (n == cfg.whitespace_token || n == cfg.end_token);                // SuppressBlankFilter
+            masked |= ts_active && (n == cfg.no_timestamps_token || (n >= sq->f_rules[2] && n < sq->f_rules[3]) ||
+                                    (n >= sq->f_rules[4] && n < sq->f_rules[5]));               // TimestampRulesFilter
+            if (masked) v = -INFINITY;
+        }
+        const bool is_ts = n >= tb;
+        float mt = is_ts ? -INFINITY : v, ms = is_ts ? v : -INFINITY;
+        int it = n, is = n;
+        const float vt = mt, vs = ms;
+        wave_argmax(mt, it);
+        wave_argmax(ms, is);
+        float st = (vt == -INFINITY) ? 0.0f : __expf(vt - mt);
+        float ss = (vs == -INFINITY) ? 0.0f : __expf(vs - ms);
+        st = wave_sum(st);
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            float* o = a.stats + ((size_t)gb * kStatBlocks + blockIdx.x) * 8;
+            o[0] = mt; o[1] = st; o[2] = __int_as_float(it); o[3] = ms; o[4] = ss; o[5] = __int_as_float(is);
+        }
+    }
+}
+
 // Workgroup = 4 waves arranged as KS K-splits x RG = 4 / KS row groups.  A wave owns R weight rows and the K range
 // [ks * K / KS, (ks + 1) * K / KS) of them (<= 1536 columns = 3 slices of 512 = 64 lanes x 8 halves), and issues ALL of its
 // weight loads before touching them: these matrices are a few MB spread over 256 CUs, so the only way to reach the
@@ -124,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     f16* xh = reinterpret_cast<f16*>(smem_raw);
     __shared__ float red[NW];
     __shared__ float kred[NW][32];
+    __shared__ float lt[MODE == MODE_LOGITS ? BT * 64 : 1];   // this workgroup's logits (<= 64 rows) for the fused sampler statistics
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.y * BT;
     const int K = a.K, d = a.d;
@@ -149,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
             const f16* wr = a.W + (size_t)min(n0 + r, a.N - 1) * K + kbase + lane * 8;
 #pragma unroll
             for (int i = 0; i < KI; ++i)
-                dst[r][i] = (lane * 8 + 512 * i < KC && !(a.xflags & 1)) ? *reinterpret_cast<const uint4*>(wr + 512 * i) : uint4{0, 0, 0, 0};
+                dst[r][i] = (lane * 8 + 512 * i < KC) ? *reinterpret_cast<const uint4*>(wr + 512 * i) : uint4{0, 0, 0, 0};
         }
     };
 
@@ -288,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
             const int kl = lane * 8 + 512 * i;     // column inside this wave's K range
-            if (kl < KC && !(a.xflags & 4)) {
+            if (kl < KC) {
                 const int k = kbase + kl;
                 // activations in chunks of <= 4 slots: bounds the live x registers (accumulation order per output unchanged)
                 constexpr int BC = BT < 4 ? BT : 4;
@@ -302,8 +391,8 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xk[b][j] = (float)hv[j];
                         } else {
-                            float4 x0 = float4{1, 2, 3, 4}, x1 = float4{5, 6, 7, 8};
-                            if (!(a.xflags & 8)) { x0 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k); x1 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k + 4); }
+                            float4 x0 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k);
+                            float4 x1 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k + 4);
                             xk[b][0] = x0.x; xk[b][1] = x0.y; xk[b][2] = x0.z; xk[b][3] = x0.w;
                             xk[b][4] = x1.x; xk[b][5] = x1.y; xk[b][6] = x1.z; xk[b][7] = x1.w;
                         }
@@ -356,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
                     a.x[(size_t)gb * d + n] += v;
                 } else {
                     a.logits[(size_t)gb * a.N + n] = v;
+                    if (a.stats) lt[b * 64 + (n - n_begin)] = v;
                 }
             }
         }
@@ -369,6 +459,9 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         } else if (p + 1 < n_pass) {
             load_group(cur, n_begin + ((p + 1) * RG + rg) * R);
         }
+    }
+    if constexpr (MODE == MODE_LOGITS) {
+        if (a.stats) logits_block_stats<BT>(a, lt, b0, n_begin, n_end);
     }
     DBG_STAMP(5); DBG_STAMP(7);
 }
@@ -384,7 +477,9 @@ struct AttnArgs {
     int* ticket;             // [B][H] arrival counters (zero between launches)
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
+    unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
+#define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
 
 // One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 halves).  Thread layout: 8 lanes per
 // key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
@@ -393,7 +488,7 @@ struct AttnArgs {
 template <int PASSES>
 __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n,
                                              float* __restrict__ raw_scores, float* red /* [16] */, float* osum /* [4][64] */,
-                                             float* o_out /* [64] */, float* m_out, float* l_out) {
+                                             float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int part = tid & 7, kg = tid >> 3;
     uint4 kreg[PASSES], vreg[PASSES];
@@ -407,6 +502,7 @@ __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const
         const int key = kg + 32 * i;
         vreg[i] = key < n ? *reinterpret_cast<const uint4*>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
+    if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
     float qv[8];
     {
         float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
@@ -433,6 +529,7 @@ __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
+    if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float lsum = 0.0f;
@@ -463,6 +560,7 @@ __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const
     }
     __syncthreads();
     if (tid < 64) o_out[tid] = (osum[tid] + osum[64 + tid]) + (osum[128 + tid] + osum[192 + tid]);
+    if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
     *m_out = m;
     *l_out = (red[4] + red[5]) + (red[6] + red[7]);
 }
@@ -498,7 +596,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
     }
     float m, l;
-    attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, raw, red, osum, o_l, &m, &l);
+    ATT_STAMP(0);
+    unsigned long long* stamp = a.dbg ? a.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 : nullptr;
+    attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, raw, red, osum, o_l, &m, &l, stamp);
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
     float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
@@ -521,6 +621,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         last_flag = last;
     }
     __syncthreads();
+    ATT_STAMP(4);
+    if (last_flag && tid == 0 && a.dbg) stamp[6] = 1;
     if (last_flag && tid < 64) {
         const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
         float mg = -INFINITY;
@@ -534,6 +636,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         }
         a.att[(size_t)b * d + h * kHeadDim + tid] = og / lg;
     }
+    ATT_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------- sampler
@@ -596,6 +699,41 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, int counter)
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// decodeText bookkeeping after one sampled token (TextDecoder.swift:573-757), then the filter rules of the next step
+__device__ __forceinline__ void advance_decode_state(const SamplerCfg& cfg, SeqState* sq, int tok, float lp, int n_tok) {
+    const int tb = cfg.time_token_begin;
+    const int ti_cur = sq->token_index;
+    const bool isFirstToken = ti_cur == cfg.prefilled_index;
+    const bool tooLow = isFirstToken && cfg.has_first_token_threshold && lp < cfg.first_token_log_prob_threshold;
+    const bool completed = tok == cfg.end_token;
+    const bool segDone = completed || n_tok >= kMaxTok - 1 || tooLow;
+    sq->steps += 1;
+    sq->first_token_too_low = tooLow ? 1 : 0;
+    if (segDone) {
+        sq->done = 1;
+        return;
+    }
+    const bool isPrefill = ti_cur < sq->prompt_len - 1;
+    int nt = n_tok;
+    if (!isPrefill) { sq->tokens[nt] = tok; sq->logprobs[nt] = lp; nt += 1; sq->n_tokens = nt; }
+    const int ti_next = ti_cur + 1;
+    if (ti_next >= cfg.loop_count) {
+        sq->done = 1;
+        return;
+    }
+    int next = tok;
+    if (ti_next < sq->prompt_len) {                                   // :581-594 (loop top of the next iteration)
+        const bool isLast = ti_next == sq->prompt_len - 1;
+        const bool isTs = sq->tokens[ti_next] >= tb;
+        const bool predTs = next >= tb;
+        if (!(isLast && isTs && predTs)) next = sq->tokens[ti_next];
+        else sq->tokens[ti_next] = next;
+    }
+    sq->token_index = ti_next;
+    sq->next_token = next;
+    compute_filter_rules(cfg, sq, nt, cfg.n_vocab, sq->f_rules);
+}
+
 // MODE bit 0: apply filters; bit 1: sample; bit 2: advance decodeText state; bit 3: write filtered logits back
 template <int DO_FILTER, int DO_SAMPLE, int DO_ADVANCE, int WRITE_BACK>
 __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __restrict__ cfgp, const int* __restrict__ suppress,
@@ -615,37 +753,10 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
     // ---- scalar filter parameters (thread 0), restating LogitsFilter.swift
     // sh_i: 0 blank_active, 1 ts_active, 2 r1_lo, 3 r1_hi, 4 r2_lo, 5 r2_hi
     if (tid == 0) {
-        int blank = 0, ts_active = 0, r1lo = 0, r1hi = 0, r2lo = 0, r2hi = 0;
-        if (DO_FILTER) {
-            blank = cfg.suppress_blank && (n_tok == cfg.prefilled_index);            // SuppressBlankFilter :44-50
-            if (cfg.timestamp_rules) {                                               // TimestampRulesFilter :72-129
-                int sb = -1;
-                if (cfg.is_multilingual) {                                           // :131-142
-                    for (int i = 0; i < 3 && i < n_tok; ++i)
-                        if (sq->tokens[i] == cfg.transcribe_token || sq->tokens[i] == cfg.translate_token) { sb = max(i + 1, cfg.initial_prompt_index); break; }
-                } else sb = cfg.initial_prompt_index;
-                if (sb >= 0 && sb <= n_tok) {
-                    ts_active = 1;
-                    if (n_tok > sb) {
-                        int cnt = n_tok - sb;
-                        bool lastTs = sq->tokens[n_tok - 1] >= tb;
-                        bool penTs = cnt < 2 || sq->tokens[n_tok - 2] >= tb;
-                        if (lastTs) {
-                            if (penTs) { r1lo = tb; r1hi = V; }          // has to be non-timestamp
-                            else { r1lo = 0; r1hi = cfg.end_token; }     // cannot be normal text
-                        }
-                        int lastTimestamp = -1;
-                        for (int i = n_tok - 1; i >= sb; --i)
-                            if (sq->tokens[i] >= tb) { lastTimestamp = sq->tokens[i]; break; }
-                        if (lastTimestamp >= 0) {
-                            int tl = (lastTs && !penTs) ? lastTimestamp : lastTimestamp + 1;
-                            r2lo = tb; r2hi = tl;
-                        }
-                    }
-                }
-            }
-        }
-        sh_i[0] = blank; sh_i[1] = ts_active; sh_i[2] = r1lo; sh_i[3] = r1hi; sh_i[4] = r2lo; sh_i[5] = r2hi;
+        int r[6] = {0, 0, 0, 0, 0, 0};
+        if (DO_FILTER) compute_filter_rules(cfg, sq, n_tok, V, r);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sh_i[i] = r[i];
     }
     if (DO_FILTER && !cfg.language_filter) {
         for (int i = tid; i < cfg.n_suppress; i += SAMP_T) {                       // SuppressTokensFilter :21-24
@@ -763,42 +874,81 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
     }
     if (tid == 0) {
         if (token_out) { token_out[b] = tok; logprob_out[b] = lp; }
-        if (DO_ADVANCE) {
-            // decodeText bookkeeping, TextDecoder.swift:573-757
-            const int ti_cur = sq->token_index;
-            const bool isFirstToken = ti_cur == cfg.prefilled_index;
-            const bool tooLow = isFirstToken && cfg.has_first_token_threshold && lp < cfg.first_token_log_prob_threshold;
-            const bool completed = tok == cfg.end_token;
-            const bool segDone = completed || n_tok >= kMaxTok - 1 || tooLow;
-            sq->steps += 1;
-            sq->first_token_too_low = tooLow ? 1 : 0;
-            if (segDone) {
-                sq->done = 1;
-            } else {
-                const bool isPrefill = ti_cur < sq->prompt_len - 1;
-                int nt = n_tok;
-                if (!isPrefill) { sq->tokens[nt] = tok; sq->logprobs[nt] = lp; nt += 1; sq->n_tokens = nt; }
-                const int ti_next = ti_cur + 1;
-                if (ti_next >= cfg.loop_count) {
-                    sq->done = 1;
-                } else {
-                    int next = tok;
-                    if (ti_next < sq->prompt_len) {                                   // :581-594 (loop top of the next iteration)
-                        const bool isLast = ti_next == sq->prompt_len - 1;
-                        const bool isTs = sq->tokens[ti_next] >= tb;
-                        const bool predTs = next >= tb;
-                        if (!(isLast && isTs && predTs)) next = sq->tokens[ti_next];
-                        else sq->tokens[ti_next] = next;
-                    }
-                    sq->token_index = ti_next;
-                    sq->next_token = next;
-                }
-            }
-        }
+        if (DO_ADVANCE) advance_decode_state(cfg, sq, tok, lp, n_tok);
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused greedy sampler, part 2
+struct SoftStat { float m, s; int i; };
+__device__ __forceinline__ void stat_merge(SoftStat& a, float em, float es, int ei) {
+    if (em == -INFINITY) return;
+    if (a.m == -INFINITY || em > a.m) {
+        a.s = (a.m == -INFINITY ? 0.0f : a.s * __expf(a.m - em)) + es;
+        a.m = em; a.i = ei;
+    } else if (em == a.m) {
+        a.s += es; a.i = min(a.i, ei);
+    } else {
+        a.s += es * __expf(em - a.m);
+    }
+}
+__device__ __forceinline__ void stat_wave_reduce(SoftStat& a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float om = __shfl_xor(a.m, o, 64), os = __shfl_xor(a.s, o, 64);
+        int oi = __shfl_xor(a.i, o, 64);
+        stat_merge(a, om, os, oi);
+    }
+}
+
+// One workgroup per slot: merge the per-workgroup (text, timestamp) statistics of the logits kernel, apply the
+// "timestamp mass beats every text token" rule (LogitsFilter.swift:144-242), take the greedy token and its log-prob
+// (TokenSampler.swift:29-252, T = 0) and advance the decodeText state.
+__global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __restrict__ cfgp, SeqState* __restrict__ seqs,
+                                                            const float* __restrict__ stats, int nblk) {
+    __shared__ float sm[4][4];
+    __shared__ int si[4][2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SeqState* sq = seqs + b;
+    if (!slot_live(sq)) return;
+    SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
+    for (int i = tid; i < nblk; i += 256) {
+        const float* e = stats + ((size_t)b * kStatBlocks + i) * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(e);
+        const float2 hi = *reinterpret_cast<const float2*>(e + 4);
+        stat_merge(t, lo.x, lo.y, __float_as_int(lo.z));
+        stat_merge(u, lo.w, hi.x, __float_as_int(hi.y));
+    }
+    stat_wave_reduce(t);
+    stat_wave_reduce(u);
+    if (lane == 0) { sm[wave][0] = t.m; sm[wave][1] = t.s; si[wave][0] = t.i; sm[wave][2] = u.m; sm[wave][3] = u.s; si[wave][1] = u.i; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { stat_merge(t, sm[w][0], sm[w][1], si[w][0]); stat_merge(u, sm[w][2], sm[w][3], si[w][1]); }
+        const SamplerCfg cfg = *cfgp;
+        const bool ts_active = sq->f_rules[1] != 0;
+        int tok; float lp;
+        const bool cond = ts_active && u.m != -INFINITY && (u.m + logf(u.s) > t.m);
+        if (cond || t.m == -INFINITY) {          // text ids masked: the candidates are the timestamp ids
+            tok = u.i; lp = -logf(u.s);
+        } else {
+            SoftStat g = t;
+            stat_merge(g, u.m, u.s, u.i);        // equal maxima: the text id (smaller index) wins, like a first-maximum argmax
+            tok = g.i; lp = -logf(g.s);
+        }
+        advance_decode_state(cfg, sq, tok, lp, sq->n_tokens);
+    }
+}
+
+__global__ void rules_init_kernel(const SamplerCfg* __restrict__ cfgp, SeqState* __restrict__ seqs) {
+    if (threadIdx.x != 0) return;
+    SeqState* sq = seqs + blockIdx.x;
+    const SamplerCfg cfg = *cfgp;
+    compute_filter_rules(cfg, sq, sq->n_tokens, cfg.n_vocab, sq->f_rules);
+}
+void launch_rules_init(const SamplerCfg* cfg_dev, SeqState* seq, int batch, hipStream_t st) { rules_init_kernel<<<batch, 64, 0, st>>>(cfg_dev, seq); }
+
 // ---------------------------------------------------------------------------------------------- launchers
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static unsigned long long* g_dbg_buf = nullptr;   // [KK_COUNT][4096][8]
 static int g_dbg_kind = 0;
 unsigned long long* debug_buffer() {
@@ -810,7 +960,6 @@ unsigned long long* debug_buffer() {
 template <int MODE, int BT, int R>
 static void launch_gemv_r(GemvArgs a, int passes, hipStream_t st) {
     a.dbg = debug_buffer() ? debug_buffer() + (size_t)g_dbg_kind * 4096 * 8 : nullptr;
-    { static int xf = -1; if (xf < 0) { const char* e = getenv("WH_XFLAGS"); xf = e ? atoi(e) : 0; } a.xflags = xf; }
     a.rows_per_block = (4 / a.k_split) * R * passes;
     dim3 g((a.N + a.rows_per_block - 1) / a.rows_per_block, (a.batch + BT - 1) / BT);
     const bool ln_mode = MODE == MODE_QKV || MODE == MODE_Q || MODE == MODE_FC1 || MODE == MODE_LOGITS;
@@ -832,8 +981,9 @@ static void launch_gemv_bt(GemvArgs a, hipStream_t st) {
     a.k_split = a.K <= 1536 ? 1 : a.K <= 3072 ? 2 : 4;
     const int rg = 4 / a.k_split;
     const int passes = (MODE == MODE_LOGITS) ? 4 : 1;
-    if ((a.N + rg * 4 - 1) / (rg * 4) >= 256) launch_gemv_r<MODE, BT, 4>(a, passes, st);
-    else if ((a.N + rg * 2 - 1) / (rg * 2) >= 256) launch_gemv_r<MODE, BT, 2>(a, passes, st);
+    static const int minblk = env_int("WH_GEMV_MINBLK", 256);   // tuning knob
+    if ((a.N + rg * 4 - 1) / (rg * 4) >= minblk) launch_gemv_r<MODE, BT, 4>(a, passes, st);
+    else if ((a.N + rg * 2 - 1) / (rg * 2) >= minblk) launch_gemv_r<MODE, BT, 2>(a, passes, st);
     else launch_gemv_r<MODE, BT, 1>(a, passes, st);
 }
 
@@ -846,7 +996,9 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
 
 int cross_attn_splits(int batch, int n_head) {
     // keys per workgroup 256 / 128 / 64: the coarsest split that still gives >= 512 workgroups
-    for (int passes = 8; passes >= 4; passes >>= 1) {
+    static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 8 / 4 / 2
+    if (forced) return (kCtx + forced * 32 - 1) / (forced * 32);
+    for (int passes : {16, 12, 8, 4}) {
         int s = (kCtx + passes * 32 - 1) / (passes * 32);
         if (s * n_head * batch >= 512) return s;
     }
@@ -858,22 +1010,19 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
     const size_t self_stride = (size_t)db.max_batch * H * kMaxTok * kHeadDim;
     const size_t cross_stride = (size_t)db.max_batch * H * kCtx * kHeadDim;
     const int S = cross_attn_splits(B, H);
-    static int same_layer = -1;   // experiment knob: WH_SAME_LAYER=1 reuses layer 0's weights for every layer, =2 also its K/V
-    if (same_layer < 0) { const char* e = getenv("WH_SAME_LAYER"); same_layer = e ? atoi(e) : 0; }
     for (int l = 0; l < L; ++l) {
-        const DecLayerW& w = db.layers_host[same_layer ? 0 : l];
-        const int lkv = same_layer >= 2 ? 0 : l;
+        const DecLayerW& w = db.layers_host[l];
         GemvArgs g{};
         g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = l; g.n_vocab = db.n_vocab; g.x = db.x;
         // LN1 + QKV
         g.N = 3 * d; g.K = d; g.W = w.qkv_w; g.bias = w.qkv_b; g.ln_g = w.ln1_g; g.ln_b = w.ln1_b;
         g.emb = db.emb; g.pos = db.pos; g.q = db.q;
-        g.self_k = db.self_k + (size_t)lkv * self_stride; g.self_v = db.self_v + (size_t)lkv * self_stride;
+        g.self_k = db.self_k + (size_t)l * self_stride; g.self_v = db.self_v + (size_t)l * self_stride;
         { ProfScope ps_(KK_DEC_QKV, st); g_dbg_kind = KK_DEC_QKV; launch_gemv<MODE_QKV>(g, st); }
         AttnArgs at{};
         at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = db.q;
         at.self_k = g.self_k; at.self_v = g.self_v;
-        at.cross_k = db.cross_k + (size_t)lkv * cross_stride; at.cross_v = db.cross_v + (size_t)lkv * cross_stride;
+        at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att = db.att; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
         { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
@@ -883,12 +1032,16 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         // LN2 + cross query
         g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
         { ProfScope ps_(KK_DEC_CQ, st); g_dbg_kind = KK_DEC_CQ; launch_gemv<MODE_Q>(g, st); }
+        at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
         {
             ProfScope ps_(KK_DEC_CROSS_ATTN, st);
             const dim3 grid(S, H, B);
-            if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, 0, st>>>(at);
-            else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, 0, st>>>(at);
-            else dec_cross_attn_kernel<2><<<grid, 256, 0, st>>>(at);
+            static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
+            if (S == 3) dec_cross_attn_kernel<16><<<grid, 256, xlds, st>>>(at);
+            else if (S == 4) dec_cross_attn_kernel<12><<<grid, 256, xlds, st>>>(at);
+            else if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, xlds, st>>>(at);
+            else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, xlds, st>>>(at);
+            else dec_cross_attn_kernel<2><<<grid, 256, xlds, st>>>(at);
         }
         // x += W_co att + b_co
         g.W = w.co_w; g.bias = w.co_b;
@@ -903,8 +1056,14 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
     GemvArgs g{};
     g.batch = B; g.d = d; g.n_head = H; g.seq = db.seq; g.layer = -1; g.n_vocab = db.n_vocab; g.x = db.x;
     g.N = db.n_vocab; g.K = d; g.W = db.emb; g.bias = nullptr; g.ln_g = db.lnf_g; g.ln_b = db.lnf_b; g.logits = db.logits;
+    const bool fused = sample && db.fused_greedy;
+    if (fused) { g.stats = db.stats; g.sup_mask = db.sup_mask; g.cfg = cfg_dev; }
     { ProfScope ps_(KK_DEC_LOGITS, st); g_dbg_kind = KK_DEC_LOGITS; launch_gemv<MODE_LOGITS>(g, st); }
-    if (sample) {
+    if (fused) {
+        ProfScope ps_(KK_SAMPLER, st);
+        const int nblk = (db.n_vocab + 63) / 64;      // launch_gemv_bt: 4 row groups x R = 4 x 4 passes = 64 rows per workgroup
+        sampler_final_kernel<<<B, 256, 0, st>>>(cfg_dev, db.seq, db.stats, nblk);
+    } else if (sample) {
         ProfScope ps_(KK_SAMPLER, st);
         sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr);
     }

@@ -247,8 +247,8 @@ void finalize_decoding_result(const SeqState& sq, const wh_decoding_options* opt
 constexpr int kStepsPerGraph = 8;
 
 struct GraphKey {
-    int batch, align;
-    bool operator<(const GraphKey& o) const { return std::tie(batch, align) < std::tie(o.batch, o.align); }
+    int batch, align, fused;
+    bool operator<(const GraphKey& o) const { return std::tie(batch, align, fused) < std::tie(o.batch, o.align, o.fused); }
 };
 struct SessionGraphs { std::map<GraphKey, hipGraphExec_t> g; };
 static std::map<wh_session*, SessionGraphs>& graph_cache() { static std::map<wh_session*, SessionGraphs> c; return c; }
@@ -261,7 +261,7 @@ static bool use_graphs() {
 }
 
 static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
-    GraphKey key{batch, s->align_enabled ? 1 : 0};
+    GraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0};
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto& cache = graph_cache()[s].g;
@@ -356,7 +356,12 @@ extern "C" int wh_decode_text(wh_session* s, int batch, const wh_decoding_option
         q.active = active ? (active[b] != 0) : 1;
         q.temperature = f16_round(temperatures ? temperatures[b] : opt->temperature);
     }
+    // fused greedy path: every active slot samples at T = 0 (filters + softmax statistics in the logits epilogue)
+    s->fused_greedy = true;
+    for (int b = 0; b < batch; ++b) if (s->seq_host[b].active && s->seq_host[b].temperature != 0.0f) s->fused_greedy = false;
+    if (const char* e = getenv("WH_NO_FUSED_SAMPLER")) if (e[0] == '1') s->fused_greedy = false;
     WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
+    launch_rules_init(s->cfg_dev, s->seq, batch, s->st);
     const int loop_count = std::min(opt->sample_length, kMaxTok - 1);
     r = run_token_loop(s, batch, std::max(loop_count, 0));
     if (r) return r;
@@ -731,6 +736,7 @@ extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double*
             q.n_tokens = pl; q.token_index = 0; q.next_token = q.tokens[0]; q.done = 0; q.active = 1; q.steps = 0; q.first_token_too_low = 0;
         }
         hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st);
+        launch_rules_init(s->cfg_dev, s->seq, batch, s->st);
         DecodeBuffers db = whi::decode_buffers(s, batch);
         for (int i = 0; i < n_steps; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
     }

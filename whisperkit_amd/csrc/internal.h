@@ -56,6 +56,9 @@ struct wh_session {
     wh::SeqState* seq_host = nullptr;     // pinned
     wh::SamplerCfg* cfg_dev = nullptr;
     int* suppress_dev = nullptr;
+    unsigned char* sup_mask_dev = nullptr;   // [V] SuppressTokensFilter byte mask (fused greedy sampler)
+    float* stats = nullptr;                  // [B][kStatBlocks][8]
+    bool fused_greedy = false;
     int *tok_out_dev = nullptr; float* lp_out_dev = nullptr;
     float* scratch_logits = nullptr;       // [V] for the filter / sample KAT entry points
     hipEvent_t ev[8]{};

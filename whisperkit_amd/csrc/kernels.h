@@ -128,7 +128,8 @@ struct SeqState {
     int active;
     float temperature;
     int prompt_len;               // initialPromptIndex
-    int pad[7];
+    int f_rules[6];               // filter rules of the NEXT sampling step: blank, ts_active, r1_lo, r1_hi, r2_lo, r2_hi
+    int pad;
 };
 
 struct DecodeBuffers {
@@ -148,17 +149,23 @@ struct DecodeBuffers {
     float* part;             // [B][H][kMaxSplit][kPartStride] cross-attention split partials
     int* ticket;             // [B][H]
     float* logits;           // [B][V]
+    float* stats;            // [B][kStatBlocks][8] per-workgroup softmax statistics of the logits kernel (fused greedy sampler)
+    const unsigned char* sup_mask;   // [V] SuppressTokensFilter as a byte mask
+    int fused_greedy;        // every active slot samples at T = 0: filters + statistics in the logits epilogue, tiny final kernel
     float* align;            // [B][224][n_align][1500] raw score rows of the alignment heads (or null)
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
 };
+constexpr int kStatBlocks = 1024; // >= workgroups of the logits kernel (V / 64 rows)
 constexpr int kMaxSplit = 24;   // cross-attention key splits (64 keys per workgroup at the finest)
 constexpr int kPartStride = 96; // floats per split partial (m, l, o[64]) padded to 3 x 128 bytes: no cache line is shared between splits
 int cross_attn_splits(int batch, int n_head);
 
 // one decoder forward + (optionally) fused filter/sample/state-advance for all slots
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st);
+// filter rules of the first sampling step of a decodeText call (later steps: computed by the sampler itself)
+void launch_rules_init(const SamplerCfg* cfg_dev, SeqState* seq, int batch, hipStream_t st);
 // standalone filter / sampler entry points (KAT surface of the C ABI)
 void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int n_vocab, hipStream_t st);
 void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits, int n_vocab, int counter, int* token_out, float* logprob_out, hipStream_t st);
