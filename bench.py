@@ -287,7 +287,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=4, help="steps (batches of --batch chunks) in flight per GPU, each on its own session / HIP stream")
+    ap.add_argument("--inflight", type=int, default=3, help="steps (batches of --batch chunks) in flight per GPU, each on its own session / HIP stream")
     ap.add_argument("--serial-reference", action="store_true", default=True)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")

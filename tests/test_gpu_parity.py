@@ -150,6 +150,35 @@ def test_encoder_batch_slots_are_independent(micro):
     np.testing.assert_array_equal(s1.getEncoderOutput(0), s3.getEncoderOutput(2))
 
 
+def test_encoder_and_cross_kv_large_batch_tile256_path():
+    """8 chunks of a tiny.en-shaped model: M = 12000 rows puts the encoder GEMMs and the cross-K/V projection on the
+    256x256 LDS-DMA kernel (the micro fixtures stay on the small-tile kernel).  Encoder output and teacher-forced logits of
+    the first and the last slot against the oracle."""
+    dims = weights.MODEL_DIMS["tiny.en"]
+    sd = weights.synthetic_state_dict(dims, seed=3)
+    model = api.Model(dims, sd)
+    om = OracleWhisper(dims, sd)
+    B = 8
+    xs = [synthetic_chunk(300 + b) for b in range(B)]
+    sess = api.Session(model, B)
+    for b, x in enumerate(xs):
+        sess.padOrTrim(x, b)
+    sess.logMelSpectrogram(B); sess.encodeFeatures(B); sess.prepareDecoderInputs(B)
+    st, _ = OD.special_tokens_for_vocab(dims.n_vocab)
+    toks = [st.startOfTranscriptToken, st.timeTokenBegin, 400, 1029]
+    states = {}
+    for b in (0, B - 1):
+        ref = om.encode(omel.log_mel_spectrogram(xs[b], dims.n_mels).astype(np.float32))
+        got = sess.getEncoderOutput(b)
+        assert np.abs(got - ref).max() <= 3e-2 and np.abs(got - ref).mean() <= 3e-3, (b, np.abs(got - ref).max())
+        states[b] = om.new_state(got.astype(np.float16).astype(np.float32))
+    for pos, t in enumerate(toks):
+        got = sess.predictLogits([int(t)] * B, [pos] * B)
+        for b in (0, B - 1):
+            ref = states[b].step(int(t), pos)
+            assert np.abs(got[b] - ref).max() <= 1e-3, (b, pos, np.abs(got[b] - ref).max())
+
+
 # ------------------------------------------------------------------------------------------------ decoder step
 @pytest.mark.parametrize("which", ["micro", "micro_ml"])
 def test_predict_logits_teacher_forced(which, request, jfk_pcm):

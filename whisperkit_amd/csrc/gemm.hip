@@ -9,12 +9,87 @@
 // Used for: conv1/conv2 as GEMMs over an overlapping-row view of the time-major input (K = 3*C_in),
 // encoder QKV / out-proj / MLP, and the cross-attention K/V projection of all decoder layers.
 // These are the encoder FLOPs of SURVEY.md section 8(d): MFMA-bound.
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace wh {
 
 constexpr int BK = 32;
 constexpr int LDT = 40;  // LDS row stride in halves (32 + 8 pad)
+
+// Fused epilogue of one wave's TM x TN accumulator tiles.  C layout of v_mfma_f32_32x32x16: col n = lane & 31,
+// row m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  m_wave / n_wave = first row / column of the wave's sub-tile.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m_wave, int n_wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_wave + j * 32 + (lane & 31);
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m_wave + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {        // 4 groups of 4 consecutive rows
+                const int mg = mb + 8 * g;
+                if (mg >= a.M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r] + bias;
+                if constexpr (EPI == EPI_QKV_ENC) {
+                    const int d = a.d_model;
+                    if (n >= 2 * d) {   // V^T[(b*H + h)*64 + c][t], 4 consecutive t -> one 8-byte store
+                        int call = n - 2 * d;
+                        int bb = mg / kCtx, t = mg - bb * kCtx;
+                        if (t + 3 < kCtx) {
+                            f16x4 pk = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                            *reinterpret_cast<f16x4*>(a.vt16 + ((size_t)bb * d + call) * kCtxPad + t) = pk;
+                        } else {        // the 4-row group straddles a slot boundary (1500 is a multiple of 4, so this is never taken)
+                            for (int r = 0; r < 4; ++r) {
+                                int m = mg + r;
+                                if (m < a.M) { int b2 = m / kCtx, t2 = m - b2 * kCtx; a.vt16[((size_t)b2 * d + call) * kCtxPad + t2] = (f16)v[r]; }
+                            }
+                        }
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mg + r;
+                    if (m >= a.M) continue;
+                    const float x = v[r];
+                    if constexpr (EPI == EPI_F16) {
+                        a.out16[(size_t)m * a.ldc + n] = (f16)x;
+                    } else if constexpr (EPI == EPI_GELU_F16) {
+                        a.out16[(size_t)m * a.ldc + n] = (f16)gelu_erf(x);
+                    } else if constexpr (EPI == EPI_RESID_F32) {
+                        a.out32[(size_t)m * a.ldc + n] += x;
+                    } else if constexpr (EPI == EPI_F32) {
+                        a.out32[(size_t)m * a.ldc + n] = x;
+                    } else if constexpr (EPI == EPI_QKV_ENC) {
+                        const int d = a.d_model;
+                        if (n < d) a.out16[(size_t)m * d + n] = (f16)x;
+                        else a.k16[(size_t)m * d + (n - d)] = (f16)x;
+                    } else if constexpr (EPI == EPI_CROSS_KV) {
+                        const int d = a.d_model, H = d >> 6;
+                        const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
+                        const int bb = m / kCtx, t = m - bb * kCtx;
+                        f16* dst = kv ? a.vt16 : a.k16;
+                        dst[((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63)] = (f16)x;
+                    } else if constexpr (EPI == EPI_CONV1) {
+                        int bb = m / a.rows_per_batch_out, t = m - bb * a.rows_per_batch_out;
+                        a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf(x);
+                    } else if constexpr (EPI == EPI_CONV2) {
+                        int t = m % a.rows_per_batch_out;
+                        a.out32[(size_t)m * a.ldc + n] = gelu_erf(x) + a.pos[(size_t)t * a.ldc + n];
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
@@ -101,70 +176,176 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue.  C layout (32x32): col n = lane & 31, row m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+// Epilogue for accumulators produced with the operands swapped (mfma(W fragment, A fragment)): the 32 x 32 tile is C^T,
+// so a lane owns ONE output row m = lane & 31 and, per register group, 4 CONSECUTIVE columns n - row-major outputs go
+// out as 8-byte (f16x4) / 16-byte (float4) accesses instead of 2- and 4-byte ones.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m_wave, int n_wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        if (n >= a.N) continue;
-        const float bias = a.bias ? a.bias[n] : 0.0f;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_wave + i * 32 + (lane & 31);
+        if (m >= a.M) continue;
+        int bb = 0, t = m;
+        if constexpr (EPI == EPI_CROSS_KV) { bb = m / kCtx; t = m - bb * kCtx; }
+        if constexpr (EPI == EPI_CONV1 || EPI == EPI_CONV2) { bb = m / a.rows_per_batch_out; t = m - bb * a.rows_per_batch_out; }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {        // 4 groups of 4 consecutive rows
-                const int mg = mb + 8 * g;
-                if (mg >= a.M) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r] + bias;
-                if constexpr (EPI == EPI_QKV_ENC) {
+            for (int g = 0; g < 4; ++g) {
+                const int n = n_wave + j * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= a.N) continue;
+                float4 bias = float4{0, 0, 0, 0};
+                if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + n);
+                float v0 = acc[i][j][4 * g] + bias.x, v1 = acc[i][j][4 * g + 1] + bias.y;
+                float v2 = acc[i][j][4 * g + 2] + bias.z, v3 = acc[i][j][4 * g + 3] + bias.w;
+                if constexpr (EPI == EPI_F16) {
+                    *reinterpret_cast<f16x4*>(a.out16 + (size_t)m * a.ldc + n) = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                } else if constexpr (EPI == EPI_GELU_F16) {
+                    *reinterpret_cast<f16x4*>(a.out16 + (size_t)m * a.ldc + n) =
+                        f16x4{(f16)gelu_erf(v0), (f16)gelu_erf(v1), (f16)gelu_erf(v2), (f16)gelu_erf(v3)};
+                } else if constexpr (EPI == EPI_RESID_F32) {
+                    float4* p = reinterpret_cast<float4*>(a.out32 + (size_t)m * a.ldc + n);
+                    float4 o = *p;
+                    o.x += v0; o.y += v1; o.z += v2; o.w += v3;
+                    *p = o;
+                } else if constexpr (EPI == EPI_F32) {
+                    *reinterpret_cast<float4*>(a.out32 + (size_t)m * a.ldc + n) = float4{v0, v1, v2, v3};
+                } else if constexpr (EPI == EPI_QKV_ENC) {   // q / k columns only (the V^T tiles use the unswapped order)
                     const int d = a.d_model;
-                    if (n >= 2 * d) {   // V^T[(b*H + h)*64 + c][t], 4 consecutive t -> one 8-byte store
-                        int call = n - 2 * d;
-                        int bb = mg / kCtx, t = mg - bb * kCtx;
-                        f16x4 pk = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                        *reinterpret_cast<f16x4*>(a.vt16 + ((size_t)bb * d + call) * kCtxPad + t) = pk;
-                        continue;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mg + r;
-                    if (m >= a.M) continue;
-                    const float x = v[r];
-                    if constexpr (EPI == EPI_F16) {
-                        a.out16[(size_t)m * a.ldc + n] = (f16)x;
-                    } else if constexpr (EPI == EPI_GELU_F16) {
-                        a.out16[(size_t)m * a.ldc + n] = (f16)gelu_erf(x);
-                    } else if constexpr (EPI == EPI_RESID_F32) {
-                        a.out32[(size_t)m * a.ldc + n] += x;
-                    } else if constexpr (EPI == EPI_F32) {
-                        a.out32[(size_t)m * a.ldc + n] = x;
-                    } else if constexpr (EPI == EPI_QKV_ENC) {
-                        const int d = a.d_model;
-                        if (n < d) a.out16[(size_t)m * d + n] = (f16)x;
-                        else a.k16[(size_t)m * d + (n - d)] = (f16)x;
-                    } else if constexpr (EPI == EPI_CROSS_KV) {
-                        const int d = a.d_model, H = d >> 6;
-                        const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
-                        const int bb = m / kCtx, t = m - bb * kCtx;
-                        f16* dst = kv ? a.vt16 : a.k16;
-                        dst[((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63)] = (f16)x;
-                    } else if constexpr (EPI == EPI_CONV1) {
-                        int bb = m / a.rows_per_batch_out, t = m - bb * a.rows_per_batch_out;
-                        a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf(x);
-                    } else if constexpr (EPI == EPI_CONV2) {
-                        int t = m % a.rows_per_batch_out;
-                        a.out32[(size_t)m * a.ldc + n] = gelu_erf(x) + a.pos[(size_t)t * a.ldc + n];
-                    }
+                    f16* dst = n < d ? a.out16 + (size_t)m * d + n : a.k16 + (size_t)m * d + (n - d);
+                    *reinterpret_cast<f16x4*>(dst) = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                } else if constexpr (EPI == EPI_CROSS_KV) {
+                    const int d = a.d_model, H = d >> 6;
+                    const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
+                    f16* dst = (kv ? a.vt16 : a.k16) + ((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63);
+                    *reinterpret_cast<f16x4*>(dst) = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                } else if constexpr (EPI == EPI_CONV1) {
+                    *reinterpret_cast<f16x4*>(a.out16 + ((size_t)bb * kFramesPad + t + 1) * a.ldc + n) =
+                        f16x4{(f16)gelu_erf(v0), (f16)gelu_erf(v1), (f16)gelu_erf(v2), (f16)gelu_erf(v3)};
+                } else if constexpr (EPI == EPI_CONV2) {
+                    const float4 ps = *reinterpret_cast<const float4*>(a.pos + (size_t)t * a.ldc + n);
+                    *reinterpret_cast<float4*>(a.out32 + (size_t)m * a.ldc + n) =
+                        float4{gelu_erf(v0) + ps.x, gelu_erf(v1) + ps.y, gelu_erf(v2) + ps.z, gelu_erf(v3) + ps.w};
                 }
             }
         }
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 256 x 256 x 64 tile
+// Large-problem path (encoder GEMMs at batch >= 2, cross-K/V projection): 8 waves (2 along M x 4 along N, wave tile
+// 128 x 64 = 4 x 2 MFMA tiles), operands staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass) into two 64 KB stages - the DMA of K-tile t+1 is in flight under the MFMAs of tile t, one barrier per
+// K-tile.  An LDS row is the 128-byte K-slice of one operand row; the DMA image is lane-linear, so the bank swizzle
+// (16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for every lane group) is applied
+// to the SOURCE address: a row's 8 chunks are fetched permuted inside the same 128-byte line, coalescing intact.
+// Workgroup ids are remapped so that the 8 XCDs (id % 8) each walk their own contiguous range of tiles, N fastest:
+// an XCD's L2 keeps one 256-row A panel and the weight panel it is sweeping.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
+    constexpr int TM = 4, TN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [2 stages][A 32 KB | B 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // XCD-aware bijective remap of the linear workgroup id
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tiles_n = (a.N + 255) >> 8;
+    const int m0 = (wg / tiles_n) << 8, n0 = (wg % tiles_n) << 8;
+
+    // ---- staging addresses: round j of an operand covers rows j*64 + (tid >> 3), LDS slot tid & 7
+    const int srow = tid >> 3;
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk of LDS slot (tid & 7) in row srow (+64 j: same swizzle)
+    const f16* a_src[4];
+    const f16* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = min(m0 + j * 64 + srow, a.M - 1);
+        a_src[j] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + chunk * 8;
+        const int n = min(n0 + j * 64 + srow, a.N - 1);
+        b_src[j] = a.W + (long long)n * a.K + chunk * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * 65536 + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
+    const int a_row_off = (wm * 128 + fr) * 128, b_row_off = 32768 + (wn * 64 + fr) * 128;
+    const int nk = a.K >> 6;
+    // SWAP: operands swapped so that a lane owns 4 consecutive output columns (row-major outputs); the V^T tiles of the
+    // encoder QKV projection keep the unswapped order (a lane owns 4 consecutive rows = 4 consecutive time steps)
+    auto body = [&](auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt have landed
+            __syncthreads();                                   // ... everyone's; and every wave is done reading stage buf ^ 1
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            const unsigned char* sb = smem + buf * 65536;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int slot = ((2 * ks + fh) ^ swz) * 16;
+                f16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 4096 + slot);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    };
+    if constexpr (EPI == EPI_QKV_ENC) {
+        if (n0 >= 2 * a.d_model) body(std::false_type{});
+        else body(std::true_type{});
+    } else {
+        body(std::true_type{});
+    }
+}
+
 template <int EPI>
 static void launch_epi(const GemmArgs& a, hipStream_t st) {
+    // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
+    const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
+    if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0 &&
+        (EPI != EPI_QKV_ENC || (2 * a.d_model) % 256 == 0)) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            raised = true;
+        }
+        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(a);
+        return;
+    }
     // small problems get 64x64 tiles so that more than a handful of CUs are busy
     long long tiles128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (tiles128 >= 192) {
