@@ -88,7 +88,7 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float):
     raise KeyError(kind)
 
 
-def measure_kernels(sess, dims, B, n_meas, decode_steps):
+def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
     """HIP-event timing of every kernel launch of one eager pass (mel, encoder, cross-K/V, n_meas decoder steps)."""
     from whisperkit_amd import api
     lib = sess.lib
@@ -115,17 +115,27 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps):
                        "bound": bound, "alg_per_launch": int(amount), "achieved": round(ach, 2), "unit": unit,
                        "frac": round(ach / peak, 4), "share_of_step": None}
     tot = sum(step_us.values())
+    # HBM traffic per launch from the off-line PMC passes (profiles/*_pmc_traffic.json), when they were taken on this workload
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if tj.get("model") == model_name and tj.get("chunks_per_gpu") == B:
+            traffic = tj["bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
     for name in table:
         table[name]["share_of_step"] = round(step_us[name] / tot, 4)
+        table[name]["traffic"] = traffic.get(name)
     dom = max(step_us, key=step_us.get)
     t = table[dom]
     return {"kernel": dom, "bound": t["bound"], "achieved": t["achieved"],
-            "peak": HBM_PEAK_GBS if t["bound"] == "hbm" else MFMA_F16_PEAK_TF, "unit": t["unit"], "frac": t["frac"], "traffic": None,
+            "peak": HBM_PEAK_GBS if t["bound"] == "hbm" else MFMA_F16_PEAK_TF, "unit": t["unit"], "frac": t["frac"], "traffic": t["traffic"],
             "avg_us": t["avg_us"], "alg_per_launch": t["alg_per_launch"], "share_of_step_time": t["share_of_step"],
             "sum_kernel_ms_per_step": round(tot / 1e3, 3), "kernels": table,
             "note": "eager launches, one HIP event pair per launch on the session stream; decoder kernels averaged over "
-                    f"{n_meas} steps (positions 0..{n_meas - 1}) and weighted to {decode_steps} steps; traffic (PMC) is "
-                    "collected off-line, see profiles/"}
+                    f"{n_meas} steps (positions 0..{n_meas - 1}) and weighted to {decode_steps} steps; traffic = HBM bytes per launch "
+                    "from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json; FETCH_SIZE x2 "
+                    "per the gfx950 correction), null when no pass exists for this workload"}
 
 
 def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu):
@@ -238,7 +248,7 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
                          "tokens_per_s": B * r2[0].steps / med[3], "us_per_decoder_step": med[3] * 1e6 / max(r2[0].steps, 1)}
         log(f"{model_name}: stages {json.dumps({k: round(v, 3) for k, v in out['stages'].items()})}")
     if rank == 0 and want_roofline:
-        out["roofline"] = measure_kernels(sess, dims, B, 16, dec_steps[0])
+        out["roofline"] = measure_kernels(sess, dims, B, 16, dec_steps[0], model_name)
         log(f"{model_name}: roofline leg done")
 
     # ---- CPU baseline: the oracle (port of the same algorithm) on the host cores, bounded sample

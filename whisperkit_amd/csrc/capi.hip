@@ -332,7 +332,9 @@ extern "C" int wh_session_synchronize(wh_session* s) {
 }
 extern "C" void* wh_session_stream(wh_session* s) { return s ? (void*)s->st : nullptr; }
 
-#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); } while (0)
+// the HIP current device is per host thread: sessions are driven from worker threads, so every entry point re-selects it
+#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); \
+                              if (hipSetDevice((s)->m->device) != hipSuccess) return set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
 #define CHECK_SLOT(s, b) do { if ((b) < 0 || (b) >= (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: slot %d out of range [0,%d)", __func__, (b), (s)->B); } while (0)
 #define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
 

@@ -27,7 +27,9 @@ int upload_sampler_cfg(wh_session* s, const wh_decoding_options* opt, const wh_s
                        int initial_prompt_index, int language_filter, uint64_t seed);
 }
 
-#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); } while (0)
+// the HIP current device is per host thread: sessions are driven from worker threads, so every entry point re-selects it
+#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); \
+                              if (hipSetDevice((s)->m->device) != hipSuccess) return set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
 #define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
 
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
