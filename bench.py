@@ -138,7 +138,7 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
                     "per the gfx950 correction), null when no pass exists for this workload"}
 
 
-def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu):
+def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False):
     import torch
     import torch.distributed as dist
     from whisperkit_amd import api, parallel, weights
@@ -160,7 +160,8 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
         for b, x in enumerate(chunks):
             ss.padOrTrim(x, b)                     # PCM resident in HBM before the timed region
     opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
-                               noSpeechThreshold=None, temperatureFallbackCount=0, sampleLength=args.sample_length)
+                               noSpeechThreshold=None, temperatureFallbackCount=0, sampleLength=args.sample_length,
+                               wordTimestamps=word_timestamps)
     prompt = sess.prefillPrompt(opts)
 
     def hot_path(ss):
@@ -168,6 +169,9 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
         ss.encodeFeatures(B)
         ss.prepareDecoderInputs(B)
         res = ss.decodeText(prompt, opts, batch=B)
+        if word_timestamps:     # findAlignment (SegmentSeeker.swift:340-408): alignment rows of the result tokens -> DTW
+            for b, r in enumerate(res):
+                api.dynamicTimeWarping(ss.getAlignmentWeights(b)[:len(r.tokens)])
         recs = np.stack([parallel.pack_record(first + b, r.tokens, 0, r.steps, r.avgLogProb, r.temperature, r.compressionRatio)
                          for b, r in enumerate(res)])
         return res, recs
@@ -257,6 +261,9 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
         from oracle import mel as omel
         from oracle.model import OracleWhisper
         n_cpu_steps = 16
+        # the per-token decoder step is a chain of matrix-vector products: beyond ~32 threads the fork/join cost of every
+        # op outweighs the extra memory bandwidth (measured on the 256-thread box: 2.6 s/step with 128 threads)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
         om = OracleWhisper(dims, sd)
         st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
         oopts = OD.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
@@ -333,6 +340,11 @@ def main():
             "value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / 8 * 1e3, 3), "steps_in_flight": o["inflight"],
             "decoder_steps": o["dec_steps"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
 
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.model, args.batch) == ("large-v3", 8):
+        o = run_config(args, "small", 8, 3, 1, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False, word_timestamps=True)
+        other["configs[2] whisper-small, 8 x 30 s chunks, greedy + word-timestamp alignment (DTW), 1 GPU"] = {
+            "value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / 3 * 1e3, 3), "steps_in_flight": o["inflight"],
+            "decoder_steps": o["dec_steps"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
     if rank == 0:
         B = args.batch
         out = {

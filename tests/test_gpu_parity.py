@@ -237,6 +237,44 @@ def test_predict_logits_batched_equals_single(micro):
             np.testing.assert_allclose(got[b], singles[b][p], atol=1e-5, rtol=0)
 
 
+def test_decode_text_batch_above_one_batch_tile(micro):
+    """10 slots = two batch tiles of the decoder GEMV kernels (8 + 2): every slot must decode exactly like it does alone."""
+    dims, _, model, om = micro
+    B = 10
+    xs = [synthetic_chunk(500 + b) for b in range(B)]
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12)
+    sb = api.Session(model, B)
+    for b, x in enumerate(xs):
+        sb.padOrTrim(x, b)
+    sb.logMelSpectrogram(B); sb.encodeFeatures(B); sb.prepareDecoderInputs(B)
+    prompt = sb.prefillPrompt(opts)
+    rb = sb.decodeText(prompt, opts, batch=B)
+    s1 = api.Session(model, 1)
+    for b in (0, 7, 8, 9):
+        s1.padOrTrim(xs[b]); s1.logMelSpectrogram(1); s1.encodeFeatures(1); s1.prepareDecoderInputs(1)
+        r1 = s1.decodeText(prompt, opts)[0]
+        assert rb[b].tokens == r1.tokens, b
+        assert rb[b].tokenLogProbs == r1.tokenLogProbs, b      # batch invariance is bit-exact (same kernels' summation orders)
+        np.testing.assert_array_equal(sb.getEncoderOutput(b), s1.getEncoderOutput(0))
+
+
+def test_fused_greedy_sampler_equals_reference_sampler_kernel(micro_ml, monkeypatch):
+    """The fused greedy path (filters + softmax statistics in the logits epilogue + sampler_final_kernel) against the
+    one-workgroup sampler kernel that restates LogitsFilter.swift / TokenSampler.swift element by element."""
+    dims, _, model, om = micro_ml
+    x = synthetic_chunk(77)
+    kw = dict(**NOFALLBACK, sampleLength=48, suppressBlank=True, suppressTokens=[11, 12, 13])
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WH_NO_FUSED_SAMPLER", flag)
+        sess = api.Session(model, 1)
+        sess.padOrTrim(x); sess.logMelSpectrogram(1); sess.encodeFeatures(1); sess.prepareDecoderInputs(1)
+        opts = api.DecodingOptions(**kw)
+        res.append(sess.decodeText(sess.prefillPrompt(opts), opts)[0])
+    assert res[0].tokens == res[1].tokens and res[0].steps == res[1].steps
+    np.testing.assert_allclose(res[0].tokenLogProbs, res[1].tokenLogProbs, atol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ filters / sampler (reference KATs on device)
 def Lh(*v):
     return np.array(v, dtype=np.float16).astype(np.float32)

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     constexpr int NV = R * BT;                              // accumulators per lane (<= 32)
     constexpr bool kPrefetchNextPass = (MODE == MODE_LOGITS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* xs = reinterpret_cast<float*>(smem_raw);   // [BT][K] f32   (MODE_FC2: f16 [BT][K])
-    f16* xh = reinterpret_cast<f16*>(smem_raw);
+    float* xs = reinterpret_cast<float*>(smem_raw);   // [BT][K] f32 (+ gamma, beta in the LayerNorm modes); unused by MODE_FC2
     __shared__ float red[NW];
     __shared__ float kred[NW][32];
     __shared__ float lt[MODE == MODE_LOGITS ? BT * 64 : 1];   // this workgroup's logits (<= 64 rows) for the fused sampler statistics
@@ -245,23 +244,18 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     // ------------------------------------------------------------------ prologue -> LDS
     // Issue order matters: memory returns are in order per wave, so the (small, L2-resident) activation loads go out
     // first and the weight stream (HBM) second - the LayerNorm then runs while the weights are still in flight.
+    // MODE_FC2: each wave needs only ITS K range of the hidden activations (f16, written by the fc1 kernel): they go straight
+    // from L2 into registers - no LDS image (80 KB at d = 1280 would cap the residency at one workgroup per CU), no barrier
+    uint4 hreg[MODE == MODE_FC2 ? BT : 1][MODE == MODE_FC2 ? KI : 1];
     if constexpr (MODE == MODE_FC2) {
-        constexpr int HV = (BT * 640 + NT - 1) / NT;    // uint4 per thread, K <= 5120
-        uint4 hreg[HV];
-        const int per_row = K / 8;
 #pragma unroll
-        for (int i = 0; i < HV; ++i) {
-            const int idx = tid + i * NT;
-            const int b = idx / per_row, c = idx - b * per_row;
-            hreg[i] = (idx < BT * per_row && b0 + b < a.batch) ? reinterpret_cast<const uint4*>(a.hbuf + (size_t)(b0 + b) * K)[c] : uint4{0, 0, 0, 0};
-        }
+        for (int b = 0; b < BT; ++b)
+#pragma unroll
+            for (int i = 0; i < KI; ++i)
+                hreg[b][i] = (b0 + b < a.batch && lane * 8 + 512 * i < KC)
+                                 ? *reinterpret_cast<const uint4*>(a.hbuf + (size_t)(b0 + b) * K + kbase + lane * 8 + 512 * i) : uint4{0, 0, 0, 0};
         load_group(cur, n_begin + rg * R);
         DBG_STAMP(1);
-#pragma unroll
-        for (int i = 0; i < HV; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < BT * per_row) reinterpret_cast<uint4*>(xh)[idx] = hreg[i];
-        }
     } else if constexpr (MODE == MODE_RESID) {
         constexpr int AV = (BT * 320 + NT - 1) / NT;    // float4 per thread, d <= 1280
         float4 areg[AV];
@@ -280,12 +274,14 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
             if (idx < BT * per_row) reinterpret_cast<float4*>(xs)[idx] = areg[i];
         }
     } else {
-        // LayerNorm in registers: row = tid / TPR, the row's d/4 float4 are dealt round-robin to its TPR threads
-        constexpr int TPR = NT / BT;
+        // LayerNorm in registers: row = tid / 32, the row's d/4 float4 are dealt round-robin to its 32 threads.  The split is
+        // the same for every batch tile size (threads beyond BT rows idle) so that the statistics - hence every logit - of a
+        // slot are bit-identical whether it is decoded alone or in a batch.
+        constexpr int TPR = 32;
         constexpr int MAXV = (320 + TPR - 1) / TPR;     // d <= 1280
         const int row = tid / TPR, li = tid - row * TPR;
         const int gb = b0 + row;
-        const bool rok = gb < a.batch;
+        const bool rok = row < BT && gb < a.batch;
         const int nv4 = d / 4;
         float4 v[MAXV];
         // gamma / beta: issued first (they depend on nothing), parked in LDS behind the activations, read back after the
@@ -356,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
                 o.x = (v[i].x - mean) * rstd * g.x + be.x; o.y = (v[i].y - mean) * rstd * g.y + be.y;
                 o.z = (v[i].z - mean) * rstd * g.z + be.z; o.w = (v[i].w - mean) * rstd * g.w + be.w;
                 if (!rok) o = float4{0, 0, 0, 0};
-                *reinterpret_cast<float4*>(xs + (size_t)row * d + c4 * 4) = o;
+                if (row < BT) *reinterpret_cast<float4*>(xs + (size_t)row * d + c4 * 4) = o;
             }
         }
     }
@@ -387,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
 #pragma unroll
                     for (int b = 0; b < BC; ++b) {
                         if constexpr (MODE == MODE_FC2) {
-                            f16x8 hv = *reinterpret_cast<const f16x8*>(xh + (size_t)(bc + b) * K + k);
+                            f16x8 hv = *reinterpret_cast<f16x8*>(&hreg[bc + b][i]);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xk[b][j] = (float)hv[j];
                         } else {
@@ -963,7 +959,7 @@ static void launch_gemv_r(GemvArgs a, int passes, hipStream_t st) {
     a.rows_per_block = (4 / a.k_split) * R * passes;
     dim3 g((a.N + a.rows_per_block - 1) / a.rows_per_block, (a.batch + BT - 1) / BT);
     const bool ln_mode = MODE == MODE_QKV || MODE == MODE_Q || MODE == MODE_FC1 || MODE == MODE_LOGITS;
-    const size_t smem = (MODE == MODE_FC2) ? (size_t)BT * a.K * sizeof(f16) : (size_t)(BT * a.K + (ln_mode ? 2 * a.d : 0)) * sizeof(float);
+    const size_t smem = (MODE == MODE_FC2) ? 0 : (size_t)(BT * a.K + (ln_mode ? 2 * a.d : 0)) * sizeof(float);
     if (smem > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation (160 KB per CU on gfx950)
         static bool raised = false;
         if (!raised) {
@@ -989,6 +985,13 @@ static void launch_gemv_bt(GemvArgs a, hipStream_t st) {
 
 template <int MODE>
 static void launch_gemv(const GemvArgs& a, hipStream_t st) {
+    if constexpr (MODE == MODE_FC2) {
+        // register-resident hidden activations: 4 slots per batch tile keep the kernel inside the VGPR budget (the second
+        // tile of a batch of 8 re-reads the weights through L2 while the first one streams them from HBM)
+        if (a.batch >= 2) launch_gemv_bt<MODE, 4>(a, st);
+        else launch_gemv_bt<MODE, 1>(a, st);
+        return;
+    }
     if (a.batch >= 5) launch_gemv_bt<MODE, 8>(a, st);
     else if (a.batch >= 2) launch_gemv_bt<MODE, 4>(a, st);
     else launch_gemv_bt<MODE, 1>(a, st);

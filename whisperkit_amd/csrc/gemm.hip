@@ -91,94 +91,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
     }
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int CA = BM * 4 / 256, CB = BN * 4 / 256;   // 16-byte chunks per thread per tile
-    __shared__ __attribute__((aligned(16))) f16 As[2][BM * LDT];
-    __shared__ __attribute__((aligned(16))) f16 Bs[2][BN * LDT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    // per-thread global row pointers (fixed across the K loop)
-    const f16* a_ptr[CA];
-    bool a_ok[CA];
-    int a_lds[CA];
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-        int c = tid + 256 * i, row = c >> 2, cc = c & 3;
-        int m = m0 + row;
-        a_ok[i] = m < a.M;
-        int mm = a_ok[i] ? m : 0;
-        long long off = (long long)(mm / a.a_rows_per_batch) * a.a_batch_stride + (long long)(mm % a.a_rows_per_batch) * a.lda;
-        a_ptr[i] = a.A + off + cc * 8;
-        a_lds[i] = row * LDT + cc * 8;
-    }
-    const f16* b_ptr[CB];
-    bool b_ok[CB];
-    int b_lds[CB];
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-        int c = tid + 256 * i, row = c >> 2, cc = c & 3;
-        int n = n0 + row;
-        b_ok[i] = n < a.N;
-        b_ptr[i] = a.W + (long long)(b_ok[i] ? n : 0) * a.K + cc * 8;
-        b_lds[i] = row * LDT + cc * 8;
-    }
-    const int kc = (tid & 3) * 8;  // this thread's k offset inside a tile
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    uint4 ra[CA], rb[CB];
-    auto gload = [&](int k0) {
-        bool kin = (k0 + kc) < a.K;
-#pragma unroll
-        for (int i = 0; i < CA; ++i) ra[i] = (a_ok[i] && kin) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : uint4{0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < CB; ++i) rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const uint4*>(b_ptr[i] + k0) : uint4{0, 0, 0, 0};
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(&As[buf][a_lds[i]]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(&Bs[buf][b_lds[i]]) = rb[i];
-    };
-
-    const int nk = (a.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int fr = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(&As[cur][(wm * WM + i * 32 + fr) * LDT + ks * 16 + fk]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(&Bs[cur][(wn * WN + j * 32 + fr) * LDT + ks * 16 + fk]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
-}
-
 // Epilogue for accumulators produced with the operands swapped (mfma(W fragment, A fragment)): the 32 x 32 tile is C^T,
 // so a lane owns ONE output row m = lane & 31 and, per register group, 4 CONSECUTIVE columns n - row-major outputs go
 // out as 8-byte (f16x4) / 16-byte (float4) accesses instead of 2- and 4-byte ones.
@@ -232,6 +144,108 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
                 }
             }
         }
+    }
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int CA = BM * 4 / 256, CB = BN * 4 / 256;   // 16-byte chunks per thread per tile
+    __shared__ __attribute__((aligned(16))) f16 As[2][BM * LDT];
+    __shared__ __attribute__((aligned(16))) f16 Bs[2][BN * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // per-thread global row pointers (fixed across the K loop)
+    const f16* a_ptr[CA];
+    bool a_ok[CA];
+    int a_lds[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        int c = tid + 256 * i, row = c >> 2, cc = c & 3;
+        int m = m0 + row;
+        a_ok[i] = m < a.M;
+        int mm = a_ok[i] ? m : 0;
+        long long off = (long long)(mm / a.a_rows_per_batch) * a.a_batch_stride + (long long)(mm % a.a_rows_per_batch) * a.lda;
+        a_ptr[i] = a.A + off + cc * 8;
+        a_lds[i] = row * LDT + cc * 8;
+    }
+    const f16* b_ptr[CB];
+    bool b_ok[CB];
+    int b_lds[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        int c = tid + 256 * i, row = c >> 2, cc = c & 3;
+        int n = n0 + row;
+        b_ok[i] = n < a.N;
+        b_ptr[i] = a.W + (long long)(b_ok[i] ? n : 0) * a.K + cc * 8;
+        b_lds[i] = row * LDT + cc * 8;
+    }
+    const int kc = (tid & 3) * 8;  // this thread's k offset inside a tile
+
+    uint4 ra[CA], rb[CB];
+    auto gload = [&](int k0) {
+        bool kin = (k0 + kc) < a.K;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ra[i] = (a_ok[i] && kin) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < CB; ++i) rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const uint4*>(b_ptr[i] + k0) : uint4{0, 0, 0, 0};
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(&As[buf][a_lds[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(&Bs[buf][b_lds[i]]) = rb[i];
+    };
+
+    const int nk = (a.K + BK - 1) / BK;
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    // Operand order per wave, the same rule as gemm256_kernel (so that both kernels produce bit-identical results and a
+    // chunk encodes the same alone or in a large batch): swapped (lane owns 4 consecutive columns) except for the V^T columns
+    // of the encoder QKV projection.  Both paths execute the same number of barriers.
+    auto body = [&](auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(&As[cur][(wm * WM + i * 32 + fr) * LDT + ks * 16 + fk]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(&Bs[cur][(wn * WN + j * 32 + fr) * LDT + ks * 16 + fk]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (kt + 1 < nk) lstore(cur ^ 1);
+            __syncthreads();
+        }
+        if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+        else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+    };
+    if constexpr (EPI == EPI_QKV_ENC) {
+        if (n0 + wn * WN >= 2 * a.d_model) body(std::false_type{});
+        else body(std::true_type{});
+    } else {
+        body(std::true_type{});
     }
 }
 
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
         else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
     };
     if constexpr (EPI == EPI_QKV_ENC) {
-        if (n0 >= 2 * a.d_model) body(std::false_type{});
+        if (n0 + wn * 64 >= 2 * a.d_model) body(std::false_type{});
         else body(std::true_type{});
     } else {
         body(std::true_type{});
@@ -336,8 +350,7 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
     // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
-    if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0 &&
-        (EPI != EPI_QKV_ENC || (2 * a.d_model) % 256 == 0)) {
+    if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
         static bool raised = false;
         if (!raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
