@@ -154,30 +154,54 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {   // ties -> s
     }
 }
 
-struct GemvArgs;
+// What the statistics epilogue of the logits kernel needs from global memory, fetched at kernel ENTRY (scalar loads keyed
+// by the wave-uniform slot index, one mask byte per lane) so that the epilogue itself is pure register / LDS work.
+struct StatPre {
+    int live[2];
+    int rules[2][6];
+    int masked;      // SuppressTokensFilter byte of row n_begin + lane (rows past n_end count as masked)
+};
+template <int BT, typename Args>
+__device__ __forceinline__ void logits_stats_prefetch(const Args& a, int b0, int n_begin, int n_end, StatPre& pre) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int b = wave + 4 * s, gb = b0 + b;
+        pre.live[s] = 0;
+        if (b < BT && gb < a.batch) {
+            const SeqState* sq = a.seq + gb;
+            pre.live[s] = slot_live(sq);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pre.rules[s][i] = sq->f_rules[i];
+        }
+    }
+    const int n = n_begin + lane;
+    pre.masked = n < n_end ? (int)a.sup_mask[n] : 1;
+}
+
 // Epilogue of the logits kernel when every live slot samples greedily: apply the index-predicate filters to this
 // workgroup's <= 64 logits per slot and reduce them to (max, argmax, sum exp) separately for text ids (< timeTokenBegin)
 // and timestamp ids; sampler_final_kernel merges the per-workgroup records.  One wave per slot, lane = row.
 template <int BT, typename Args>
-__device__ __forceinline__ void logits_block_stats(const Args& a, const float* lt, int b0, int n_begin, int n_end) {
+__device__ __forceinline__ void logits_block_stats(const Args& a, const float* lt, const StatPre& pre, int b0, int n_begin, int n_end,
+                                                   int tb, int ws_tok, int eot_tok, int no_ts_tok) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const SamplerCfg cfg = *a.cfg;
-    const int tb = cfg.time_token_begin;
-    for (int b = wave; b < BT; b += 4) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int b = wave + 4 * s;
+        if (b >= BT || !pre.live[s]) continue;
         const int gb = b0 + b;
-        if (gb >= a.batch) continue;
-        const SeqState* sq = a.seq + gb;
-        if (!slot_live(sq)) continue;
         const int n = n_begin + lane;
         float v = -INFINITY;
         if (n < n_end) {
             v = lt[b * 64 + lane];
-            const int blank = sq->f_rules[0], ts_active = sq->f_rules[1];
-            bool masked = a.sup_mask[n] != 0;                                                    // SuppressTokensFilter
-            masked |= blank && (n == cfg.whitespace_token || n == cfg.end_token);                // SuppressBlankFilter
-            masked |= ts_active && (n == cfg.no_timestamps_token || (n >= sq->f_rules[2] && n < sq->f_rules[3]) ||
-                                    (n >= sq->f_rules[4] && n < sq->f_rules[5]));               // TimestampRulesFilter
+            const int blank = pre.rules[s][0], ts_active = pre.rules[s][1];
+            bool masked = pre.masked != 0;                                                       // SuppressTokensFilter
+            masked |= blank && (n == ws_tok || n == eot_tok);                                    // SuppressBlankFilter
+            masked |= ts_active && (n == no_ts_tok || (n >= pre.rules[s][2] && n < pre.rules[s][3]) ||
+                                    (n >= pre.rules[s][4] && n < pre.rules[s][5]));             // TimestampRulesFilter
             if (masked) v = -INFINITY;
         }
         const bool is_ts = n >= tb;
@@ -192,7 +216,8 @@ __device__ __forceinline__ void logits_block_stats(const Args& a, const float* l
         ss = wave_sum(ss);
         if (lane == 0) {
             float* o = a.stats + ((size_t)gb * kStatBlocks + blockIdx.x) * 8;
-            o[0] = mt; o[1] = st; o[2] = __int_as_float(it); o[3] = ms; o[4] = ss; o[5] = __int_as_float(is);
+            *reinterpret_cast<float4*>(o) = float4{mt, st, __int_as_float(it), ms};
+            *reinterpret_cast<float2*>(o + 4) = float2{ss, __int_as_float(is)};
         }
     }
 }
@@ -359,6 +384,14 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     __syncthreads();
     DBG_STAMP(2);
 
+    StatPre pre;
+    int st_tb = 0, st_ws = 0, st_eot = 0, st_nots = 0;
+    if constexpr (MODE == MODE_LOGITS) {
+        if (a.stats) {
+            logits_stats_prefetch<BT>(a, b0, n_begin, n_end, pre);
+            st_tb = a.cfg->time_token_begin; st_ws = a.cfg->whitespace_token; st_eot = a.cfg->end_token; st_nots = a.cfg->no_timestamps_token;
+        }
+    }
     // ------------------------------------------------------------------ GEMV passes
 #pragma unroll 1
     for (int p = 0; p < n_pass; ++p) {
@@ -457,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         }
     }
     if constexpr (MODE == MODE_LOGITS) {
-        if (a.stats) logits_block_stats<BT>(a, lt, b0, n_begin, n_end);
+        if (a.stats) logits_block_stats<BT>(a, lt, pre, b0, n_begin, n_end, st_tb, st_ws, st_eot, st_nots);
     }
     DBG_STAMP(5); DBG_STAMP(7);
 }
@@ -903,9 +936,13 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
                                                             const float* __restrict__ stats, int nblk) {
     __shared__ float sm[4][4];
     __shared__ int si[4][2];
+    __shared__ SeqState sq_l;     // the slot's whole decode state: thread 0's bookkeeping (token history scans, appends) runs on
+                                  // this LDS copy instead of a chain of dependent global round trips
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SeqState* sq = seqs + b;
     if (!slot_live(sq)) return;
+    constexpr int kWords = sizeof(SeqState) / 4;
+    for (int i = tid; i < kWords; i += 256) reinterpret_cast<int*>(&sq_l)[i] = reinterpret_cast<const int*>(sq)[i];
     SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
     for (int i = tid; i < nblk; i += 256) {
         const float* e = stats + ((size_t)b * kStatBlocks + i) * 8;
@@ -921,7 +958,7 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
     if (tid == 0) {
         for (int w = 1; w < 4; ++w) { stat_merge(t, sm[w][0], sm[w][1], si[w][0]); stat_merge(u, sm[w][2], sm[w][3], si[w][1]); }
         const SamplerCfg cfg = *cfgp;
-        const bool ts_active = sq->f_rules[1] != 0;
+        const bool ts_active = sq_l.f_rules[1] != 0;
         int tok; float lp;
         const bool cond = ts_active && u.m != -INFINITY && (u.m + logf(u.s) > t.m);
         if (cond || t.m == -INFINITY) {          // text ids masked: the candidates are the timestamp ids
@@ -931,8 +968,10 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
             stat_merge(g, u.m, u.s, u.i);        // equal maxima: the text id (smaller index) wins, like a first-maximum argmax
             tok = g.i; lp = -logf(g.s);
         }
-        advance_decode_state(cfg, sq, tok, lp, sq->n_tokens);
+        advance_decode_state(cfg, &sq_l, tok, lp, sq_l.n_tokens);
     }
+    __syncthreads();
+    for (int i = tid; i < kWords; i += 256) reinterpret_cast<int*>(sq)[i] = reinterpret_cast<const int*>(&sq_l)[i];
 }
 
 __global__ void rules_init_kernel(const SamplerCfg* __restrict__ cfgp, SeqState* __restrict__ seqs) {
