@@ -347,6 +347,14 @@ def main():
         other["configs[2] whisper-small, 8 x 30 s chunks, greedy + word-timestamp alignment (DTW), 1 GPU"] = {
             "value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / 3 * 1e3, 3), "steps_in_flight": o["inflight"],
             "decoder_steps": o["dec_steps"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.model, args.batch) == ("large-v3", 8):
+        saved = args.inflight
+        args.inflight = 2
+        o = run_config(args, "large-v3", 32, 4, 2, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        args.inflight = saved
+        other["whisper-large-v3, 32 x 30 s chunks per step (batch scaling of the same engine), greedy, 1 GPU"] = {
+            "value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / 4 * 1e3, 3), "steps_in_flight": o["inflight"],
+            "decoder_steps": o["dec_steps"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
     if rank == 0:
         B = args.batch
         out = {
