@@ -143,3 +143,28 @@ def test_prefill_prompt_matches_oracle():
     assert D.prefill_prompt(o, s_ml, True) == [s_ml.startOfPreviousToken, 5, 6, 7, s_ml.startOfTranscriptToken, s_ml.englishToken,
                                                s_ml.transcribeToken, s_ml.timeTokenBegin, 8, 9]
     assert lib.wh_prefill_prompt(None, None, None, -1, None, 0) == -1
+
+
+def test_bench_knows_every_kernel_kind():
+    """bench.py prices every kernel kind the library can report (wh_kernel_kind_name): a new kind without an algorithmic
+    byte / FLOP formula must fail here, not in the middle of a GPU bench run."""
+    import importlib.util
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "whisperkit_amd", "csrc", "host.hip")).read()
+    block = src[src.index("kKindNames[KK_COUNT]"):]
+    names = re.findall(r'"([a-z0-9_]+)"', block[:block.index("};")])
+    assert len(names) >= 20 and "dec_cross_attn" in names
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from whisperkit_amd import weights
+    lib = L.load()
+    assert lib.wh_kernel_kind_count() == len(names)
+    assert [lib.wh_kernel_kind_name(k).decode() for k in range(len(names))] == names
+    for model in ("tiny.en", "large-v3"):
+        for n in names:
+            bound, amount = bench.algorithmic_work(n, weights.MODEL_DIMS[model], 8, 8.5)
+            assert bound in ("hbm", "mfma") and amount > 0

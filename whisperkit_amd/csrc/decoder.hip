@@ -1030,7 +1030,8 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
         else launch_gemv_bt<MODE, 1>(a, st);
         return;
     }
-    if (a.batch >= 5) launch_gemv_bt<MODE, 8>(a, st);
+    static const int bt4 = env_int("WH_GEMV_BT4", 0);   // tuning knob: batch tiles of 4 slots for every GEMV
+    if (a.batch >= 5 && !bt4) launch_gemv_bt<MODE, 8>(a, st);
     else if (a.batch >= 2) launch_gemv_bt<MODE, 4>(a, st);
     else launch_gemv_bt<MODE, 1>(a, st);
 }
