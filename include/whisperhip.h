@@ -235,6 +235,14 @@ int wh_transcribe(wh_session* s, const float* pcm_host, int n_samples, const wh_
 /* WhisperKit.transcribe(audioArrays:) (Core/WhisperKit.swift:716-812): independent audios/chunks, batched on device */
 int wh_transcribe_batch(wh_session* s, const float* const* pcm_host, const int32_t* n_samples, int n_audio,
                         const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out /* [n_audio] */);
+/* WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): audio longer than one window is
+ * split by VADAudioChunker.chunkAll, the chunks are transcribed as independent audios (batched on the device, clipTimestamps
+ * reset) and every segment / word is shifted by its chunk's seek offset (AudioChunking.updateSeekOffsetsForResults,
+ * Core/Audio/AudioChunker.swift:14-39; TranscriptionUtilities.updateSegmentTimings, Utilities/TranscriptionUtilities.swift:55-69).
+ * Writes one transcription per chunk into out[0..*n_out) (chunk order) and the chunks' seek offsets (samples) into
+ * seek_offsets_out (may be NULL); returns WH_ERR_INVALID_ARGUMENT when more than `capacity` chunks are needed. */
+int wh_transcribe_chunked(wh_session* s, const float* pcm_host, int n_samples, const wh_decoding_options* opt,
+                          const wh_special_tokens* st, wh_transcription** out, int capacity, int32_t* seek_offsets_out, int* n_out);
 void wh_transcription_free(wh_transcription* t);
 int wh_transcription_n_segments(const wh_transcription* t);
 int wh_transcription_segment(const wh_transcription* t, int i, wh_segment* out);

@@ -884,3 +884,37 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
             result.windows += 1
     result.segments, result.tokens, result.language = allSegments, allTokens, detectedLanguage or "en"
     return result
+
+
+# ----------------------------------------------------------------------------- WhisperKit.transcribe(audioArray:) with .vad chunking
+def update_segment_timings(segment: TranscriptionSegment, seekTime: float) -> TranscriptionSegment:
+    """Utilities/TranscriptionUtilities.swift:55-69 (Float arithmetic)."""
+    seg = dataclasses.replace(segment)
+    st32 = np.float32(seekTime)
+    seg.seek = segment.seek + int(st32 * np.float32(SAMPLE_RATE))
+    seg.start = float(np.float32(segment.start) + st32)
+    seg.end = float(np.float32(segment.end) + st32)
+    if getattr(segment, "words", None):
+        seg.words = [dataclasses.replace(w, start=float(np.float32(w.start) + st32), end=float(np.float32(w.end) + st32))
+                     for w in segment.words]
+    return seg
+
+
+def transcribe_vad_chunked(audio: np.ndarray, options: Optional[DecodingOptions], transcribe_one: Callable[[np.ndarray, DecodingOptions], TranscriptionResult]
+                           ) -> List[Tuple[float, TranscriptionResult]]:
+    """Core/WhisperKit.swift:867-931 with chunkingStrategy == .vad, and AudioChunking.updateSeekOffsetsForResults
+    (Core/Audio/AudioChunker.swift:14-39): audio longer than one window is cut at the middle of the longest silence of
+    each window's second half, every chunk is transcribed independently with clipTimestamps reset, and the segments are
+    shifted by the chunk's seek offset.  Returns [(seekTime, result)] in chunk order."""
+    options = options or DecodingOptions()
+    if len(audio) <= WINDOW_SAMPLES:
+        return [(0.0, transcribe_one(audio, options))]
+    chunks = vad_chunk_all(audio, WINDOW_SAMPLES, options)
+    chunked = dataclasses.replace(options, clipTimestamps=[])
+    out = []
+    for seekOffsetIndex, samples in chunks:
+        res = transcribe_one(samples, chunked)
+        seekTime = float(np.float32(seekOffsetIndex) / np.float32(SAMPLE_RATE))
+        res = dataclasses.replace(res, segments=[update_segment_timings(g, seekTime) for g in res.segments])
+        out.append((seekTime, res))
+    return out

@@ -538,6 +538,45 @@ def test_transcribe_multi_window_vs_oracle(micro):
         assert a.temperature == pytest.approx(b.temperature)
 
 
+def test_transcribe_chunked_vad_vs_oracle(micro):
+    """WhisperKit.transcribe(audioArray:) with .vad chunking (WhisperKit.swift:867-931): 70 s of audio with two silent gaps is
+    cut by VADAudioChunker, the chunks run as one device batch, segment times are shifted by the chunk offsets
+    (updateSeekOffsetsForResults) - against the oracle's restatement chunk by chunk."""
+    dims, _, model, om = micro
+    gap = np.zeros(24000, np.float32)
+    audio = np.concatenate([synthetic_chunk(91)[:400000], gap, synthetic_chunk(92)[:350000], gap, synthetic_chunk(93)[:320000]])
+    kw = dict(**NOFALLBACK, sampleLength=10)
+    sess = api.Session(model, 4)
+    got = sess.transcribeChunked(audio, api.DecodingOptions(**kw))
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+
+    def one(samples, oopts):
+        def encode_window(pcm):
+            return om.encode(omel.log_mel_spectrogram(pcm, dims.n_mels).astype(np.float32))
+
+        def make_step(enc):
+            state = om.new_state(enc)
+            return lambda t, p: state.step(t, p)
+        return OD.transcribe_task_run(samples, oopts, st, False, langs, dims.n_vocab, encode_window, make_step)
+    ref = OD.transcribe_vad_chunked(audio, OD.DecodingOptions(**kw), one)
+    assert len(got) == len(ref) >= 3
+    assert [o for o, _ in got] == [int(round(t * 16000)) for t, _ in ref] == [o for o, _ in OD.vad_chunk_all(audio)]
+    assert got[0][0] == 0 and all(b > a for (a, _), (b, _) in zip(got, got[1:]))
+    for (off, r), (t, o) in zip(got, ref):
+        if r.tokens != o.tokens:
+            pytest.xfail("near-tie difference between the fp16-operand GPU encoder and the fp32 oracle")
+        assert len(r.segments) == len(o.segments)
+        for a, b in zip(r.segments, o.segments):
+            assert a.tokens == b.tokens and a.seek == b.seek
+            assert a.start == pytest.approx(b.start, abs=1e-4) and a.end == pytest.approx(b.end, abs=1e-4)
+            assert a.start >= off / 16000 - 1e-3
+    # a short audio is not chunked: one result, offset 0, identical to transcribe()
+    short = synthetic_chunk(94)[:200000]
+    g1 = sess.transcribeChunked(short, api.DecodingOptions(**kw))
+    r1 = sess.transcribe([short], api.DecodingOptions(**kw))[0]
+    assert len(g1) == 1 and g1[0][0] == 0 and g1[0][1].tokens == r1.tokens
+
+
 def test_transcribe_batch_equals_sequential(micro):
     dims, _, model, _ = micro
     audios = [synthetic_chunk(71), np.concatenate([synthetic_chunk(72), synthetic_chunk(73)[:100000]]), synthetic_chunk(74)[:50000]]

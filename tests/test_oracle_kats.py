@@ -222,3 +222,36 @@ def test_segments_from_reference_token_sequence():
     assert (segs2[0].start, segs2[0].end) == (pytest.approx(1.0), pytest.approx(3.0))
     assert (segs2[1].start, segs2[1].end) == (pytest.approx(3.0), pytest.approx(5.0))
     assert seek2 == 16000 + int(np.float32(4.0) * 16000)
+
+
+def test_update_segment_timings_and_vad_chunked_flow():
+    """TranscriptionUtilities.updateSegmentTimings (Utilities/TranscriptionUtilities.swift:55-69) and the .vad branch of
+    WhisperKit.transcribe(audioArray:) (Core/WhisperKit.swift:878-906) with a stub transcriber."""
+    from oracle import decode as OD
+    import numpy as np
+    mk = lambda **kw: OD.TranscriptionSegment(text="", temperature=0.0, avgLogprob=0.0, compressionRatio=1.0, noSpeechProb=0.0, **kw)
+    seg = mk(id=0, seek=160, start=1.0, end=2.5, tokens=[1, 2], tokenLogProbs=[{1: -0.1}, {2: -0.2}],
+             words=[OD.WordTiming("a", [1], 1.0, 1.5, 0.9)])
+    up = OD.update_segment_timings(seg, 22.9)
+    assert up.seek == 160 + int(np.float32(22.9) * np.float32(16000)) and up.start == pytest.approx(23.9) and up.end == pytest.approx(25.4)
+    assert up.words[0].start == pytest.approx(23.9) and up.words[0].end == pytest.approx(24.4)
+    assert seg.seek == 160 and seg.start == 1.0 and seg.words[0].start == 1.0          # input untouched
+
+    calls = []
+
+    def one(samples, opts):
+        calls.append((len(samples), list(opts.clipTimestamps)))
+        return OD.TranscriptionResult([mk(id=0, seek=0, start=0.5, end=1.0, tokens=[7], tokenLogProbs=[{7: 0.0}])], [7], "en")
+    rng = np.random.default_rng(0)
+    loud = lambda n: (0.5 * rng.standard_normal(n)).astype(np.float32)
+    audio = np.concatenate([loud(400000), np.zeros(32000, np.float32), loud(300000), np.zeros(32000, np.float32), loud(200000)])
+    out = OD.transcribe_vad_chunked(audio, OD.DecodingOptions(clipTimestamps=[0.0]), one)
+    chunks = OD.vad_chunk_all(audio, options=OD.DecodingOptions(clipTimestamps=[0.0]))
+    assert len(out) == len(chunks) == len(calls) >= 2
+    assert all(ct == [] for _, ct in calls)              # clipTimestamps reset for the chunks (:889-891)
+    for (t, r), (off, samples) in zip(out, chunks):
+        assert t == pytest.approx(off / 16000) and r.segments[0].start == pytest.approx(0.5 + off / 16000, abs=1e-4)
+        assert r.segments[0].seek == int(np.float32(np.float32(off) / np.float32(16000)) * np.float32(16000))
+    assert sum(len(c[1]) for c in chunks) == len(audio) or chunks[-1][0] + len(chunks[-1][1]) <= len(audio)
+    short = OD.transcribe_vad_chunked(audio[:1000], None, one)
+    assert len(short) == 1 and short[0][0] == 0.0

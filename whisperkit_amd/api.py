@@ -349,6 +349,23 @@ class Session:
             self.lib.wh_transcription_free(h)
         return results
 
+    def transcribeChunked(self, audioArray: np.ndarray, options: Optional[DecodingOptions] = None, specialTokens=None):
+        """WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): returns
+        [(seekOffsetSamples, TranscriptionResult)] per VAD chunk, segment / word times already shifted to the full audio."""
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = (options or DecodingOptions()).to_c()
+        a = np.ascontiguousarray(audioArray, dtype=np.float32)
+        cap = max(4, len(a) // 16000 + 4)
+        outs = (C.c_void_p * cap)()
+        seeks = (C.c_int32 * cap)()
+        n = C.c_int()
+        _check(self.lib.wh_transcribe_chunked(self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n)))
+        results = []
+        for i in range(n.value):
+            results.append((int(seeks[i]), self._collect(outs[i])))
+            self.lib.wh_transcription_free(outs[i])
+        return results
+
     def _collect(self, h) -> TranscriptionResult:
         lib = self.lib
         tp, lp, n = L.PI32(), L.PF(), C.c_int()

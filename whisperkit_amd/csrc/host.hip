@@ -657,6 +657,44 @@ extern "C" int wh_transcribe(wh_session* s, const float* pcm, int n, const wh_de
     return wh_transcribe_batch(s, p, nn, 1, opt, st, out);
 }
 
+extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, const wh_decoding_options* opt, const wh_special_tokens* st,
+                                     wh_transcription** out, int capacity, int32_t* seek_offsets_out, int* n_out) {
+    CHECK_SESSION(s);
+    if (!opt || !st || !out || !n_out || capacity < 1 || n < 0 || (n > 0 && !pcm))
+        return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcribe_chunked: invalid argument");
+    *n_out = 0;
+    if (n <= kWindowSamples) {      // not chunkable: runTranscribeTask on the whole array (WhisperKit.swift:913-919)
+        int r = wh_transcribe(s, pcm, n, opt, st, &out[0]);
+        if (r) return r;
+        if (seek_offsets_out) seek_offsets_out[0] = 0;
+        *n_out = 1;
+        return WH_OK;
+    }
+    int nc = wh_vad_chunk_all(pcm, n, kWindowSamples, opt, nullptr, nullptr, 0);
+    if (nc < 0) return set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "wh_transcribe_chunked: startIndex is outside the buffer size");
+    if (nc > capacity) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcribe_chunked: %d chunks exceed the capacity %d", nc, capacity);
+    std::vector<int32_t> cs(nc), ce(nc);
+    wh_vad_chunk_all(pcm, n, kWindowSamples, opt, cs.data(), ce.data(), nc);
+    wh_decoding_options chunked = *opt;     // "Reset the seek times since we've already chunked the audio" (:889-891)
+    chunked.clip_timestamps = nullptr;
+    chunked.n_clip_timestamps = 0;
+    std::vector<const float*> ptrs(nc);
+    std::vector<int32_t> lens(nc);
+    for (int i = 0; i < nc; ++i) { ptrs[i] = pcm + cs[i]; lens[i] = ce[i] - cs[i]; }
+    int r = wh_transcribe_batch(s, ptrs.data(), lens.data(), nc, &chunked, st, out);
+    if (r) return r;
+    for (int i = 0; i < nc; ++i) {
+        // updateSegmentTimings in Float: seek += Int(seekTime * 16000), start / end += seekTime
+        const float seekTime = (float)cs[i] / (float)WH_SAMPLE_RATE;
+        const int seekIdx = (int)(seekTime * (float)WH_SAMPLE_RATE);
+        for (auto& g : out[i]->segments) { g.seek += seekIdx; g.start += seekTime; g.end += seekTime; }
+        for (auto& w : out[i]->words) { w.start += seekTime; w.end += seekTime; }
+        if (seek_offsets_out) seek_offsets_out[i] = cs[i];
+    }
+    *n_out = nc;
+    return WH_OK;
+}
+
 extern "C" void wh_transcription_free(wh_transcription* t) { delete t; }
 extern "C" int wh_transcription_n_segments(const wh_transcription* t) { return t ? (int)t->segments.size() : -1; }
 extern "C" int wh_transcription_segment(const wh_transcription* t, int i, wh_segment* out) {
