@@ -529,7 +529,7 @@ def test_transcribe_multi_window_vs_oracle(micro):
     ores = OD.transcribe_task_run(audio, OD.DecodingOptions(**okw), st, False, langs, dims.n_vocab, encode_window, make_step, seed=seed)
     assert res.seeks == ores.seeks
     assert len(res.seeks) == 3 and res.timings["total_decoding_fallbacks"] == 3     # every window falls back once
-    if res.tokens != ores.tokens:
+    if [t for g in res.segments for t in g.tokens] != ores.tokens:      # oracle result tokens = concatenated segment tokens
         pytest.xfail("near-tie / top-5 boundary difference between the fp16-operand GPU encoder and the fp32 oracle")
     assert [s.id for s in res.segments] == [s.id for s in ores.segments]
     for a, b in zip(res.segments, ores.segments):
@@ -550,21 +550,36 @@ def test_transcribe_chunked_vad_vs_oracle(micro):
     got = sess.transcribeChunked(audio, api.DecodingOptions(**kw))
     st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
 
+    s_enc = api.Session(model, 1)
+
     def one(samples, oopts):
         def encode_window(pcm):
-            return om.encode(omel.log_mel_spectrogram(pcm, dims.n_mels).astype(np.float32))
+            # the oracle decodes from the GPU's encoder output (stage isolation, as in test_decode_text_greedy_vs_oracle):
+            # the restated window / seek / segment logic is what this test pins, not the fp16-vs-fp32 encoder rounding
+            s_enc.padOrTrim(pcm); s_enc.logMelSpectrogram(1); s_enc.encodeFeatures(1)
+            return s_enc.getEncoderOutput(0)
 
         def make_step(enc):
-            state = om.new_state(enc)
+            state = om.new_state(enc.astype(np.float16).astype(np.float32))     # the cross-K/V GEMM reads fp16 operands
             return lambda t, p: state.step(t, p)
         return OD.transcribe_task_run(samples, oopts, st, False, langs, dims.n_vocab, encode_window, make_step)
     ref = OD.transcribe_vad_chunked(audio, OD.DecodingOptions(**kw), one)
     assert len(got) == len(ref) >= 3
     assert [o for o, _ in got] == [int(round(t * 16000)) for t, _ in ref] == [o for o, _ in OD.vad_chunk_all(audio)]
     assert got[0][0] == 0 and all(b > a for (a, _), (b, _) in zip(got, got[1:]))
+    # exact: every chunk of the batched call == the same samples transcribed alone, shifted by the chunk offset
+    s1 = api.Session(model, 1)
+    for (off, r), (_, samples) in zip(got, OD.vad_chunk_all(audio)):
+        alone = s1.transcribe([samples], api.DecodingOptions(**kw))[0]
+        assert r.tokens == alone.tokens and len(r.segments) == len(alone.segments)
+        seek_time = np.float32(off) / np.float32(16000)
+        for a, b in zip(r.segments, alone.segments):
+            assert a.tokens == b.tokens and a.seek == b.seek + int(seek_time * np.float32(16000))
+            assert a.start == float(np.float32(b.start) + seek_time) and a.end == float(np.float32(b.end) + seek_time)
     for (off, r), (t, o) in zip(got, ref):
-        if r.tokens != o.tokens:
-            pytest.xfail("near-tie difference between the fp16-operand GPU encoder and the fp32 oracle")
+        seg_tokens = [t for g in r.segments for t in g.tokens]
+        if seg_tokens != o.tokens:
+            pytest.xfail(f"token difference vs the fp32 oracle in chunk at {off}: {seg_tokens} vs {o.tokens} (seeks {r.seeks} vs {o.seeks})")
         assert len(r.segments) == len(o.segments)
         for a, b in zip(r.segments, o.segments):
             assert a.tokens == b.tokens and a.seek == b.seek
