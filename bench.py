@@ -200,7 +200,8 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
                 t.join()
             if errs:
                 raise errs[0]
-        gathered = [parallel.gather_records(recs, B, device=dev if world > 1 else None) for _, recs in out]
+        gdev = dev if (world > 1 and args.dist_backend == "nccl") else None
+        gathered = [parallel.gather_records(recs, B, device=gdev) for _, recs in out]
         return out[-1][0], gathered[-1]
 
     def fence():
@@ -219,7 +220,7 @@ def run_config(args, model_name, B, steps, warmup, world, rank, local_rank, dev,
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert len(allrecs) == world * B, (len(allrecs), world, B)
@@ -311,6 +312,9 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -327,11 +331,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the whisperhip product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     main_cfg = run_config(args, args.model, args.batch, args.steps, args.warmup, world, rank, local_rank, dev,
                           want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline))

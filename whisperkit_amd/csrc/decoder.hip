@@ -243,11 +243,21 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     const int KS = a.k_split, RG = NW / KS;
     const int ks = wave % KS, rg = wave / KS;
     const int KC = K / KS, kbase = ks * KC;
-    bool any_live = false;
+    // Slot liveness is LOADED here but only LOOKED AT after the activation and weight loads have been issued (LIVE_CHECK):
+    // a test right away would put one more dependent L2 round trip in front of every kernel of the chain.
+    int s_act[BT], s_done[BT];
 #pragma unroll
-    for (int i = 0; i < BT; ++i)
-        if (b0 + i < a.batch) any_live |= slot_live(&a.seq[b0 + i]);
-    if (!any_live) return;
+    for (int i = 0; i < BT; ++i) {
+        const bool in = b0 + i < a.batch;
+        s_act[i] = in ? a.seq[b0 + i].active : 0;
+        s_done[i] = in ? a.seq[b0 + i].done : 1;
+    }
+#define LIVE_CHECK()                                                          \
+    do {                                                                      \
+        bool any_live_ = false;                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < BT; ++i_) any_live_ |= (s_act[i_] && !s_done[i_]); \
+        if (!any_live_) return;                                               \
+    } while (0)
     DBG_STAMP(6);
 
     const int n_begin = blockIdx.x * a.rows_per_block;
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
                                  ? *reinterpret_cast<const uint4*>(a.hbuf + (size_t)(b0 + b) * K + kbase + lane * 8 + 512 * i) : uint4{0, 0, 0, 0};
         load_group(cur, n_begin + rg * R);
         DBG_STAMP(1);
+        LIVE_CHECK();
     } else if constexpr (MODE == MODE_RESID) {
         constexpr int AV = (BT * 320 + NT - 1) / NT;    // float4 per thread, d <= 1280
         float4 areg[AV];
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         }
         load_group(cur, n_begin + rg * R);
         DBG_STAMP(1);
+        LIVE_CHECK();
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int idx = tid + i * NT;
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         }
         load_group(cur, n_begin + rg * R);
         DBG_STAMP(1);
+        LIVE_CHECK();
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int idx = tid + i * NT;
@@ -399,6 +412,18 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         uint4 nxt[kPrefetchNextPass ? R : 1][kPrefetchNextPass ? KI : 1];
         if constexpr (kPrefetchNextPass) {
             if (p + 1 < n_pass) load_group(nxt, n_begin + ((p + 1) * RG + rg) * R);
+        }
+        // epilogue operands of this lane's output (bias, residual value, cache position): fetched now, used after the FMAs
+        constexpr int SHp = (NV == 32) ? 1 : (NV == 16) ? 2 : (NV == 8) ? 3 : (NV == 4) ? 4 : (NV == 2) ? 5 : 6;
+        const int idx_p = lane >> SHp;
+        const int n_l = n0 + idx_p / BT, gb_l = b0 + idx_p % BT;
+        const bool out_l = ks == 0 && (lane & ((1 << SHp) - 1)) == 0 && n_l < n_end && gb_l < a.batch;
+        float bias_l = 0.0f, xold_l = 0.0f;
+        int pos_l = 0;
+        if (out_l) {
+            if (a.bias) bias_l = a.bias[n_l];
+            if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) xold_l = a.x[(size_t)gb_l * d + n_l];
+            if constexpr (MODE == MODE_QKV) pos_l = a.seq[gb_l].token_index;
         }
         float acc[NV];
 #pragma unroll
@@ -456,9 +481,9 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
             const int r = idx / BT, b = idx - r * BT;
             const int n = n0 + r, gb = b0 + b;
             if (n < n_end && gb < a.batch) {
-                float v = tot + (a.bias ? a.bias[n] : 0.0f);
+                float v = tot + bias_l;
                 if constexpr (MODE == MODE_QKV) {
-                    int pos = min(max(a.seq[gb].token_index, 0), kMaxTok - 1);
+                    int pos = min(max(pos_l, 0), kMaxTok - 1);
                     if (n < d) a.q[(size_t)gb * d + n] = v;
                     else {
                         int c = n - d;
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
                 } else if constexpr (MODE == MODE_FC1) {
                     a.hbuf[(size_t)gb * a.N + n] = (f16)gelu_erf(v);
                 } else if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) {
-                    a.x[(size_t)gb * d + n] += v;
+                    a.x[(size_t)gb * d + n] = xold_l + v;
                 } else {
                     a.logits[(size_t)gb * a.N + n] = v;
                     if (a.stats) lt[b * 64 + (n - n_begin)] = v;
@@ -514,30 +539,34 @@ struct AttnArgs {
 // key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
 // before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
 // o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
-template <int PASSES>
-__device__ __forceinline__ void attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n,
-                                             float* __restrict__ raw_scores, float* red /* [16] */, float* osum /* [4][64] */,
+template <int PASSES, typename GetN>
+__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
+                                             GetN get_n, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
                                              float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
+    // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
+    // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int part = tid & 7, kg = tid >> 3;
     uint4 kreg[PASSES], vreg[PASSES];
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = kg + 32 * i;
-        kreg[i] = key < n ? *reinterpret_cast<const uint4*>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        kreg[i] = key < n_load ? *reinterpret_cast<const uint4*>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = kg + 32 * i;
-        vreg[i] = key < n ? *reinterpret_cast<const uint4*>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        vreg[i] = key < n_load ? *reinterpret_cast<const uint4*>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
-    if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
     float qv[8];
     {
         float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
         float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
         qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
     }
+    const int n = get_n();
+    if (n < 0) return false;            // workgroup-uniform
+    float* raw_scores = *raw_pp;
     float s[PASSES];
     float lmax = -INFINITY;
 #pragma unroll
@@ -567,8 +596,10 @@ __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        const float p = (kg + 32 * i < n) ? __expf(s[i] - m) : 0.0f;
+        const bool valid = kg + 32 * i < n;
+        const float p = valid ? __expf(s[i] - m) : 0.0f;
         if (part == 0) lsum += p;
+        if (!valid) vreg[i] = uint4{0, 0, 0, 0};          // rows past n were fetched speculatively: keep 0 * garbage out
         f16x8 v8 = *reinterpret_cast<f16x8*>(&vreg[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
@@ -592,17 +623,21 @@ __device__ __forceinline__ void attend_block(const float* __restrict__ qg, const
     if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
     *m_out = m;
     *l_out = (red[4] + red[5]) + (red[6] + red[7]);
+    return true;
 }
 
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     __shared__ float red[16], osum[256], o_l[64];
     const int h = blockIdx.x, b = blockIdx.y;
-    if (!slot_live(&a.seq[b])) return;
-    const int pos = min(max(a.seq[b].token_index, 0), kMaxTok - 1);
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
     const int d = a.d;
     const size_t base = ((size_t)b * a.n_head + h) * kMaxTok * kHeadDim;
     float m, l;
-    attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, pos + 1, nullptr, red, osum, o_l, &m, &l);
+    float* raw = nullptr;
+    auto get_n = [&]() { return (s_act && !s_done) ? min(max(s_ti, 0), kMaxTok - 1) + 1 : -1; };
+    if (!attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, kMaxTok, get_n, &raw, red, osum, o_l, &m, &l))
+        return;
     if (threadIdx.x < 64) a.att[(size_t)b * d + h * kHeadDim + threadIdx.x] = o_l[threadIdx.x] / l;
 }
 
@@ -612,22 +647,27 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     __shared__ float red[16], osum[256], o_l[64];
     __shared__ int last_flag;
     const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    if (!slot_live(&a.seq[b])) return;
-    const int pos = min(max(a.seq[b].token_index, 0), kMaxTok - 1);
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
     const int d = a.d, S = a.n_split;
     const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
     const size_t base = (((size_t)b * a.n_head + h) * kCtx + t0) * kHeadDim;
-    // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296), raw scores here,
-    // softmax + head mean in alignment_mean_kernel
-    float* raw = nullptr;
-    if (a.align) {
-        int slot = a.align_slot[a.layer * a.n_head + h];
-        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
-    }
+    int slot = -1;
+    if (a.align) slot = a.align_slot[a.layer * a.n_head + h];
     float m, l;
     ATT_STAMP(0);
     unsigned long long* stamp = a.dbg ? a.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 : nullptr;
-    attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, raw, red, osum, o_l, &m, &l, stamp);
+    // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296), raw scores here,
+    // softmax + head mean in alignment_mean_kernel
+    float* raw = nullptr;
+    auto get_n = [&]() {
+        if (!(s_act && !s_done)) return -1;
+        const int pos = min(max(s_ti, 0), kMaxTok - 1);
+        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
+        return n;
+    };
+    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, &raw, red, osum, o_l, &m, &l, stamp))
+        return;
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
     float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
@@ -651,18 +691,35 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     __syncthreads();
     ATT_STAMP(4);
     if (last_flag && tid == 0 && a.dbg) stamp[6] = 1;
-    if (last_flag && tid < 64) {
+    if (last_flag) {      // workgroup-uniform
+        // all S partials (S x 66 floats) are fetched by the whole workgroup in ONE round of independent sc1 loads into LDS
+        // (a per-thread loop over the splits is S dependent L2 round trips: 24 us at S = 24) and combined from there
+        __shared__ float pl[kMaxSplit * 66];
         const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
-        float mg = -INFINITY;
-        auto ld = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // sc1: L1 bypass
-        for (int i = 0; i < S; ++i) mg = fmaxf(mg, ld(p0 + i * kPartStride));
-        float lg = 0.0f, og = 0.0f;
-        for (int i = 0; i < S; ++i) {
-            const float w = __expf(ld(p0 + i * kPartStride) - mg);
-            lg = fmaf(w, ld(p0 + i * kPartStride + 1), lg);
-            og = fmaf(w, ld(p0 + i * kPartStride + 2 + tid), og);
+        constexpr int NLD = (kMaxSplit * 66 + 255) / 256;
+        float tmp[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {         // issue every load before the first use
+            const int i = tid + 256 * k, sp_i = i / 66, e = i - sp_i * 66;
+            tmp[k] = i < S * 66 ? __hip_atomic_load(p0 + sp_i * kPartStride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;   // sc1
         }
-        a.att[(size_t)b * d + h * kHeadDim + tid] = og / lg;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S * 66) pl[i] = tmp[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float mg = -INFINITY;
+            for (int i = 0; i < S; ++i) mg = fmaxf(mg, pl[i * 66]);
+            float lg = 0.0f, og = 0.0f;
+            for (int i = 0; i < S; ++i) {
+                const float w = __expf(pl[i * 66] - mg);
+                lg = fmaf(w, pl[i * 66 + 1], lg);
+                og = fmaf(w, pl[i * 66 + 2 + tid], og);
+            }
+            a.att[(size_t)b * d + h * kHeadDim + tid] = og / lg;
+        }
     }
     ATT_STAMP(5);
 }
@@ -943,12 +1000,22 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
     constexpr int kWords = sizeof(SeqState) / 4;
     for (int i = tid; i < kWords; i += 256) reinterpret_cast<int*>(&sq_l)[i] = reinterpret_cast<const int*>(sq)[i];
     SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
-    for (int i = tid; i < nblk; i += 256) {
-        const float* e = stats + ((size_t)b * kStatBlocks + i) * 8;
-        const float4 lo = *reinterpret_cast<const float4*>(e);
-        const float2 hi = *reinterpret_cast<const float2*>(e + 4);
-        stat_merge(t, lo.x, lo.y, __float_as_int(lo.z));
-        stat_merge(u, lo.w, hi.x, __float_as_int(hi.y));
+    constexpr int NR = kStatBlocks / 256;      // records per thread: all loads are issued before the first merge (one L2 round
+    float4 lo[NR];                             // trip instead of NR dependent ones)
+    float2 hi[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int i = tid + 256 * k;
+        const float* e = stats + ((size_t)b * kStatBlocks + min(i, nblk - 1)) * 8;
+        lo[k] = *reinterpret_cast<const float4*>(e);
+        hi[k] = *reinterpret_cast<const float2*>(e + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (tid + 256 * k < nblk) {
+            stat_merge(t, lo[k].x, lo[k].y, __float_as_int(lo[k].z));
+            stat_merge(u, lo[k].w, hi[k].x, __float_as_int(hi[k].y));
+        }
     }
     stat_wave_reduce(t);
     stat_wave_reduce(u);
