@@ -258,6 +258,28 @@ def test_decode_text_batch_above_one_batch_tile(micro):
         np.testing.assert_array_equal(sb.getEncoderOutput(b), s1.getEncoderOutput(0))
 
 
+def test_decode_is_bit_reproducible_across_repeats(micro):
+    """Race screen for the cross-workgroup hand-offs of the decoder (split cross-attention + ticket combine): the same batch
+    decoded to the length cap twelve times must give identical tokens and log-probs every time."""
+    dims, _, model, _ = micro
+    B = 5
+    sess = api.Session(model, B)
+    for b in range(B):
+        sess.padOrTrim(synthetic_chunk(700 + b), b)
+    sess.logMelSpectrogram(B); sess.encodeFeatures(B); sess.prepareDecoderInputs(B)
+    opts = api.DecodingOptions(**NOFALLBACK)
+    prompt = sess.prefillPrompt(opts)
+    first = None
+    for rep in range(12):
+        sess.resetDecoderInputs(B)
+        r = sess.decodeText(prompt, opts, batch=B)
+        sig = [(x.tokens, x.tokenLogProbs) for x in r]
+        assert r[0].steps == 223
+        if first is None:
+            first = sig
+        assert sig == first, f"repeat {rep} differs"
+
+
 def test_fused_greedy_sampler_equals_reference_sampler_kernel(micro_ml, monkeypatch):
     """The fused greedy path (filters + softmax statistics in the logits epilogue + sampler_final_kernel) against the
     one-workgroup sampler kernel that restates LogitsFilter.swift / TokenSampler.swift element by element."""

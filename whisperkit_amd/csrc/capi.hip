@@ -307,6 +307,9 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
     (void)wh::debug_buffer();   // WH_DBG=1 probe buffer must exist before any stream capture
+    // the zero-fills above ran on the NULL stream, which does not order against the session's non-blocking stream: make sure
+    // they are done before the first kernel (a late memset of e.g. the arrival counters would corrupt a running decode)
+    if (hipDeviceSynchronize() != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipDeviceSynchronize failed after session allocation"); }
     *out = s;
     return WH_OK;
 }

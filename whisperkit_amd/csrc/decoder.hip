@@ -683,9 +683,13 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         int* cnt = a.ticket + b * a.n_head + h;
         int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int last = (t == S - 1);
-        // no acquire fence: the partials were stored write-through (sc1) and are read back with sc1 loads (L1 bypass), the
-        // form MI355X_MICROARCH.md lists as sufficient; an agent acquire (buffer_inv sc1) costs ~1.7 us on the critical tail
-        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        if (last) {
+            // agent-scope acquire on the combining CU: the partial slots are rewritten by every layer's launch, and a copy
+            // left in this XCD's L2 by an earlier combine must not be served to the sc1 loads below (the recipe of
+            // MI355X_MICROARCH.md: one relaxed ticket, one agent acquire; it is not measurable in the step time)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
         last_flag = last;
     }
     __syncthreads();
