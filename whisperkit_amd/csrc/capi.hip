@@ -72,18 +72,32 @@ static int build_mel_tables(wh_model* m) {
         if (hi < lo) { lo = 0; hi = -1; }
         rng[j] = int2{lo, hi};
     }
-    size_t bytes = (2 * nb + nf) * sizeof(float) + n_mels * sizeof(int2);
+    // compact non-zero weights per filter (<= 2 filters overlap a bin, so <= ~2 * 201 values): the kernel keeps them in LDS
+    std::vector<float> fc;
+    std::vector<int> foff(n_mels);
+    for (int j = 0; j < n_mels; ++j) {
+        foff[j] = (int)fc.size();
+        for (int k = rng[j].x; k <= rng[j].y; ++k) fc.push_back(filt[(size_t)k * n_mels + j]);
+    }
+    if (fc.size() > 1024) return set_error(WH_ERR_MODELS_UNAVAILABLE, "mel filterbank has %zu non-zeros (> 1024)", fc.size());
+    const size_t o_filt = 2 * nb * 4, o_rng = o_filt + nf * 4, o_fc = o_rng + n_mels * sizeof(int2), o_foff = o_fc + fc.size() * 4;
+    size_t bytes = o_foff + n_mels * sizeof(int);
     char* dev = nullptr;
     WH_HIP(hipMalloc((void**)&dev, bytes));
     m->mel_tables_dev = dev;
     WH_HIP(hipMemcpy(dev, bc.data(), nb * 4, hipMemcpyHostToDevice));
     WH_HIP(hipMemcpy(dev + nb * 4, bs.data(), nb * 4, hipMemcpyHostToDevice));
-    WH_HIP(hipMemcpy(dev + 2 * nb * 4, filt.data(), nf * 4, hipMemcpyHostToDevice));
-    WH_HIP(hipMemcpy(dev + 2 * nb * 4 + nf * 4, rng.data(), n_mels * sizeof(int2), hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + o_filt, filt.data(), nf * 4, hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + o_rng, rng.data(), n_mels * sizeof(int2), hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + o_fc, fc.data(), fc.size() * 4, hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(dev + o_foff, foff.data(), n_mels * sizeof(int), hipMemcpyHostToDevice));
     m->mel.basis_c = (const float*)dev;
     m->mel.basis_s = (const float*)(dev + nb * 4);
-    m->mel.filt = (const float*)(dev + 2 * nb * 4);
-    m->mel.filt_range = (const int2*)(dev + 2 * nb * 4 + nf * 4);
+    m->mel.filt = (const float*)(dev + o_filt);
+    m->mel.filt_range = (const int2*)(dev + o_rng);
+    m->mel.filt_c = (const float*)(dev + o_fc);
+    m->mel.filt_off = (const int*)(dev + o_foff);
+    m->mel.filt_nnz = (int)fc.size();
     m->mel.n_mels = n_mels;
     return WH_OK;
 }

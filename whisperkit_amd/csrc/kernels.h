@@ -35,6 +35,9 @@ struct MelTables {
     const float* basis_s;   // [200][208] w[n] sin(2 pi n k / 400)
     const float* filt;      // [201][n_mels] slaney mel filterbank
     const int2* filt_range; // [n_mels] first / last non-zero bin
+    const float* filt_c;    // compact non-zero weights, filter m at [filt_off[m], filt_off[m] + last - first]
+    const int* filt_off;    // [n_mels]
+    int filt_nnz;
     int n_mels;
 };
 

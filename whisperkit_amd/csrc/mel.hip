@@ -4,7 +4,7 @@
 // Algorithm (openai/whisper audio.py): reflect pad 200, hann(400) STFT hop 160 -> |X|^2 (201 bins)
 // -> slaney mel filterbank -> log10(max(.,1e-10)) -> max(., global_max - 8) -> (x + 4) / 4.
 //
-// Kernel 1 (mel_power_kernel): one workgroup = 16 frames.  The 400-point real DFT is evaluated as two
+// Kernel 1 (mel_power_kernel): one workgroup = 64 frames (4 groups of 16 sharing every basis fragment).  The 400-point real DFT is evaluated as two
 // K=200 real GEMMs on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chain):
 //     Re X[k] = sum_{n=1..200} (x[n] + x[400-n]) * w[n] cos(2 pi n k / 400)      (x[200] counted once)
 //     Im X[k] = sum_{n=1..199} (x[n] - x[400-n]) * w[n] sin(2 pi n k / 400)
@@ -30,22 +30,31 @@ __device__ __forceinline__ float load_padded(const float* __restrict__ pcm, int 
     return p < n_valid ? pcm[p] : 0.0f;
 }
 
+constexpr int FG = 4;      // 16-frame groups per workgroup: every basis fragment fetched from L2 feeds FG MFMAs
+
 __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ pcm_all, const int* __restrict__ n_valid_all,
                                                         const float* __restrict__ basis_c, const float* __restrict__ basis_s,
-                                                        const float* __restrict__ filt, const int2* __restrict__ filt_range,
+                                                        const float* __restrict__ filt_c, const int* __restrict__ filt_off, int filt_nnz,
+                                                        const int2* __restrict__ filt_range,
                                                         int n_mels, float* __restrict__ logspec, unsigned* __restrict__ maxkey) {
-    __shared__ float fe[16 * LDA];
-    __shared__ float fo[16 * LDA];
-    __shared__ float pw[16 * LDP];
+    extern __shared__ __attribute__((aligned(16))) float mel_smem[];
+    float* fe = mel_smem;                        // [FG*16][LDA] even folds
+    float* fo = fe + FG * 16 * LDA;              // [FG*16][LDA] odd folds
+    float* pw = fo + FG * 16 * LDA;              // [16][LDP]    power of one frame group at a time
     __shared__ float red[4];
+    __shared__ float fc_l[1024];                 // compact mel filter weights (a global-memory filter loop is a chain of
+    __shared__ int2 rg_l[128];                   // dependent L2 round trips: it was the whole kernel time)
+    __shared__ int fo_l[128];
+    for (int i = threadIdx.x; i < filt_nnz; i += 256) fc_l[i] = filt_c[i];
+    for (int i = threadIdx.x; i < n_mels; i += 256) { rg_l[i] = filt_range[i]; fo_l[i] = filt_off[i]; }
     const int b = blockIdx.y;
-    const int f0 = blockIdx.x * 16;
+    const int f0 = blockIdx.x * (16 * FG);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pcm = pcm_all + (size_t)b * kWindowSamples;
     const int n_valid = n_valid_all[b];
 
-    // fold the 16 frames: fe[i][m] = x[n] + x[400-n], fo[i][m] = x[n] - x[400-n], n = m + 1
-    for (int idx = tid; idx < 16 * 200; idx += 256) {
+    // fold the 64 frames: fe[i][m] = x[n] + x[400-n], fo[i][m] = x[n] - x[400-n], n = m + 1
+    for (int idx = tid; idx < FG * 16 * 200; idx += 256) {
         int i = idx / 200, m = idx - i * 200;
         int n = m + 1;
         int base = (f0 + i) * kHop;
@@ -57,16 +66,19 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    f32x4 acc_re[4], acc_im[4];
+    f32x4 acc_re[FG][4], acc_im[FG][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc_re[t] = f32x4{0, 0, 0, 0}; acc_im[t] = f32x4{0, 0, 0, 0}; }
+    for (int g = 0; g < FG; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc_re[g][t] = f32x4{0, 0, 0, 0}; acc_im[g][t] = f32x4{0, 0, 0, 0}; }
     const int ai = lane & 15, ak = lane >> 4;
     // wave w owns bin tiles w, w+4, w+8, w+12 (13 tiles of 16 bins)
 #pragma unroll 2
     for (int ks = 0; ks < 50; ++ks) {
         int k = ks * 4 + ak;
-        float a_e = fe[ai * LDA + k];
-        float a_o = fo[ai * LDA + k];
+        float a_e[FG], a_o[FG];
+#pragma unroll
+        for (int g = 0; g < FG; ++g) { a_e[g] = fe[(g * 16 + ai) * LDA + k]; a_o[g] = fo[(g * 16 + ai) * LDA + k]; }
         const float* bc = basis_c + (size_t)k * kBinsPad + ai;
         const float* bs = basis_s + (size_t)k * kBinsPad + ai;
 #pragma unroll
@@ -75,38 +87,45 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
             if (tile < 13) {
                 float b_c = bc[tile * 16];
                 float b_s = bs[tile * 16];
-                acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e, b_c, acc_re[t], 0, 0, 0);
-                acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, b_s, acc_im[t], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < FG; ++g) {
+                    acc_re[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_e[g], b_c, acc_re[g][t], 0, 0, 0);
+                    acc_im[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o[g], b_s, acc_im[g][t], 0, 0, 0);
+                }
             }
         }
     }
-    // C layout 16x16: col = lane & 15 (bin), row = (lane >> 4) * 4 + r (frame)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        int tile = wave + 4 * t;
-        if (tile < 13) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int i = ak * 4 + r;
-                float re = acc_re[t][r], im = acc_im[t][r];
-                pw[i * LDP + tile * 16 + ai] = re * re + im * im;
-            }
-        }
-    }
-    __syncthreads();
-
     float lmax = -INFINITY;
-    for (int idx = tid; idx < 16 * n_mels; idx += 256) {
-        int i = idx & 15, m = idx >> 4;
-        int f = f0 + i;
-        int2 rg = filt_range[m];
-        float v = 0.0f;
-        for (int bin = rg.x; bin <= rg.y; ++bin) v = fmaf(pw[i * LDP + bin], filt[bin * n_mels + m], v);
-        float lg = log10f(fmaxf(v, 1e-10f));
-        if (f < kFrames) {
-            logspec[((size_t)b * n_mels + m) * kFrames + f] = lg;
-            lmax = fmaxf(lmax, lg);
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {
+        // C layout 16x16: col = lane & 15 (bin), row = (lane >> 4) * 4 + r (frame)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int tile = wave + 4 * t;
+            if (tile < 13) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int i = ak * 4 + r;
+                    float re = acc_re[g][t][r], im = acc_im[g][t][r];
+                    pw[i * LDP + tile * 16 + ai] = re * re + im * im;
+                }
+            }
         }
+        __syncthreads();
+        for (int idx = tid; idx < 16 * n_mels; idx += 256) {
+            int i = idx & 15, m = idx >> 4;
+            int f = f0 + g * 16 + i;
+            const int2 rg = rg_l[m];
+            const float* fw = fc_l + fo_l[m] - rg.x;
+            float v = 0.0f;
+            for (int bin = rg.x; bin <= rg.y; ++bin) v = fmaf(pw[i * LDP + bin], fw[bin], v);
+            float lg = log10f(fmaxf(v, 1e-10f));
+            if (f < kFrames) {
+                logspec[((size_t)b * n_mels + m) * kFrames + f] = lg;
+                lmax = fmaxf(lmax, lg);
+            }
+        }
+        __syncthreads();
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
@@ -156,8 +175,11 @@ __global__ void mel_import_kernel(const float* __restrict__ mel_f32, int n_mels,
 void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, int batch, float* logspec, unsigned* maxkey,
                     f16* mel_t, float* mel_f32, hipStream_t st) {
     hipMemsetAsync(maxkey, 0, sizeof(unsigned) * batch, st);
-    dim3 g1((kFrames + 15) / 16, batch);
-    { ProfScope ps_(KK_MEL_POWER, st); mel_power_kernel<<<g1, 256, 0, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt, t.filt_range, t.n_mels, logspec, maxkey); }
+    dim3 g1((kFrames + 16 * FG - 1) / (16 * FG), batch);
+    const size_t smem1 = (size_t)(2 * FG * 16 * LDA + 16 * LDP) * sizeof(float);   // 116.8 KB
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1); raised = true; }
+    { ProfScope ps_(KK_MEL_POWER, st); mel_power_kernel<<<g1, 256, smem1, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt_c, t.filt_off, t.filt_nnz, t.filt_range, t.n_mels, logspec, maxkey); }
     dim3 g2((kFrames + 63) / 64, batch);
     { ProfScope ps_(KK_MEL_FINALIZE, st); mel_finalize_kernel<<<g2, 256, t.n_mels * 65 * sizeof(float), st>>>(logspec, maxkey, t.n_mels, mel_t, mel_f32); }
 }
