@@ -696,6 +696,74 @@ def merge_punctuations(alignment: List[WordTiming], prepended: str = "\"'“¡¿
     return [w for w in app if w.word != "" and not (w.word in appended) and not (w.word in prepended)]
 
 
+def update_segments_with_word_timings(segments: List[TranscriptionSegment], mergedAlignment: List[WordTiming], seek: int,
+                                      lastSpeechTimestamp: float, constrainedMedianDuration: float, maxDuration: float,
+                                      specialTokenBegin: int, decode_fn: Optional[Callable[[List[int]], str]] = None
+                                      ) -> List[TranscriptionSegment]:
+    """Core/Text/SegmentSeeker.swift:528-659 (Float arithmetic; `.rounded(2)` = _rounded).  `decode_fn` stands in for
+    tokenizer.decode when a merged word loses special tokens (:552-554)."""
+    f = np.float32
+    timeOffset = f(seek) / f(SAMPLE_RATE)
+    cmd, mx = f(constrainedMedianDuration), f(maxDuration)
+    lastSpeech = f(lastSpeechTimestamp)
+    wordIndex = 0
+    updated: List[TranscriptionSegment] = []
+    for segmentIndex, segment in enumerate(segments):
+        savedTokens = 0
+        textTokens = [t for t in segment.tokens if t < specialTokenBegin]
+        words: List[WordTiming] = []
+        while wordIndex < len(mergedAlignment) and savedTokens < len(textTokens):
+            timing = mergedAlignment[wordIndex]
+            wordIndex += 1
+            timingTokens = [t for t in timing.tokens if t < specialTokenBegin]
+            if not timingTokens:
+                continue
+            if len(timingTokens) < len(timing.tokens):
+                if decode_fn is None:
+                    raise ValueError("a merged word lost special tokens: decode_fn (tokenizer.decode) is required")
+                word = decode_fn(timingTokens)
+            else:
+                word = timing.word
+            start = f(_rounded(float(timeOffset + f(timing.start)), 2))
+            end = f(_rounded(float(timeOffset + f(timing.end)), 2))
+            if end - start < cmd / f(4):
+                if words:
+                    previousEnd = f(words[-1].end)
+                    if start > previousEnd:
+                        desired = min(start - previousEnd, cmd / f(2))
+                        start = f(_rounded(float(start - desired), 2))
+                elif segmentIndex > 0 and len(updated) > segmentIndex - 1 and start > f(updated[segmentIndex - 1].end):
+                    desired = min(start - f(updated[segmentIndex - 1].end), cmd / f(2))
+                    start = f(_rounded(float(start - desired), 2))
+            words.append(WordTiming(word, timingTokens, float(start), float(end), _rounded(timing.probability, 2)))
+            savedTokens += len(timingTokens)
+        seg = dataclasses.replace(segment)
+        if words:
+            first = words[0]
+            pauseLength = f(first.end) - lastSpeech
+            firstWordTooLong = f(first.duration) > mx
+            bothWordsTooLong = len(words) > 1 and f(words[1].end) - f(first.start) > mx * f(2)
+            if pauseLength > cmd * f(4) and (firstWordTooLong or bothWordsTooLong):
+                if len(words) > 1 and f(words[1].duration) > mx:
+                    boundary = max(f(words[1].end) / f(2), f(words[1].end) - mx)
+                    words[0].end = float(boundary)
+                    words[1].start = float(boundary)
+                words[0].start = float(max(lastSpeech, f(words[0].end) - mx))
+            if f(segment.start) < f(words[0].end) and f(segment.start) - f(0.5) > f(words[0].start):
+                words[0].start = float(max(f(0), min(f(words[0].end) - cmd, f(segment.start))))
+            else:
+                seg.start = words[0].start
+            last = words[-1]
+            if f(seg.end) > f(last.start) and f(segment.end) + f(0.5) < f(last.end):
+                words[-1].end = float(max(f(last.start) + cmd, f(segment.end)))
+            else:
+                seg.end = last.end
+            lastSpeech = f(seg.end)
+        seg.words = words
+        updated.append(seg)
+    return updated
+
+
 # ----------------------------------------------------------------------------- VAD / chunking
 def calculate_voice_activity_in_chunks(signal: np.ndarray, chunkCount: int, frameLengthSamples: int,
                                        frameOverlapSamples: int = 0, energyThreshold: float = 0.022) -> List[bool]:

@@ -255,3 +255,103 @@ def test_update_segment_timings_and_vad_chunked_flow():
     assert sum(len(c[1]) for c in chunks) == len(audio) or chunks[-1][0] + len(chunks[-1][1]) <= len(audio)
     short = OD.transcribe_vad_chunked(audio[:1000], None, one)
     assert len(short) == 1 and short[0][0] == 0.0
+
+
+# ----------------------------------------------------------------------------- mergePunctuations KATs (UnitTests.swift:2484-2667)
+def _wt(word, tokens, start, end, prob=1.0):
+    from oracle import decode as OD
+    return OD.WordTiming(word, list(tokens), float(start), float(end), float(prob))
+
+
+def _assert_words(got, expected):
+    assert len(got) == len(expected)
+    for g, e in zip(got, expected):
+        assert (g.word, g.tokens, g.start, g.end, g.probability) == (e.word, e.tokens, e.start, e.end, e.probability)
+
+
+def test_merge_punctuations_empty_and_english():  # UnitTests.swift:2484-2539
+    from oracle import decode as OD
+    assert OD.merge_punctuations([]) == []
+    words = [_wt("<|0.00|>", [50364], 0, 1), _wt(" Hello", [2425], 1, 2), _wt(",", [11], 2, 3), _wt(" world", [1002], 3, 4),
+             _wt("!", [0], 4, 5), _wt("<|1.00|>", [50414], 5, 6), _wt("<|1.00|>", [50414], 6, 7), _wt(" This", [639], 7, 8),
+             _wt(" is", [307], 8, 9), _wt(" a", [257], 9, 10), _wt(" test", [220, 31636], 10, 11), _wt(",", [11], 11, 12),
+             _wt(" isn't", [1943, 380], 12, 13), _wt(" it", [309], 13, 14), _wt("?", [30], 14, 15), _wt("<|endoftext|>", [50257], 15, 16)]
+    got = OD.merge_punctuations(words, prepended="\"'“¿([{-", appended="\"'.。,，!！?？:：”)]}、")
+    _assert_words(got, [_wt("<|0.00|>", [50364], 0, 1), _wt(" Hello,", [2425, 11], 1, 2), _wt(" world!", [1002, 0], 3, 4),
+                        _wt("<|1.00|>", [50414], 5, 6), _wt("<|1.00|>", [50414], 6, 7), _wt(" This", [639], 7, 8), _wt(" is", [307], 8, 9),
+                        _wt(" a", [257], 9, 10), _wt(" test,", [220, 31636, 11], 10, 11), _wt(" isn't", [1943, 380], 12, 13),
+                        _wt(" it?", [309, 30], 13, 14), _wt("<|endoftext|>", [50257], 15, 16)])
+
+
+def test_merge_punctuations_spanish():  # UnitTests.swift:2541-2587
+    from oracle import decode as OD
+    words = [_wt("<|notimestamps|>", [50363], 0, 1), _wt(" ¡", [24364], 0, 1), _wt("Hola", [48529], 1, 2), _wt(" Mundo", [376, 6043], 2, 3),
+             _wt("!", [0], 3, 4), _wt(" Esta", [20547], 4, 5), _wt(" es", [785], 5, 6), _wt(" una", [2002], 6, 7),
+             _wt(" prueba", [48241], 7, 8), _wt(",", [11], 8, 9), _wt(" ¿", [3841], 9, 10), _wt("no", [1771], 10, 11), _wt("?", [30], 11, 12),
+             _wt("<|endoftext|>", [50257], 12, 13)]
+    _assert_words(OD.merge_punctuations(words),
+                  [_wt("<|notimestamps|>", [50363], 0, 1), _wt(" ¡Hola", [24364, 48529], 1, 2), _wt(" Mundo!", [376, 6043, 0], 2, 3),
+                   _wt(" Esta", [20547], 4, 5), _wt(" es", [785], 5, 6), _wt(" una", [2002], 6, 7), _wt(" prueba,", [48241, 11], 7, 8),
+                   _wt(" ¿no?", [3841, 1771, 30], 10, 11), _wt("<|endoftext|>", [50257], 12, 13)])
+
+
+def test_merge_punctuations_spanish_start_with_prepend():  # UnitTests.swift:2589-2622
+    from oracle import decode as OD
+    words = [_wt(" ¿", [1201], 0, 1), _wt("Que", [1202], 1, 2, 0.9), _wt(" pasa", [1203], 2, 3), _wt(" mundo", [1204], 3, 4, 0.6),
+             _wt("?", [1205], 4, 5, 0.4)]
+    _assert_words(OD.merge_punctuations(words),
+                  [_wt(" ¿Que", [1201, 1202], 1, 2, 0.9), _wt(" pasa", [1203], 2, 3), _wt(" mundo?", [1204, 1205], 3, 4, 0.6)])
+
+
+def test_merge_punctuations_japanese():  # UnitTests.swift:2624-2667
+    from oracle import decode as OD
+    words = [_wt("<|0.00|>", [50364], 0, 1), _wt("こんにちは", [38088], 1, 2), _wt("、", [1231], 2, 3), _wt("世界", [24486], 3, 4),
+             _wt("！", [171, 120, 223], 4, 5), _wt("これは", [25212], 5, 6), _wt("テ", [22985], 6, 7), _wt("スト", [40498], 7, 8),
+             _wt("です", [4767], 8, 9), _wt("よね", [30346], 9, 10), _wt("？", [171, 120, 253], 10, 11), _wt("<|endoftext|>", [50257], 11, 12)]
+    _assert_words(OD.merge_punctuations(words),
+                  [_wt("<|0.00|>", [50364], 0, 1), _wt("こんにちは、", [38088, 1231], 1, 2), _wt("世界！", [24486, 171, 120, 223], 3, 4),
+                   _wt("これは", [25212], 5, 6), _wt("テ", [22985], 6, 7), _wt("スト", [40498], 7, 8), _wt("です", [4767], 8, 9),
+                   _wt("よね？", [30346, 171, 120, 253], 9, 10), _wt("<|endoftext|>", [50257], 11, 12)])
+
+
+# ----------------------------------------------------------------------------- word-duration KATs (UnitTests.swift:2754-2937)
+def _seg(i, start, end, tokens):
+    from oracle import decode as OD
+    return OD.TranscriptionSegment(id=i, seek=0, start=start, end=end, text="", tokens=list(tokens), tokenLogProbs=[{0: 0.0}] * len(tokens),
+                                   temperature=0.0, avgLogprob=0.0, compressionRatio=1.0, noSpeechProb=0.0)
+
+
+def test_long_word_durations():  # UnitTests.swift:2754-2867
+    from oracle import decode as OD
+    words = [_wt(" The", [264], 0.5, 1.0), _wt(" first", [4589], 1.0, 2.0), _wt(" segment", [234], 2.0, 3.0), _wt(" with", [567], 3.0, 4.0),
+             _wt(" a", [257], 4.0, 5.0), _wt(" long", [890], 5.0, 6.0), _wt(" ending", [123], 6.0, 35.0), _wt(".", [13], 35.0, 35.0)]
+    segments = [_seg(0, 0.0, 6.0, [264, 4589, 234, 567, 257, 890]), _seg(1, 6.5, 30.0, [123, 13])]
+    med, mx = OD.calculate_word_duration_constraints(words)
+    assert med == pytest.approx(0.7, abs=1e-7) and mx == pytest.approx(1.4, abs=1e-6)
+    merged = OD.merge_punctuations(OD.truncate_long_words_at_sentence_boundaries(words, mx))
+    upd = OD.update_segments_with_word_timings(segments, merged, 0, 0.0, med, mx, specialTokenBegin=50257)
+    allw = [w for g in upd for w in g.words]
+    assert len(upd) == 2
+    assert allw[-1].duration == pytest.approx(mx, abs=1e-4)
+    assert upd[-1].end - upd[-1].start <= 19.5
+    k = next(i for i, w in enumerate(allw) if w.word == " ending.")
+    assert allw[k].duration == pytest.approx(mx, abs=1e-4)
+    assert allw[k].start == pytest.approx(33.6, abs=1e-5)
+    assert all(a.end <= b.start for a, b in zip(allw, allw[1:]))
+
+
+def test_single_token_segment_word_duration():  # UnitTests.swift:2869-2937
+    from oracle import decode as OD
+    words = [_wt("<|notimestamps|>", [50363], 0, 0.5), _wt(" Hello", [314], 0.5, 20.5), _wt("<|endoftext|>", [50257], 20.5, 30)]
+    segments = [_seg(0, 0.0, 30.0, [314])]
+    med, mx = OD.calculate_word_duration_constraints(words)
+    assert med == pytest.approx(0.7, abs=1e-7) and mx == pytest.approx(1.4, abs=1e-6)
+    merged = OD.merge_punctuations(OD.truncate_long_words_at_sentence_boundaries(words, mx))
+    upd = OD.update_segments_with_word_timings(segments, merged, 0, 0.0, med, mx, specialTokenBegin=50257)
+    ws = upd[0].words
+    hello = next(w for w in ws if w.word == " Hello")
+    assert hello.duration <= mx + 1e-6
+    prev_end = 0.0
+    for w in ws:
+        assert w.start >= prev_end and w.duration <= mx + 1e-6
+        prev_end = w.end
