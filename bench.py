@@ -71,7 +71,9 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float):
         return "hbm", 3 * d * d * 2 + 3 * d * 4 + act + B * 3 * d * 2
     if kind == "dec_self_attn":  # K,V rows of <= len cached positions, q in, att out
         return "hbm", B * 2 * avg_len * d * 2 + 2 * act
-    if kind in ("dec_gemv_oproj", "dec_gemv_coproj"):   # x += W att + b
+    if kind == "dec_gemv_oproj":   # x += W_o att + b_o, and in the same launch the folded cross query u = [Wq'|M] (hi|lo) [x ; att] + c0
+        return "hbm", d * d * 2 + 4 * d * d * 2 + 4 * act
+    if kind == "dec_gemv_coproj":  # x += W_co att + b_co
         return "hbm", d * d * 2 + 3 * act
     if kind == "dec_gemv_cq":    # LN2 + cross query
         return "hbm", d * d * 2 + 2 * act

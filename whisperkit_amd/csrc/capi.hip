@@ -146,6 +146,7 @@ static int bind_weights(wh_model* m) {
         GET16(p + ".o.w", w.o_w); GET32(p + ".o.b", w.o_b);
         GET32(p + ".ln2.g", w.ln2_g); GET32(p + ".ln2.b", w.ln2_b); GET16(p + ".cq.w", w.cq_w); GET32(p + ".cq.b", w.cq_b);
         GET16(p + ".co.w", w.co_w); GET32(p + ".co.b", w.co_b);
+        GET16(p + ".cqf.w", w.cqf_w); GET32(p + ".cqf.c0", w.cqf_c0); GET32(p + ".cqf.r", w.cqf_r); GET32(p + ".cqf.c", w.cqf_c);
         GET32(p + ".ln3.g", w.ln3_g); GET32(p + ".ln3.b", w.ln3_b);
         GET16(p + ".fc1.w", w.fc1_w); GET32(p + ".fc1.b", w.fc1_b); GET16(p + ".fc2.w", w.fc2_w); GET32(p + ".fc2.b", w.fc2_b);
     }
@@ -470,6 +471,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch) {
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
     db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v; db.x = s->xa; db.q = s->q; db.att = s->att;
     db.hbuf = s->hbuf; db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
+    { static const bool off = [] { const char* e = getenv("WH_NO_FUSED_CQ"); return e && e[0] == '1'; }(); db.fused_cq = off ? 0 : 1; }
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
     return db;

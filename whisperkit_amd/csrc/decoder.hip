@@ -44,6 +44,9 @@ struct GemvArgs {
     const float *ln_g, *ln_b;  // prologue LayerNorm (QKV, Q, FC1, LOGITS)
     float* x;                  // residual stream [B][d]
     const float* ain;          // MODE_RESID input [B][d] f32 (attention output)
+    // MODE_RESID, optional second problem in the same launch (workgroups >= nblk1): u = W2 [x ; att] + bias2, W2 = [N2][K2 = 4d]
+    // fp16 hi|lo pairs of the folded cross-query matrices, out2 [B][N2] (finished to q by the cross-attention kernel)
+    const f16* W2; const float* bias2; float* out2; int N2, K2, k_split2, rows_per_block2, nblk1;
     const f16* emb; const float* pos;   // layer-0 embedding
     float* q;                  // [B][d] f32 query out (QKV / Q)
     f16* self_k; f16* self_v;  // this layer's cache base [Bmax][H][224][64]
@@ -239,10 +242,20 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     __shared__ float lt[MODE == MODE_LOGITS ? BT * 64 : 1];   // this workgroup's logits (<= 64 rows) for the fused sampler statistics
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.y * BT;
-    const int K = a.K, d = a.d;
-    const int KS = a.k_split, RG = NW / KS;
+    const int d = a.d;
+    // MODE_RESID can carry a second, independent GEMV in the same launch (the folded cross-attention query): workgroups
+    // >= nblk1 work on it.  The choice is workgroup-uniform; everything below reads the selected problem.
+    const bool second = (MODE == MODE_RESID) && a.W2 != nullptr && (int)blockIdx.x >= a.nblk1;
+    const int K = second ? a.K2 : a.K, N = second ? a.N2 : a.N;
+    const f16* const Wp = second ? a.W2 : a.W;
+    const float* const biasp = second ? a.bias2 : a.bias;
+    const int rows_per_block = second ? a.rows_per_block2 : a.rows_per_block;
+    const int bx = second ? (int)blockIdx.x - a.nblk1 : (int)blockIdx.x;
+    const int KS = second ? a.k_split2 : a.k_split, RG = NW / KS;
     const int ks = wave % KS, rg = wave / KS;
     const int KC = K / KS, kbase = ks * KC;
+    const int ldx = second ? 2 * d : K;                      // LDS row stride of the staged activations
+    const int xoff = second ? (ks >> 1) * d : kbase;          // [x ; att]: K quarters 0,1 read x, quarters 2,3 read att
     // Slot liveness is LOADED here but only LOOKED AT after the activation and weight loads have been issued (LIVE_CHECK):
     // a test right away would put one more dependent L2 round trip in front of every kernel of the chain.
     int s_act[BT], s_done[BT];
@@ -260,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     } while (0)
     DBG_STAMP(6);
 
-    const int n_begin = blockIdx.x * a.rows_per_block;
-    const int n_end = min(a.N, n_begin + a.rows_per_block);
+    const int n_begin = bx * rows_per_block;
+    const int n_end = min(N, n_begin + rows_per_block);
     const int rows_per_pass = RG * R;
     const int n_pass = (n_end - n_begin + rows_per_pass - 1) / rows_per_pass;
 
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
     auto load_group = [&](uint4 (&dst)[R][KI], int n0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const f16* wr = a.W + (size_t)min(n0 + r, a.N - 1) * K + kbase + lane * 8;
+            const f16* wr = Wp + (size_t)min(n0 + r, N - 1) * K + kbase + lane * 8;
 #pragma unroll
             for (int i = 0; i < KI; ++i)
                 dst[r][i] = (lane * 8 + 512 * i < KC) ? *reinterpret_cast<const uint4*>(wr + 512 * i) : uint4{0, 0, 0, 0};
@@ -294,13 +307,15 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         LIVE_CHECK();
     } else if constexpr (MODE == MODE_RESID) {
         constexpr int AV = (BT * 320 + NT - 1) / NT;    // float4 per thread, d <= 1280
-        float4 areg[AV];
+        float4 areg[AV], xreg[AV];
         const int per_row = d / 4;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int idx = tid + i * NT;
             const int b = idx / per_row, c = idx - b * per_row;
-            areg[i] = (idx < BT * per_row && b0 + b < a.batch) ? reinterpret_cast<const float4*>(a.ain + (size_t)(b0 + b) * d)[c] : float4{0, 0, 0, 0};
+            const bool ok = idx < BT * per_row && b0 + b < a.batch;
+            areg[i] = ok ? reinterpret_cast<const float4*>(a.ain + (size_t)(b0 + b) * d)[c] : float4{0, 0, 0, 0};
+            xreg[i] = (ok && second) ? reinterpret_cast<const float4*>(a.x + (size_t)(b0 + b) * d)[c] : float4{0, 0, 0, 0};
         }
         load_group(cur, n_begin + rg * R);
         DBG_STAMP(1);
@@ -308,7 +323,15 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int idx = tid + i * NT;
-            if (idx < BT * per_row) reinterpret_cast<float4*>(xs)[idx] = areg[i];
+            if (idx < BT * per_row) {
+                const int b = idx / per_row, c = idx - b * per_row;
+                if (second) {       // row layout [x | att]
+                    reinterpret_cast<float4*>(xs + (size_t)b * ldx)[c] = xreg[i];
+                    reinterpret_cast<float4*>(xs + (size_t)b * ldx + d)[c] = areg[i];
+                } else {
+                    reinterpret_cast<float4*>(xs + (size_t)b * ldx)[c] = areg[i];
+                }
+            }
         }
     } else {
         // LayerNorm in registers: row = tid / 32, the row's d/4 float4 are dealt round-robin to its 32 threads.  The split is
@@ -421,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
         float bias_l = 0.0f, xold_l = 0.0f;
         int pos_l = 0;
         if (out_l) {
-            if (a.bias) bias_l = a.bias[n_l];
-            if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) xold_l = a.x[(size_t)gb_l * d + n_l];
+            if (biasp) bias_l = biasp[n_l];
+            if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) { if (!second) xold_l = a.x[(size_t)gb_l * d + n_l]; }
             if constexpr (MODE == MODE_QKV) pos_l = a.seq[gb_l].token_index;
         }
         float acc[NV];
@@ -445,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xk[b][j] = (float)hv[j];
                         } else {
-                            float4 x0 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k);
-                            float4 x1 = *reinterpret_cast<const float4*>(xs + (bc + b) * K + k + 4);
+                            float4 x0 = *reinterpret_cast<const float4*>(xs + (bc + b) * ldx + xoff + kl);
+                            float4 x1 = *reinterpret_cast<const float4*>(xs + (bc + b) * ldx + xoff + kl + 4);
                             xk[b][0] = x0.x; xk[b][1] = x0.y; xk[b][2] = x0.z; xk[b][3] = x0.w;
                             xk[b][4] = x1.x; xk[b][5] = x1.y; xk[b][6] = x1.z; xk[b][7] = x1.w;
                         }
@@ -494,11 +517,12 @@ __global__ __launch_bounds__(256, 2) void dec_gemv_kernel(const GemvArgs a) {
                 } else if constexpr (MODE == MODE_Q) {
                     a.q[(size_t)gb * d + n] = v;
                 } else if constexpr (MODE == MODE_FC1) {
-                    a.hbuf[(size_t)gb * a.N + n] = (f16)gelu_erf(v);
+                    a.hbuf[(size_t)gb * N + n] = (f16)gelu_erf(v);
                 } else if constexpr (MODE == MODE_RESID || MODE == MODE_FC2) {
-                    a.x[(size_t)gb * d + n] = xold_l + v;
+                    if (second) a.out2[(size_t)gb * N + n] = v;
+                    else a.x[(size_t)gb * d + n] = xold_l + v;
                 } else {
-                    a.logits[(size_t)gb * a.N + n] = v;
+                    a.logits[(size_t)gb * N + n] = v;
                     if (a.stats) lt[b * 64 + (n - n_begin)] = v;
                 }
             }
@@ -531,6 +555,8 @@ struct AttnArgs {
     int* ticket;             // [B][H] arrival counters (zero between launches)
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
+    // folded cross query (xq != null): a.q holds u; q = (u - mean(x') r) * rstd(x') + c is finished here, x' = xq [B][d]
+    const float* xq; const float* qr; const float* qc;
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
 #define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
@@ -539,9 +565,9 @@ struct AttnArgs {
 // key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
 // before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
 // o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
-template <int PASSES, typename GetN>
+template <int PASSES, typename GetN, typename QFix>
 __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
-                                             GetN get_n, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
+                                             GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
                                              float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
     // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
     // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
@@ -566,6 +592,7 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
     }
     const int n = get_n();
     if (n < 0) return false;            // workgroup-uniform
+    qfix(qv, part);                     // identity, or the LayerNorm-folded cross query finish
     float* raw_scores = *raw_pp;
     float s[PASSES];
     float lmax = -INFINITY;
@@ -636,7 +663,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     float m, l;
     float* raw = nullptr;
     auto get_n = [&]() { return (s_act && !s_done) ? min(max(s_ti, 0), kMaxTok - 1) + 1 : -1; };
-    if (!attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, kMaxTok, get_n, &raw, red, osum, o_l, &m, &l))
+    auto qfix = [](float (&)[8], int) {};
+    if (!attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, kMaxTok, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
     if (threadIdx.x < 64) a.att[(size_t)b * d + h * kHeadDim + threadIdx.x] = o_l[threadIdx.x] / l;
 }
@@ -660,13 +688,49 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296), raw scores here,
     // softmax + head mean in alignment_mean_kernel
     float* raw = nullptr;
+    // folded cross query: this slot's residual row x' (for its LayerNorm statistics) and the r / c constants of the lane's 8
+    // query channels are requested now, ahead of the K/V stream issued inside attend_block
+    const bool fq = a.xq != nullptr;
+    const int nv4 = d >> 2, tidq = threadIdx.x;
+    float4 xa = float4{0, 0, 0, 0}, xb = float4{0, 0, 0, 0}, r0 = xa, r1 = xa, c0 = xa, c1 = xa;
+    if (fq) {
+        const float4* xr = reinterpret_cast<const float4*>(a.xq + (size_t)b * d);
+        if (tidq < nv4) xa = xr[tidq];
+        if (tidq + 256 < nv4) xb = xr[tidq + 256];
+        const int qo = h * kHeadDim + (tidq & 7) * 8;
+        r0 = *reinterpret_cast<const float4*>(a.qr + qo); r1 = *reinterpret_cast<const float4*>(a.qr + qo + 4);
+        c0 = *reinterpret_cast<const float4*>(a.qc + qo); c1 = *reinterpret_cast<const float4*>(a.qc + qo + 4);
+    }
+    float q_mean = 0.0f, q_rstd = 1.0f;
     auto get_n = [&]() {
         if (!(s_act && !s_done)) return -1;
         const int pos = min(max(s_ti, 0), kMaxTok - 1);
         if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
+        if (fq) {       // LayerNorm statistics of x'[b] (two-pass, fixed order: the same in every workgroup of the slot)
+            const int lane = tidq & 63, wave = tidq >> 6;
+            float sm = (xa.x + xa.y) + (xa.z + xa.w) + ((xb.x + xb.y) + (xb.z + xb.w));
+            sm = wave_sum(sm);
+            if (lane == 0) red[8 + wave] = sm;
+            __syncthreads();
+            q_mean = ((red[8] + red[9]) + (red[10] + red[11])) / (float)d;
+            float qv2 = 0.0f;
+            if (tidq < nv4) { float e0 = xa.x - q_mean, e1 = xa.y - q_mean, e2 = xa.z - q_mean, e3 = xa.w - q_mean; qv2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3); }
+            if (tidq + 256 < nv4) { float e0 = xb.x - q_mean, e1 = xb.y - q_mean, e2 = xb.z - q_mean, e3 = xb.w - q_mean; qv2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3); }
+            qv2 = wave_sum(qv2);
+            if (lane == 0) red[12 + wave] = qv2;
+            __syncthreads();
+            q_rstd = rsqrtf(((red[12] + red[13]) + (red[14] + red[15])) / (float)d + 1e-5f);
+        }
         return n;
     };
-    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, &raw, red, osum, o_l, &m, &l, stamp))
+    auto qfix = [&](float (&qv)[8], int) {
+        if (!fq) return;
+        const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (qv[j] - q_mean * rr[j]) * q_rstd + cc[j];
+    };
+    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
         return;
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
@@ -1092,6 +1156,21 @@ static void launch_gemv_bt(GemvArgs a, hipStream_t st) {
     else launch_gemv_r<MODE, BT, 1>(a, passes, st);
 }
 
+// out projection + folded cross query in one launch (MODE_RESID with a second problem): batch tiles of 4 slots so that the
+// [x ; att] image of the second problem is 2 * 4 * d floats of LDS, R = 4 rows per wave for both problems
+static void launch_gemv_resid_cq(GemvArgs a, hipStream_t st) {
+    a.k_split = 1;
+    a.rows_per_block = 4 * 4;                    // 4 row groups x R
+    a.nblk1 = (a.N + a.rows_per_block - 1) / a.rows_per_block;
+    a.k_split2 = 4;                              // the four K quarters Wq'_hi | Wq'_lo | M_hi | M_lo, one wave each
+    a.rows_per_block2 = 4;                       // 1 row group x R
+    const int nblk2 = (a.N2 + a.rows_per_block2 - 1) / a.rows_per_block2;
+    a.dbg = debug_buffer() ? debug_buffer() + (size_t)g_dbg_kind * 4096 * 8 : nullptr;
+    const size_t smem4 = (size_t)4 * 2 * a.d * sizeof(float), smem1 = (size_t)2 * a.d * sizeof(float);
+    if (a.batch >= 2) dec_gemv_kernel<MODE_RESID, 4, 4><<<dim3(a.nblk1 + nblk2, (a.batch + 3) / 4), 256, smem4, st>>>(a);
+    else dec_gemv_kernel<MODE_RESID, 1, 4><<<dim3(a.nblk1 + nblk2, 1), 256, smem1, st>>>(a);
+}
+
 template <int MODE>
 static void launch_gemv(const GemvArgs& a, hipStream_t st) {
     if constexpr (MODE == MODE_FC2) {
@@ -1139,12 +1218,20 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         at.att = db.att; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
         { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
-        // x += W_o att + b_o
+        // x += W_o att + b_o   (+ in the same launch, when fused: u = Wq' x + M att + c0, the LayerNorm-folded cross query)
         g.N = d; g.K = d; g.W = w.o_w; g.bias = w.o_b; g.ain = db.att;
-        { ProfScope ps_(KK_DEC_OPROJ, st); g_dbg_kind = KK_DEC_OPROJ; launch_gemv<MODE_RESID>(g, st); }
-        // LN2 + cross query
-        g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
-        { ProfScope ps_(KK_DEC_CQ, st); g_dbg_kind = KK_DEC_CQ; launch_gemv<MODE_Q>(g, st); }
+        const bool fcq = db.fused_cq != 0;
+        if (fcq) {
+            GemvArgs g2 = g;
+            g2.W2 = w.cqf_w; g2.bias2 = w.cqf_c0; g2.out2 = db.q; g2.N2 = d; g2.K2 = 4 * d;
+            ProfScope ps_(KK_DEC_OPROJ, st); g_dbg_kind = KK_DEC_OPROJ; launch_gemv_resid_cq(g2, st);
+            at.xq = db.x; at.qr = w.cqf_r; at.qc = w.cqf_c;
+        } else {
+            { ProfScope ps_(KK_DEC_OPROJ, st); g_dbg_kind = KK_DEC_OPROJ; launch_gemv<MODE_RESID>(g, st); }
+            // LN2 + cross query
+            g.W = w.cq_w; g.bias = w.cq_b; g.ln_g = w.ln2_g; g.ln_b = w.ln2_b;
+            { ProfScope ps_(KK_DEC_CQ, st); g_dbg_kind = KK_DEC_CQ; launch_gemv<MODE_Q>(g, st); }
+        }
         at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
         {
             ProfScope ps_(KK_DEC_CROSS_ATTN, st);

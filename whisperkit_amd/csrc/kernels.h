@@ -97,6 +97,7 @@ struct DecLayerW {
     const f16* o_w; const float* o_b;
     const float *ln2_g, *ln2_b; const f16* cq_w; const float* cq_b;
     const f16* co_w; const float* co_b;
+    const f16* cqf_w; const float *cqf_c0, *cqf_r, *cqf_c;   // LN2 + cross query folded over the out projection (weights.py)
     const float *ln3_g, *ln3_b; const f16* fc1_w; const float* fc1_b; const f16* fc2_w; const float* fc2_b;
 };
 
@@ -154,6 +155,7 @@ struct DecodeBuffers {
     float* logits;           // [B][V]
     float* stats;            // [B][kStatBlocks][8] per-workgroup softmax statistics of the logits kernel (fused greedy sampler)
     const unsigned char* sup_mask;   // [V] SuppressTokensFilter as a byte mask
+    int fused_cq;            // out-projection launch also computes the folded cross query (one launch less per layer)
     int fused_greedy;        // every active slot samples at T = 0: filters + statistics in the logits epilogue, tiny final kernel
     float* align;            // [B][224][n_align][1500] raw score rows of the alignment heads (or null)
     const int* align_slot;   // [L*H] -> slot index or -1
