@@ -35,6 +35,7 @@ extern "C" {
 typedef struct wh_model wh_model;
 typedef struct wh_session wh_session;
 typedef struct wh_transcription wh_transcription;
+typedef struct wh_tokenizer wh_tokenizer;
 
 /* Utilities/WhisperError.swift:7-18 */
 typedef enum wh_status {
@@ -138,7 +139,8 @@ typedef struct wh_segment {
 } wh_segment;
 
 typedef struct wh_word_timing {
-    int32_t token_offset, n_tokens;
+    int32_t token_offset, n_tokens; /* into the transcription's flat WORD-token array (wh_transcription_word_tokens): a merged
+                                       word keeps only its text tokens, which need not be adjacent in the segment */
     float start, end, probability;
 } wh_word_timing;
 
@@ -149,6 +151,11 @@ typedef struct wh_timings {
         decoding_loop, full_pipeline, input_audio_seconds;
     double total_decoding_loops, total_decoding_windows, total_decoding_fallbacks, total_encoding_runs,
         total_logmel_runs;
+    /* the remaining stored properties of TranscriptionTimings, so that the JSON report carries every key of the reference's:
+     * pipeline_start / first_token_time are CFAbsoluteTime (seconds since 2001-01-01 UTC) */
+    double pipeline_start, first_token_time, model_loading, prewarm_load_time, encoder_load_time, decoder_load_time,
+        encoder_specialization_time, decoder_specialization_time, tokenizer_load_time, audio_loading, decoding_non_prediction,
+        total_audio_processing_runs, total_kv_update_runs, total_timestamp_alignment_runs;
 } wh_timings;
 
 const char* wh_last_error(void);
@@ -229,6 +236,33 @@ int wh_detect_language(wh_session* s, int batch, const wh_special_tokens* st, in
 int wh_prefill_prompt(const wh_model* m, const wh_decoding_options* opt, const wh_special_tokens* st,
                       int32_t language_token, int32_t* prompt_out, int capacity);
 
+/* ---- tokenizer text: WhisperTokenizer (Core/Models.swift:1150-1307) over the vendored swift-transformers decoder
+ * (ArgmaxCore/External/Tokenizers/Tokenizer.swift:510-525, Decoder.swift:126-165).  Host only - no GPU involved.
+ * Strings are UTF-8; functions that write a string return its full byte length (without the NUL) and truncate to
+ * capacity-1 bytes + NUL, so a first call with (NULL, 0) sizes the buffer. */
+/* ModelUtilities.loadTokenizer (Utilities/ModelUtilities.swift:175-203): ByteLevel-BPE `tokenizer.json`; a
+ * `tokenizer_config.json` next to it supplies clean_up_tokenization_spaces (default true). */
+int wh_tokenizer_load(const char* tokenizer_json_path, wh_tokenizer** out);
+void wh_tokenizer_destroy(wh_tokenizer* t);
+int wh_tokenizer_vocab_size(const wh_tokenizer* t);
+int wh_tokenizer_decode(const wh_tokenizer* t, const int32_t* tokens, int n, int skip_special_tokens, char* out, int capacity);
+int wh_tokenizer_token_to_id(const wh_tokenizer* t, const char* token);                    /* convertTokenToId; -1 = nil */
+int wh_tokenizer_id_to_token(const wh_tokenizer* t, int id, char* out, int capacity);      /* convertIdToToken; -1 = nil */
+/* WhisperTokenizerWrapper.init (Core/Models.swift:1198-1224): ids looked up by token text, reference defaults otherwise */
+int wh_tokenizer_special_tokens(const wh_tokenizer* t, wh_special_tokens* out);
+/* splitToWordTokens (Core/Models.swift:1226-1306).  The reference picks the unicode / space splitter with Apple's
+ * NLLanguageRecognizer; here the caller passes the language code (zh ja th lo my yue -> unicode splitter).  Returns the
+ * number of words; word_token_counts[i] = tokens of word i (consecutive in `tokens`), word_byte_counts[i] = UTF-8 bytes of
+ * word i; words_out receives the words back to back without terminators (a byte token may decode to NUL);
+ * *words_bytes = bytes needed.  -2 when a buffer is too small. */
+int wh_tokenizer_split_to_word_tokens(const wh_tokenizer* t, const int32_t* tokens, int n, const char* language_code,
+                                      int32_t* word_token_counts, int32_t* word_byte_counts, int counts_capacity,
+                                      char* words_out, int words_capacity, int* words_bytes);
+/* TextDecoding.tokenizer (Core/TextDecoder.swift:61): with a tokenizer attached the transcribe entry points produce
+ * segment / word / result text, group word timestamps by real words and infer the language code.  NULL detaches.
+ * The tokenizer must outlive the session's use of it. */
+int wh_session_set_tokenizer(wh_session* s, const wh_tokenizer* t);
+
 /* ---- TranscribeTask.run (Core/TranscribeTask.swift:57-296) --------------------------------------- */
 int wh_transcribe(wh_session* s, const float* pcm_host, int n_samples, const wh_decoding_options* opt,
                   const wh_special_tokens* st, wh_transcription** out);
@@ -252,6 +286,56 @@ int wh_transcription_tokens(const wh_transcription* t, const int32_t** tokens, c
 int wh_transcription_language_token(const wh_transcription* t);
 int wh_transcription_timings(const wh_transcription* t, wh_timings* out);
 int wh_transcription_window_seeks(const wh_transcription* t, const int32_t** seeks, int* n);
+
+/* ---- text of a transcription (present when a tokenizer was attached to the session, or for objects built by
+ * wh_transcription_create / wh_merge_transcriptions); string-returning functions follow the wh_tokenizer_decode convention */
+int wh_transcription_has_text(const wh_transcription* t);
+int wh_transcription_text(const wh_transcription* t, char* out, int capacity);            /* TranscriptionResult.text */
+int wh_transcription_language(const wh_transcription* t, char* out, int capacity);        /* TranscriptionResult.language ("en", ...) */
+int wh_transcription_segment_text(const wh_transcription* t, int i, char* out, int capacity); /* TranscriptionSegment.text */
+int wh_transcription_word_text(const wh_transcription* t, int i, char* out, int capacity);    /* WordTiming.word */
+int wh_transcription_word_tokens(const wh_transcription* t, const int32_t** tokens, int* n);  /* flat WordTiming.tokens */
+int wh_transcription_seek_time(const wh_transcription* t, float* out);                    /* 1 + *out when seekTime != nil, else 0 */
+
+/* SegmentSeeker.addWordTimestamps (Core/Text/SegmentSeeker.swift:410-496) for one window as a pure host function: DTW over
+ * `alignment` ([alignment_rows][1500], row r = r-th token of the segments in order), word grouping (splitToWordTokens),
+ * duration constraints, punctuation merge, updateSegmentsWithWordTimings.  `segments` index `tokens` / `logprobs`.
+ * Returns a new transcription holding the updated segments (+ text), the words and their tokens. */
+int wh_add_word_timestamps(const wh_tokenizer* tok, const char* language_code, const wh_special_tokens* st,
+                           const wh_segment* segments, int n_segments, const int32_t* tokens, const float* logprobs, int n_tokens,
+                           const float* alignment, int alignment_rows, int seek, float last_speech_timestamp,
+                           int skip_special_tokens, wh_transcription** out);
+
+/* ---- result assembly and on-disk formats ------------------------------------------------------------ */
+/* TranscriptionResult(text:segments:language:timings:seekTime:) from parts (tok may be NULL: no text); seek_time NAN = nil */
+int wh_transcription_create(const wh_tokenizer* tok, const wh_special_tokens* st, const wh_segment* segments, int n_segments,
+                            const int32_t* tokens, const float* logprobs, int n_tokens, int language_token,
+                            int skip_special_tokens, float seek_time, const wh_timings* timings, wh_transcription** out);
+/* TranscriptionUtilities.mergeTranscriptionResults (Utilities/TranscriptionUtilities.swift:76-157); results[i] may be NULL
+ * (a failed chunk); confirmed_words != NULL replaces the joined text by the concatenation of those words */
+int wh_merge_transcriptions(const wh_transcription* const* results, int n, const char* const* confirmed_words, int n_confirmed,
+                            wh_transcription** out);
+/* ResultWriting.formatTime (Utilities/ResultWriter.swift:14-26) */
+int wh_format_time(float seconds, int always_include_hours, char decimal_marker, char* out, int capacity);
+/* WriteSRT / WriteVTT / WriteJSON (Utilities/ResultWriter.swift:40-134); `path` is the full file name */
+int wh_write_srt(const wh_transcription* t, const char* path);
+int wh_write_vtt(const wh_transcription* t, const char* path);
+int wh_write_json(const wh_transcription* t, const char* path);
+
+/* ---- audio ingest (Core/Audio/AudioProcessor.swift) ------------------------------------------------- */
+enum { WH_CHANNEL_SPECIFIC = 0, WH_CHANNEL_SUM = 1 }; /* AudioInputConfig.ChannelMode :30-42 */
+/* AudioProcessor.convertToMono (:525-625) on planar float channels; indices NULL / empty = all channels */
+int wh_convert_to_mono(const float* const* channels, int n_channels, int n_frames, int mode, const int32_t* indices,
+                       int n_indices, float* out);
+/* resampleAudio (:458-519): equal rates pass through; other rates use a Kaiser-windowed sinc (AVAudioConverter's own filter
+ * is unpublished - not sample-identical).  out == NULL returns the output length. */
+int wh_resample(const float* in, int n_in, double in_rate, double out_rate, float* out, int capacity);
+/* AudioProcessor.loadAudio(fromPath:channelMode:startTime:endTime:maxReadFrameSize:) (:229-300) for RIFF/WAVE files
+ * (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) -> 16 kHz mono float; end_time NAN = nil,
+ * max_read_frame_size 0 = Constants.defaultAudioReadFrameSize.  Free with wh_audio_free. */
+int wh_load_audio(const char* path, int channel_mode, const int32_t* channel_indices, int n_channel_indices, double start_time,
+                  double end_time, int max_read_frame_size, float** pcm_out, int* n_out);
+void wh_audio_free(float* pcm);
 
 /* ---- host utilities restated from the reference -------------------------------------------------- */
 float wh_compression_ratio(const int32_t* tokens, int n);          /* TextUtilities.compressionRatio, Utilities/TextUtilities.swift:14-30 */

@@ -659,6 +659,22 @@ def truncate_long_words_at_sentence_boundaries(alignment: List[WordTiming], maxD
     return out
 
 
+def is_swift_whitespace(ch: str) -> bool:
+    """CharacterSet.whitespaces: Unicode general category Zs plus CHARACTER TABULATION."""
+    import unicodedata
+    return ch == "\t" or unicodedata.category(ch) == "Zs"
+
+
+def trim_whitespaces(s: str) -> str:
+    """String.trimmingCharacters(in: .whitespaces)."""
+    a, b = 0, len(s)
+    while a < b and is_swift_whitespace(s[a]):
+        a += 1
+    while b > a and is_swift_whitespace(s[b - 1]):
+        b -= 1
+    return s[a:b]
+
+
 def merge_punctuations(alignment: List[WordTiming], prepended: str = "\"'“¡¿([{-",
                        appended: str = "\"'.。,，!！?？:：”)]}、") -> List[WordTiming]:
     """Core/Text/SegmentSeeker.swift:280-338 (defaults: Constants.defaultPrepend/AppendPunctuations)."""
@@ -667,13 +683,13 @@ def merge_punctuations(alignment: List[WordTiming], prepended: str = "\"'“¡¿
     al = [dataclasses.replace(w) for w in alignment]
     pre: List[WordTiming] = []
     app: List[WordTiming] = []
-    if al[0].word.strip(" \t") not in prepended or al[0].word.strip(" \t") == "":
+    if trim_whitespaces(al[0].word) not in prepended or trim_whitespaces(al[0].word) == "":
         # Swift `String.contains("")` is false for the empty string
         pre.append(al[0])
     for i in range(1, len(al)):
         cur, prev = dataclasses.replace(al[i]), al[i - 1]
-        pw = prev.word.strip(" \t")
-        if prev.word[:1].isspace() and prev.word[:1] in " \t " and pw != "" and pw in prepended:
+        pw = trim_whitespaces(prev.word)
+        if prev.word[:1] != "" and is_swift_whitespace(prev.word[0]) and pw != "" and pw in prepended:
             cur.word = prev.word + cur.word
             cur.tokens = prev.tokens + cur.tokens
             if not pre:
@@ -686,7 +702,7 @@ def merge_punctuations(alignment: List[WordTiming], prepended: str = "\"'“¡¿
         app.append(pre[0])
     for i in range(1, len(pre)):
         cur, prev = pre[i], dataclasses.replace(pre[i - 1])
-        cw = cur.word.strip(" \t")
+        cw = trim_whitespaces(cur.word)
         if not prev.word.endswith(" ") and cw != "" and cw in appended:
             prev.word = prev.word + cur.word
             prev.tokens = prev.tokens + cur.tokens
@@ -986,3 +1002,128 @@ def transcribe_vad_chunked(audio: np.ndarray, options: Optional[DecodingOptions]
         res = dataclasses.replace(res, segments=[update_segment_timings(g, seekTime) for g in res.segments])
         out.append((seekTime, res))
     return out
+
+
+# ----------------------------------------------------------------------------- SegmentSeeker.addWordTimestamps
+def add_word_timestamps(segments: List[TranscriptionSegment], alignmentWeights: np.ndarray, split_fn: Callable,
+                        decode_fn: Optional[Callable[[List[int]], str]], seek: int, lastSpeechTimestamp: float,
+                        specialTokenBegin: int) -> List[TranscriptionSegment]:
+    """Core/Text/SegmentSeeker.swift:410-496.  `split_fn(tokenIds) -> (words, wordTokens)` is tokenizer.splitToWordTokens,
+    `decode_fn` tokenizer.decode; row r of `alignmentWeights` belongs to the r-th token of the segments in order
+    (filteredIndices = index + indexOffset, :427-437)."""
+    wordTokenIds: List[int] = []
+    logProbs: List[float] = []
+    for g in segments:
+        for i, t in enumerate(g.tokens):
+            wordTokenIds.append(t)
+            lp = g.tokenLogProbs[i]
+            logProbs.append(lp[t] if isinstance(lp, dict) else lp)
+    filtered = np.asarray(alignmentWeights, dtype=np.float32)[:len(wordTokenIds)]
+    alignment = find_alignment(wordTokenIds, filtered, logProbs, split_fn) if wordTokenIds else []
+    median, maxDuration = calculate_word_duration_constraints(alignment)
+    alignment = truncate_long_words_at_sentence_boundaries(alignment, maxDuration)
+    if alignment:
+        alignment = merge_punctuations(alignment)
+    return update_segments_with_word_timings(segments, alignment, seek, lastSpeechTimestamp, median, maxDuration,
+                                             specialTokenBegin, decode_fn)
+
+
+# ----------------------------------------------------------------------------- result assembly and formats
+def format_time(seconds: float, alwaysIncludeHours: bool, decimalMarker: str) -> str:
+    """ResultWriting.formatTime, Utilities/ResultWriter.swift:14-26 (Float arithmetic)."""
+    f = np.float32
+    s = f(seconds)
+    hrs = int(s / f(3600))
+    mins = int(f(math.fmod(float(s), 3600.0)) / f(60))
+    secs = int(f(math.fmod(float(s), 60.0)))
+    msec = int(f(s - f(math.floor(float(s)))) * f(1000))
+    if alwaysIncludeHours or hrs > 0:
+        return f"{hrs:02d}:{mins:02d}:{secs:02d}{decimalMarker}{msec:03d}"
+    return f"{mins:02d}:{secs:02d}{decimalMarker}{msec:03d}"
+
+
+def srt_text(segments: List[TranscriptionSegment]) -> str:
+    """WriteSRT.write, Utilities/ResultWriter.swift:70-100."""
+    out, index = "", 1
+    for g in segments:
+        cues = [(w.start, w.end, w.word) for w in g.words] if g.words else [(g.start, g.end, g.text)]
+        for a, b, text in cues:
+            out += f"{index}\n{format_time(a, True, ',')} --> {format_time(b, True, ',')}\n{text}\n\n"
+            index += 1
+    return out
+
+
+def vtt_text(segments: List[TranscriptionSegment]) -> str:
+    """WriteVTT.write, Utilities/ResultWriter.swift:103-134."""
+    out = "WEBVTT\n\n"
+    for g in segments:
+        cues = [(w.start, w.end, w.word) for w in g.words] if g.words else [(g.start, g.end, g.text)]
+        for a, b, text in cues:
+            out += f"{format_time(a, False, '.')} --> {format_time(b, False, '.')}\n{text}\n\n"
+    return out
+
+
+def merge_transcription_results(results: List[Optional[dict]], confirmedWords: Optional[List[str]] = None) -> dict:
+    """TranscriptionUtilities.mergeTranscriptionResults, Utilities/TranscriptionUtilities.swift:76-157.  A result is a dict
+    {text, segments, language, timings: {...}, seekTime}; timings keys follow wh_timings' snake_case names."""
+    text = "".join(confirmedWords) if confirmedWords is not None else " ".join((r["text"] if r else "") for r in results)
+    valid = [r for r in results if r is not None]
+    segments = []
+    for ri, r in enumerate(valid):
+        for si, g in enumerate(r["segments"]):
+            segments.append(dataclasses.replace(g, id=ri + si))
+    language = valid[0]["language"] if valid else "en"
+    T = [r["timings"] for r in valid]
+    g = lambda k: [t.get(k, 0.0) for t in T]
+    earliestStart = min(g("pipeline_start")) if T else 0.0
+    earliestToken = min(g("first_token_time")) if T else 0.0
+    latestEnd = max((t.get("pipeline_start", 0.0) + t.get("full_pipeline", 0.0)) for t in T) if T else 0.0
+    merged = {}
+    for k in ("model_loading", "prewarm_load_time", "encoder_load_time", "decoder_load_time", "tokenizer_load_time"):
+        merged[k] = max(g(k)) if T else 0.0
+    for k in ("audio_loading", "audio_processing", "logmels", "encoding", "decoding_init", "decoding_loop", "decoding_predictions",
+              "decoding_filtering", "decoding_sampling", "decoding_fallback", "decoding_windowing", "decoding_kv_caching",
+              "decoding_word_timestamps", "decoding_non_prediction", "total_audio_processing_runs", "total_logmel_runs",
+              "total_encoding_runs", "total_decoding_loops", "total_kv_update_runs", "total_timestamp_alignment_runs",
+              "total_decoding_fallbacks", "total_decoding_windows", "input_audio_seconds"):
+        merged[k] = sum(g(k))
+    merged["full_pipeline"] = min(latestEnd - earliestStart, sum(g("full_pipeline")))
+    merged["pipeline_start"] = earliestStart
+    merged["first_token_time"] = earliestToken
+    return {"text": text, "segments": segments, "language": language, "timings": merged, "seekTime": None}
+
+
+# ----------------------------------------------------------------------------- audio ingest
+def convert_to_mono(channels: np.ndarray, mode: str = "sumChannels", indices: Optional[Sequence[int]] = None) -> np.ndarray:
+    """AudioProcessor.convertToMono, Core/Audio/AudioProcessor.swift:525-625 (vDSP float32: sum in channel order, then scale by
+    maxOriginalPeak / max(monoPeak, 1e-4))."""
+    x = np.asarray(channels, dtype=np.float32)
+    n = x.shape[0]
+    if n <= 1:
+        return x[0].copy()
+    if mode == "specificChannel":
+        c = indices[0] if indices else 0
+        return x[c if 0 <= c < n else 0].copy()
+    sel = [c for c in indices if 0 <= c < n] if indices else list(range(n))
+    if indices and not sel:
+        return x[0].copy()
+    peak = np.float32(max(np.abs(x[c]).max() if x.shape[1] else 0.0 for c in sel))
+    mono = np.zeros(x.shape[1], np.float32)
+    for c in sel:
+        mono = (mono + x[c]).astype(np.float32)
+    monoPeak = np.float32(np.abs(mono).max() if len(mono) else 0.0)
+    scale = np.float32(peak / max(monoPeak, np.float32(0.0001)))
+    return (mono * scale).astype(np.float32)
+
+
+def load_wav_16k_mono(path: str, startTime: float = 0.0, endTime: Optional[float] = None) -> np.ndarray:
+    """AudioProcessor.loadAudio for the directly readable case (16 kHz mono PCM16 WAV, Core/Audio/AudioProcessor.swift:262-274):
+    frames [Int(start*rate), min(Int(end*rate), length)) scaled by 1/32768 (AVAudioFile .pcmFormatFloat32)."""
+    import wave
+    with wave.open(path, "rb") as w:
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        n = w.getnframes()
+        pcm = np.frombuffer(w.readframes(n), dtype="<i2")
+    a = int(startTime * 16000)
+    b = n if endTime is None else min(int(endTime * 16000), n)
+    return (pcm[a:b].astype(np.float32) / np.float32(32768.0)).astype(np.float32)

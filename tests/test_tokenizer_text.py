@@ -1,0 +1,248 @@
+"""Tokenizer text side of the path: oracle restatement pinned to the reference's own known-answer
+tests, cross-checked against the HF `tokenizers` library, and the native implementation behind the C ABI compared with the oracle.
+All host logic: runs without a GPU."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import tokenizer as otok
+from whisperkit_amd import synth
+
+
+@pytest.fixture(scope="module")
+def tok_dirs(tmp_path_factory):
+    out = {}
+    for n in (51864, 51865, 51866):
+        d = tmp_path_factory.mktemp(f"tok{n}")
+        synth.write_kat_tokenizer(str(d), n)
+        out[n] = str(d)
+    return out
+
+
+@pytest.fixture(scope="module")
+def otoks(tok_dirs):
+    return {n: otok.Tokenizer(os.path.join(d, "tokenizer.json")) for n, d in tok_dirs.items()}
+
+
+# ---------------------------------------------------------------------------------------------- reference KATs on the oracle
+def test_kat_tokenizer_output(otoks):
+    """UnitTests.swift:1288-1297 testTokenizerOutput (large-v3 vocabulary)."""
+    ids = [50364, 400, 370, 452, 7177, 6280, 1029, 406, 437, 428, 1941, 393, 360, 337, 291, 1029, 437, 291, 393, 360, 337, 428,
+           1941, 13, 50889]
+    assert otoks[51866].decode(ids) == ("<|notimestamps|> And so my fellow Americans ask not what your country can do for you "
+                                        "ask what you can do for your country.<|10.48|>")
+
+
+def test_kat_split_to_word_tokens_english(otoks):
+    """UnitTests.swift:1326-1341 testSplitToWordTokens."""
+    ids = [50364, 2425, 11, 1002, 0, 50414, 50414, 639, 307, 257, 220, 31636, 11, 1943, 380, 309, 30, 50257]
+    words, wt = otoks[51865].splitToWordTokens(ids, "en")
+    assert words == ["<|0.00|>", " Hello", ",", " world", "!", "<|1.00|>", "<|1.00|>", " This", " is", " a", " test", ",", " isn't",
+                     " it", "?", "<|endoftext|>"]
+    assert wt == [[50364], [2425], [11], [1002], [0], [50414], [50414], [639], [307], [257], [220, 31636], [11], [1943, 380], [309],
+                  [30], [50257]]
+    assert words != [otoks[51865].convertIdToToken(i) for i in ids]
+
+
+def test_kat_split_to_word_tokens_spanish(otoks):
+    """UnitTests.swift:1343-1358 testSplitToWordTokensSpanish."""
+    ids = [50363, 24364, 48529, 376, 6043, 0, 20547, 785, 2002, 48241, 11, 3841, 1771, 30, 50257]
+    words, wt = otoks[51865].splitToWordTokens(ids, "es")
+    assert words == ["<|notimestamps|>", "¡Hola", " Mundo", "!", " Esta", " es", " una", " prueba", ",", " ¿no", "?", "<|endoftext|>"]
+    assert wt == [[50363], [24364, 48529], [376, 6043], [0], [20547], [785], [2002], [48241], [11], [3841, 1771], [30], [50257]]
+
+
+def test_kat_split_to_word_tokens_japanese(otoks):
+    """UnitTests.swift:1360-1375 testSplitToWordTokensJapanese (unicode splitter: raw byte tokens regroup into characters)."""
+    ids = [50364, 38088, 1231, 24486, 171, 120, 223, 25212, 22985, 40498, 4767, 30346, 171, 120, 253, 50257]
+    words, wt = otoks[51865].splitToWordTokens(ids, "ja")
+    assert words == ["<|0.00|>", "こんにちは", "、", "世界", "！", "これは", "テ", "スト", "です", "よね", "？", "<|endoftext|>"]
+    assert wt == [[50364], [38088], [1231], [24486], [171, 120, 223], [25212], [22985], [40498], [4767], [30346], [171, 120, 253],
+                  [50257]]
+
+
+def test_special_tokens_from_vocabulary(otoks):
+    """WhisperTokenizerWrapper.init (Core/Models.swift:1198-1224): ids looked up by token text equal the ids the decoder oracle
+    derives from the vocabulary size; multilingual ids equal the reference defaults (:1309-1322)."""
+    from oracle import decode as od
+    for n, t in otoks.items():
+        st, langs = od.special_tokens_for_vocab(n)
+        assert t.specialTokens() == st
+        assert t.allLanguageTokens(synth.LANGUAGE_CODES) == set(langs)
+    assert otoks[51865].specialTokens() == od.SpecialTokens()
+    assert otok.trimming_special_token_characters(otoks[51865].decode([50357])) == "su"
+
+
+def test_oracle_decode_matches_hf_tokenizers(tok_dirs, otoks):
+    """The HF `tokenizers` library (what swift-transformers mirrors) decodes the same ids to the same text; it has no cleanUp
+    step (that lives in transformers / Tokenizer.swift:433-449), so compare against the oracle with cleanUp disabled, and it
+    treats a run across an added token as one byte string - equal unless an added token splits a broken UTF-8 sequence."""
+    hf = pytest.importorskip("tokenizers")
+    for n in (51865, 51864):
+        t = hf.Tokenizer.from_file(os.path.join(tok_dirs[n], "tokenizer.json"))
+        o = otoks[n]
+        rng = random.Random(n)
+        keep = o.clean_up
+        o.clean_up = False
+        try:
+            for trial in range(300):
+                ids = [rng.randrange(0, n) if rng.random() < 0.9 else rng.randrange(0, 256) for _ in range(rng.randrange(1, 40))]
+                want = t.decode(ids, skip_special_tokens=False)
+                got = o.decode(ids)
+                if got != want:      # only allowed around an added token that cuts an incomplete multi-byte sequence
+                    assert any(i in o.special_ids for i in ids) and otok.REPLACEMENT in got, (ids, got, want)
+                assert o.decode(ids, skipSpecialTokens=True) == \
+                    (lambda s: s)(o.decode([i for i in ids if i not in o.special_ids]))
+        finally:
+            o.clean_up = keep
+
+
+def test_clean_up_tokenization_spaces(otoks):
+    """Tokenizer.swift:433-449: the ten literal replacements, applied in order, only when the tokenizer config asks for it."""
+    o = otoks[51865]
+    assert o.cleanUp("we 're here , ok ? yes ! it 's . i 'm , they 've , is n't") == "we're here, ok? yes! it's. i'm, they've, isn't"
+    assert o.cleanUp("a ' b") == "a'b"
+    ids = [2425, 220, 11, 1002, 220, 0]                       # " Hello" " " "," " world" " " "!"
+    assert o.decode(ids) == " Hello, world!"
+    o.clean_up = False
+    try:
+        assert o.decode(ids) == " Hello , world !"
+    finally:
+        o.clean_up = True
+
+
+# ---------------------------------------------------------------------------------------------- native (C ABI) vs oracle
+from whisperkit_amd import api   # noqa: E402  (host-only entry points: no GPU needed)
+from oracle import decode as od  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ntoks(tok_dirs):
+    return {n: api.Tokenizer(os.path.join(d, "tokenizer.json")) for n, d in tok_dirs.items()}
+
+
+def _random_ids(rng, n_vocab, length):
+    out = []
+    for _ in range(length):
+        r = rng.random()
+        if r < 0.15:
+            out.append(rng.randrange(0, 256))                 # raw byte tokens: broken UTF-8 runs
+        elif r < 0.25:
+            out.append(rng.randrange(n_vocab - 1600, n_vocab))  # specials / timestamps
+        elif r < 0.3:
+            out.append(rng.choice([11, 13, 0, 30, 220, 1231]))  # punctuation, space
+        else:
+            out.append(rng.randrange(256, n_vocab - 1600))
+    return out
+
+
+def test_native_reference_kats(ntoks):
+    """The same four reference KATs through the C ABI."""
+    t = ntoks[51866]
+    assert t.decode([50364, 400, 370, 452, 7177, 6280, 1029, 406, 437, 428, 1941, 393, 360, 337, 291, 1029, 437, 291, 393, 360, 337, 428,
+                     1941, 13, 50889]) == ("<|notimestamps|> And so my fellow Americans ask not what your country can do for you "
+                                           "ask what you can do for your country.<|10.48|>")
+    t = ntoks[51865]
+    w, wt = t.splitToWordTokens([50364, 2425, 11, 1002, 0, 50414, 50414, 639, 307, 257, 220, 31636, 11, 1943, 380, 309, 30, 50257], "en")
+    assert w == ["<|0.00|>", " Hello", ",", " world", "!", "<|1.00|>", "<|1.00|>", " This", " is", " a", " test", ",", " isn't", " it", "?",
+                 "<|endoftext|>"]
+    assert wt[10] == [220, 31636] and wt[12] == [1943, 380]
+    w, wt = t.splitToWordTokens([50363, 24364, 48529, 376, 6043, 0, 20547, 785, 2002, 48241, 11, 3841, 1771, 30, 50257], "es")
+    assert w == ["<|notimestamps|>", "¡Hola", " Mundo", "!", " Esta", " es", " una", " prueba", ",", " ¿no", "?", "<|endoftext|>"]
+    w, wt = t.splitToWordTokens([50364, 38088, 1231, 24486, 171, 120, 223, 25212, 22985, 40498, 4767, 30346, 171, 120, 253, 50257], "ja")
+    assert w == ["<|0.00|>", "こんにちは", "、", "世界", "！", "これは", "テ", "スト", "です", "よね", "？", "<|endoftext|>"]
+    assert wt[4] == [171, 120, 223]
+
+
+@pytest.mark.parametrize("n_vocab", [51864, 51865, 51866])
+def test_native_decode_and_special_tokens_equal_oracle(ntoks, otoks, n_vocab):
+    n, o = ntoks[n_vocab], otoks[n_vocab]
+    st = o.specialTokens()
+    c = n.specialTokens
+    assert (c.end_token, c.english_token, c.no_speech_token, c.no_timestamps_token, c.special_token_begin, c.start_of_previous_token,
+            c.start_of_transcript_token, c.time_token_begin, c.transcribe_token, c.translate_token, c.whitespace_token) == \
+        (st.endToken, st.englishToken, st.noSpeechToken, st.noTimestampsToken, st.specialTokenBegin, st.startOfPreviousToken,
+         st.startOfTranscriptToken, st.timeTokenBegin, st.transcribeToken, st.translateToken, st.whitespaceToken)
+    langs = sorted(o.allLanguageTokens(synth.LANGUAGE_CODES))
+    assert (c.language_token_begin, c.n_language_tokens) == (langs[0], len(langs))
+    assert n.vocabSize == n_vocab
+    assert n.convertTokenToId("<|startoftranscript|>") == st.startOfTranscriptToken and n.convertTokenToId("nope-not-a-token") is None
+    assert n.convertIdToToken(st.endToken) == "<|endoftext|>" and n.convertIdToToken(n_vocab + 5) is None
+    rng = random.Random(7 + n_vocab)
+    for trial in range(400):
+        ids = _random_ids(rng, n_vocab, rng.randrange(0, 48)) + ([n_vocab + 3] if trial % 50 == 0 else [])   # unknown id is dropped
+        assert n.decode(ids) == o.decode(ids), ids
+        assert n.decode(ids, skipSpecialTokens=True) == o.decode(ids, skipSpecialTokens=True), ids
+
+
+@pytest.mark.parametrize("language", ["en", "ja", "zh", "de"])
+def test_native_split_to_word_tokens_equals_oracle(ntoks, otoks, language):
+    n, o = ntoks[51865], otoks[51865]
+    rng = random.Random(sum(map(ord, language)))
+    for trial in range(150):
+        ids = _random_ids(rng, 51865, rng.randrange(0, 60))
+        assert n.splitToWordTokens(ids, language) == tuple(o.splitToWordTokens(ids, language)), ids
+
+
+def _window(rng, st, n_text=40, n_segments=3):
+    """A decoded window the way findSeekPointAndSegments slices it: [<|t0|> text.. <|t1|>][<|t1|> text.. <|t2|>]..."""
+    tb = st.timeTokenBegin
+    times = sorted(rng.sample(range(0, 1400, 2), n_segments + 1))
+    segs, tokens, lps = [], [], []
+    for s in range(n_segments):
+        toks = [tb + times[s]]
+        for _ in range(rng.randrange(1, n_text // n_segments + 2)):
+            r = rng.random()
+            toks.append(rng.choice([11, 13, 0, 30, 220, 1231, 6, 7, 1]) if r < 0.25 else rng.randrange(256, 50000))
+        toks.append(tb + times[s + 1])
+        lp = [-rng.random() * 2 for _ in toks]
+        segs.append(od.TranscriptionSegment(id=s, seek=0, start=times[s] * 0.02, end=times[s + 1] * 0.02, text="", tokens=toks,
+                                            tokenLogProbs=[{t: l} for t, l in zip(toks, lp)], temperature=0.0, avgLogprob=-0.3,
+                                            compressionRatio=1.2, noSpeechProb=0.0))
+        tokens += toks
+        lps += lp
+    return segs, tokens, lps
+
+
+def _alignment(rng_np, n_rows):
+    """Cross-attention-like matrix: noise plus a monotone ridge with random speed (so words get uneven durations)."""
+    a = rng_np.random((n_rows, 1500)).astype(np.float32) * 0.2
+    pos = np.sort(rng_np.integers(0, 1500, n_rows))
+    for r in range(n_rows):
+        lo, hi = max(0, pos[r] - 3), min(1500, pos[r] + 4)
+        a[r, lo:hi] += 1.0
+    return a
+
+
+@pytest.mark.parametrize("language", ["en", "ja"])
+def test_native_add_word_timestamps_equals_oracle(ntoks, otoks, language):
+    """SegmentSeeker.addWordTimestamps end to end (DTW, word grouping, duration constraints, punctuation merge,
+    updateSegmentsWithWordTimings) on random windows: native C++ against the oracle, Float for Float."""
+    n, o = ntoks[51865], otoks[51865]
+    st = o.specialTokens()
+    rng = random.Random(11)
+    rng_np = np.random.default_rng(5)
+    compared = 0
+    for trial in range(60):
+        osegs, tokens, lps = _window(rng, st, n_text=rng.randrange(6, 60), n_segments=rng.randrange(1, 5))
+        seek = rng.choice([0, 160000, 480000 * 3 + 3200])
+        last = float(np.float32(seek) / np.float32(16000))
+        align = _alignment(rng_np, len(tokens))
+        want = od.add_word_timestamps(osegs, align, lambda ids: o.splitToWordTokens(ids, language), o.decode, seek, last, st.specialTokenBegin)
+        asegs = [api.TranscriptionSegment(g.id, g.seek, g.start, g.end, g.tokens, [lp[t] for lp, t in zip(g.tokenLogProbs, g.tokens)],
+                                          g.temperature, g.avgLogprob, g.compressionRatio, g.noSpeechProb, []) for g in osegs]
+        got = api.addWordTimestamps(asegs, np.vstack([align, np.zeros((224 - len(align), 1500), np.float32)]) if len(align) < 224 else align,
+                                    n, seek, last, language)
+        assert len(got.segments) == len(want)
+        for g, w in zip(got.segments, want):
+            assert np.float32(g.start) == np.float32(w.start) and np.float32(g.end) == np.float32(w.end), (trial, g, w)
+            assert [x.word for x in g.words] == [x.word for x in w.words], trial
+            assert [x.tokens for x in g.words] == [x.tokens for x in w.words], trial
+            for x, y in zip(g.words, w.words):
+                assert np.float32(x.start) == np.float32(y.start) and np.float32(x.end) == np.float32(y.end), (trial, x, y)
+                assert abs(x.probability - y.probability) <= 0.0101, (trial, x, y)      # expf vs np.exp at a .5 rounding edge
+                compared += 1
+            assert g.text == o.decode(w.tokens)
+    assert compared > 250

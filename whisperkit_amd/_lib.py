@@ -67,7 +67,10 @@ class WhTimings(C.Structure):
         "audio_processing", "logmels", "encoding", "decoding_init", "decoding_predictions", "decoding_filtering",
         "decoding_sampling", "decoding_kv_caching", "decoding_word_timestamps", "decoding_fallback", "decoding_windowing",
         "decoding_loop", "full_pipeline", "input_audio_seconds", "total_decoding_loops", "total_decoding_windows",
-        "total_decoding_fallbacks", "total_encoding_runs", "total_logmel_runs")]
+        "total_decoding_fallbacks", "total_encoding_runs", "total_logmel_runs",
+        "pipeline_start", "first_token_time", "model_loading", "prewarm_load_time", "encoder_load_time", "decoder_load_time",
+        "encoder_specialization_time", "decoder_specialization_time", "tokenizer_load_time", "audio_loading",
+        "decoding_non_prediction", "total_audio_processing_runs", "total_kv_update_runs", "total_timestamp_alignment_runs")]
 
 
 # every symbol include/whisperhip.h declares: (restype, argtypes)
@@ -122,6 +125,34 @@ SYMBOLS = {
     "wh_transcription_language_token": (I, [VP]),
     "wh_transcription_timings": (I, [VP, C.POINTER(WhTimings)]),
     "wh_transcription_window_seeks": (I, [VP, C.POINTER(PI32), C.POINTER(I)]),
+    # tokenizer text, result assembly, formats, audio ingest (host only)
+    "wh_tokenizer_load": (I, [C.c_char_p, PVP]),
+    "wh_tokenizer_destroy": (None, [VP]),
+    "wh_tokenizer_vocab_size": (I, [VP]),
+    "wh_tokenizer_decode": (I, [VP, PI32, I, I, C.c_char_p, I]),
+    "wh_tokenizer_token_to_id": (I, [VP, C.c_char_p]),
+    "wh_tokenizer_id_to_token": (I, [VP, I, C.c_char_p, I]),
+    "wh_tokenizer_special_tokens": (I, [VP, PST]),
+    "wh_tokenizer_split_to_word_tokens": (I, [VP, PI32, I, C.c_char_p, PI32, PI32, I, C.c_char_p, I, C.POINTER(I)]),
+    "wh_session_set_tokenizer": (I, [VP, VP]),
+    "wh_transcription_has_text": (I, [VP]),
+    "wh_transcription_text": (I, [VP, C.c_char_p, I]),
+    "wh_transcription_language": (I, [VP, C.c_char_p, I]),
+    "wh_transcription_segment_text": (I, [VP, I, C.c_char_p, I]),
+    "wh_transcription_word_text": (I, [VP, I, C.c_char_p, I]),
+    "wh_transcription_word_tokens": (I, [VP, C.POINTER(PI32), C.POINTER(I)]),
+    "wh_transcription_seek_time": (I, [VP, PF]),
+    "wh_add_word_timestamps": (I, [VP, C.c_char_p, PST, C.POINTER(WhSegment), I, PI32, PF, I, PF, I, I, F, I, PVP]),
+    "wh_transcription_create": (I, [VP, PST, C.POINTER(WhSegment), I, PI32, PF, I, I, I, F, C.POINTER(WhTimings), PVP]),
+    "wh_merge_transcriptions": (I, [PVP, I, C.POINTER(C.c_char_p), I, PVP]),
+    "wh_format_time": (I, [F, I, C.c_char, C.c_char_p, I]),
+    "wh_write_srt": (I, [VP, C.c_char_p]),
+    "wh_write_vtt": (I, [VP, C.c_char_p]),
+    "wh_write_json": (I, [VP, C.c_char_p]),
+    "wh_convert_to_mono": (I, [PVP, I, I, I, PI32, I, PF]),
+    "wh_resample": (I, [PF, I, C.c_double, C.c_double, PF, I]),
+    "wh_load_audio": (I, [C.c_char_p, I, PI32, I, C.c_double, C.c_double, I, C.POINTER(PF), C.POINTER(I)]),
+    "wh_audio_free": (None, [PF]),
     "wh_compression_ratio": (F, [PI32, I]),
     "wh_dynamic_time_warping": (I, [PF, I, I, PI32, PI32, I]),
     "wh_decoding_fallback": (I, [POPT, I, F, F, F, PI32]),

@@ -16,7 +16,8 @@ from __future__ import annotations
 import ctypes as C
 import dataclasses
 import math
-from typing import List, Optional, Sequence
+import weakref
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -139,6 +140,7 @@ class WordTiming:
     start: float
     end: float
     probability: float
+    word: str = ""          # filled when a tokenizer is attached
 
 
 @dataclasses.dataclass
@@ -154,6 +156,7 @@ class TranscriptionSegment:
     compressionRatio: float
     noSpeechProb: float
     words: List[WordTiming]
+    text: str = ""          # filled when a tokenizer is attached
 
 
 @dataclasses.dataclass
@@ -163,6 +166,121 @@ class TranscriptionResult:
     languageToken: int
     timings: dict
     seeks: List[int]
+    text: Optional[str] = None        # None without a tokenizer
+    language: Optional[str] = None
+    seekTime: Optional[float] = None
+    _handle: object = dataclasses.field(default=None, repr=False, compare=False)   # the C object, freed with this result
+
+    # ResultWriting (Utilities/ResultWriter.swift:40-134); `path` is the full file name
+    def writeSRT(self, path: str):
+        _check(L.load().wh_write_srt(self._handle, path.encode()))
+
+    def writeVTT(self, path: str):
+        _check(L.load().wh_write_vtt(self._handle, path.encode()))
+
+    def writeJSON(self, path: str):
+        _check(L.load().wh_write_json(self._handle, path.encode()))
+
+    @property
+    def allWords(self) -> List[WordTiming]:
+        return [w for g in self.segments for w in g.words]
+
+
+def _string(fn, *args) -> str:
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise WhisperError(100, L.load().wh_last_error().decode())
+    buf = C.create_string_buffer(n + 1)
+    fn(*args, buf, n + 1)
+    return buf.raw[:n].decode("utf-8")
+
+
+def _collect(h) -> TranscriptionResult:
+    """Copies a wh_transcription into the Python mirror types; the result keeps the C object alive for the writers / merge."""
+    lib = L.load()
+    h = C.c_void_p(h) if not isinstance(h, C.c_void_p) else h
+    tp, lp, n = L.PI32(), L.PF(), C.c_int()
+    _check(lib.wh_transcription_tokens(h, C.byref(tp), C.byref(lp), C.byref(n)))
+    toks = [tp[i] for i in range(n.value)]
+    lps = [lp[i] for i in range(n.value)]
+    wp, wn = L.PI32(), C.c_int()
+    _check(lib.wh_transcription_word_tokens(h, C.byref(wp), C.byref(wn)))
+    wtoks = [wp[i] for i in range(wn.value)]
+    has_text = bool(lib.wh_transcription_has_text(h))
+    words = []
+    for i in range(lib.wh_transcription_n_words(h)):
+        w = L.WhWordTiming()
+        _check(lib.wh_transcription_word(h, i, C.byref(w)))
+        words.append(WordTiming(wtoks[w.token_offset:w.token_offset + w.n_tokens], w.start, w.end, w.probability,
+                                _string(lib.wh_transcription_word_text, h, i) if has_text else ""))
+    segs = []
+    for i in range(lib.wh_transcription_n_segments(h)):
+        g = L.WhSegment()
+        _check(lib.wh_transcription_segment(h, i, C.byref(g)))
+        segs.append(TranscriptionSegment(g.id, g.seek, g.start, g.end, toks[g.token_offset:g.token_offset + g.n_tokens],
+                                         lps[g.token_offset:g.token_offset + g.n_tokens], g.temperature, g.avg_logprob,
+                                         g.compression_ratio, g.no_speech_prob, words[g.word_offset:g.word_offset + g.n_words],
+                                         _string(lib.wh_transcription_segment_text, h, i) if has_text else ""))
+    t = L.WhTimings()
+    _check(lib.wh_transcription_timings(h, C.byref(t)))
+    sp, sn = L.PI32(), C.c_int()
+    _check(lib.wh_transcription_window_seeks(h, C.byref(sp), C.byref(sn)))
+    sk = C.c_float()
+    has_seek = lib.wh_transcription_seek_time(h, C.byref(sk))
+    res = TranscriptionResult(segs, toks, lib.wh_transcription_language_token(h),
+                              {k: getattr(t, k) for k, _ in L.WhTimings._fields_}, [sp[i] for i in range(sn.value)],
+                              _string(lib.wh_transcription_text, h) if has_text else None,
+                              _string(lib.wh_transcription_language, h) if has_text else None,
+                              sk.value if has_seek else None, h)
+    weakref.finalize(res, lib.wh_transcription_free, h)
+    return res
+
+
+class Tokenizer:
+    """WhisperTokenizer (Core/Models.swift:1150-1307) loaded from a HF `tokenizer.json` (ModelUtilities.loadTokenizer)."""
+
+    def __init__(self, tokenizerJsonPath: str):
+        self.lib = L.load()
+        self.handle = C.c_void_p()
+        _check(self.lib.wh_tokenizer_load(tokenizerJsonPath.encode(), C.byref(self.handle)))
+        st = L.WhSpecialTokens()
+        _check(self.lib.wh_tokenizer_special_tokens(self.handle, C.byref(st)))
+        self.specialTokens = st
+        weakref.finalize(self, self.lib.wh_tokenizer_destroy, self.handle)
+
+    vocabSize = property(lambda s: s.lib.wh_tokenizer_vocab_size(s.handle))
+
+    def decode(self, tokens: Sequence[int], skipSpecialTokens: bool = False) -> str:
+        a = np.ascontiguousarray(list(tokens), dtype=np.int32)
+        return _string(self.lib.wh_tokenizer_decode, self.handle, a.ctypes.data_as(L.PI32), len(a), int(skipSpecialTokens))
+
+    def convertTokenToId(self, token: str) -> Optional[int]:
+        i = self.lib.wh_tokenizer_token_to_id(self.handle, token.encode("utf-8"))
+        return None if i < 0 else i
+
+    def convertIdToToken(self, i: int) -> Optional[str]:
+        if self.lib.wh_tokenizer_id_to_token(self.handle, i, None, 0) < 0:
+            return None
+        return _string(self.lib.wh_tokenizer_id_to_token, self.handle, i)
+
+    def splitToWordTokens(self, tokenIds: Sequence[int], language: str = "en") -> Tuple[List[str], List[List[int]]]:
+        a = np.ascontiguousarray(list(tokenIds), dtype=np.int32)
+        nb = C.c_int()
+        nw = self.lib.wh_tokenizer_split_to_word_tokens(self.handle, a.ctypes.data_as(L.PI32), len(a), language.encode(), None, None, 0, None, 0, C.byref(nb))
+        if nw < 0:
+            raise WhisperError(100, self.lib.wh_last_error().decode())
+        counts, lens = (C.c_int32 * max(nw, 1))(), (C.c_int32 * max(nw, 1))()
+        buf = C.create_string_buffer(max(nb.value, 1))
+        self.lib.wh_tokenizer_split_to_word_tokens(self.handle, a.ctypes.data_as(L.PI32), len(a), language.encode(), counts, lens, nw, buf, nb.value, C.byref(nb))
+        words, pos = [], 0
+        for i in range(nw):
+            words.append(buf.raw[pos:pos + lens[i]].decode("utf-8"))
+            pos += lens[i]
+        wt, off = [], 0
+        for i in range(nw):
+            wt.append([int(x) for x in a[off:off + counts[i]]])
+            off += counts[i]
+        return words, wt
 
 
 class Model:
@@ -233,6 +351,11 @@ class Session:
 
     def synchronize(self):
         _check(self.lib.wh_session_synchronize(self.handle))
+
+    def setTokenizer(self, tokenizer: Optional["Tokenizer"]):
+        """TextDecoding.tokenizer (Core/TextDecoder.swift:61): transcribe results gain text, real word grouping, language code."""
+        self.tokenizer = tokenizer      # keep it alive
+        _check(self.lib.wh_session_set_tokenizer(self.handle, tokenizer.handle if tokenizer is not None else None))
 
     # ---- AudioProcessing.padOrTrimAudio
     def padOrTrim(self, audio, slot: int = 0):
@@ -343,11 +466,7 @@ class Session:
         lens = (C.c_int32 * n)(*[len(a) for a in arrs])
         outs = (C.c_void_p * n)()
         _check(self.lib.wh_transcribe_batch(self.handle, ptrs, lens, n, C.byref(o), C.byref(st), outs))
-        results = []
-        for h in outs:
-            results.append(self._collect(h))
-            self.lib.wh_transcription_free(h)
-        return results
+        return [_collect(h) for h in outs]
 
     def transcribeChunked(self, audioArray: np.ndarray, options: Optional[DecodingOptions] = None, specialTokens=None):
         """WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): returns
@@ -360,38 +479,7 @@ class Session:
         seeks = (C.c_int32 * cap)()
         n = C.c_int()
         _check(self.lib.wh_transcribe_chunked(self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n)))
-        results = []
-        for i in range(n.value):
-            results.append((int(seeks[i]), self._collect(outs[i])))
-            self.lib.wh_transcription_free(outs[i])
-        return results
-
-    def _collect(self, h) -> TranscriptionResult:
-        lib = self.lib
-        tp, lp, n = L.PI32(), L.PF(), C.c_int()
-        _check(lib.wh_transcription_tokens(h, C.byref(tp), C.byref(lp), C.byref(n)))
-        toks = [tp[i] for i in range(n.value)]
-        lps = [lp[i] for i in range(n.value)]
-        words = []
-        for i in range(lib.wh_transcription_n_words(h)):
-            w = L.WhWordTiming()
-            _check(lib.wh_transcription_word(h, i, C.byref(w)))
-            words.append(w)
-        segs = []
-        for i in range(lib.wh_transcription_n_segments(h)):
-            g = L.WhSegment()
-            _check(lib.wh_transcription_segment(h, i, C.byref(g)))
-            ws = [WordTiming(toks[w.token_offset:w.token_offset + w.n_tokens], w.start, w.end, w.probability)
-                  for w in words[g.word_offset:g.word_offset + g.n_words]]
-            segs.append(TranscriptionSegment(g.id, g.seek, g.start, g.end, toks[g.token_offset:g.token_offset + g.n_tokens],
-                                             lps[g.token_offset:g.token_offset + g.n_tokens], g.temperature, g.avg_logprob,
-                                             g.compression_ratio, g.no_speech_prob, ws))
-        t = L.WhTimings()
-        _check(lib.wh_transcription_timings(h, C.byref(t)))
-        sp, sn = L.PI32(), C.c_int()
-        _check(lib.wh_transcription_window_seeks(h, C.byref(sp), C.byref(sn)))
-        return TranscriptionResult(segs, toks, lib.wh_transcription_language_token(h),
-                                   {k: getattr(t, k) for k, _ in L.WhTimings._fields_}, [sp[i] for i in range(sn.value)])
+        return [(int(seeks[i]), _collect(outs[i])) for i in range(n.value)]
 
 
 # ---- host utilities (no GPU needed) ---------------------------------------------------------------
@@ -453,3 +541,100 @@ def findSeekPointAndSegments(tokens: Sequence[int], logprobs: Sequence[float], o
     n = L.load().wh_find_seek_point_and_segments(C.byref(r), C.byref(o), C.byref(specialTokens), allSegmentsCount, currentSeek,
                                                  segmentSize, C.byref(seek), segs, L.WH_MAX_RESULT_TOKENS)
     return seek.value, (None if n < 0 else [segs[i] for i in range(n)])
+
+
+# ---- tokenizer text / result assembly / audio ingest (host only) ----------------------------------
+def _segments_to_c(segments: Sequence[TranscriptionSegment]):
+    """Flattens mirror segments into (WhSegment[], tokens int32[], logprobs float32[])."""
+    segs = (L.WhSegment * max(len(segments), 1))()
+    toks, lps = [], []
+    for i, g in enumerate(segments):
+        c = segs[i]
+        c.id, c.seek, c.start, c.end = g.id, g.seek, g.start, g.end
+        c.token_offset, c.n_tokens = len(toks), len(g.tokens)
+        c.temperature, c.avg_logprob, c.compression_ratio, c.no_speech_prob = g.temperature, g.avgLogprob, g.compressionRatio, g.noSpeechProb
+        toks += list(g.tokens)
+        lps += list(g.tokenLogProbs)
+    return segs, np.ascontiguousarray(toks, dtype=np.int32), np.ascontiguousarray(lps, dtype=np.float32)
+
+
+def addWordTimestamps(segments: Sequence[TranscriptionSegment], alignmentWeights: np.ndarray, tokenizer: Tokenizer, seek: int,
+                      lastSpeechTimestamp: float, language: str = "en", skipSpecialTokens: bool = False) -> TranscriptionResult:
+    """SegmentSeeker.addWordTimestamps (Core/Text/SegmentSeeker.swift:410-496) on one window's segments; row r of
+    `alignmentWeights` belongs to the r-th token of the segments in order."""
+    segs, toks, lps = _segments_to_c(segments)
+    a = np.ascontiguousarray(alignmentWeights, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == L.AUDIO_CTX
+    out = C.c_void_p()
+    _check(L.load().wh_add_word_timestamps(tokenizer.handle, language.encode(), C.byref(tokenizer.specialTokens), segs, len(segments),
+                                           toks.ctypes.data_as(L.PI32), lps.ctypes.data_as(L.PF), len(toks), a.ctypes.data_as(L.PF), a.shape[0],
+                                           seek, lastSpeechTimestamp, int(skipSpecialTokens), C.byref(out)))
+    return _collect(out)
+
+
+def makeTranscriptionResult(segments: Sequence[TranscriptionSegment], tokenizer: Optional[Tokenizer], specialTokens=None,
+                            languageToken: int = -1, skipSpecialTokens: bool = False, seekTime: Optional[float] = None,
+                            timings: Optional[dict] = None) -> TranscriptionResult:
+    """TranscriptionResult(text:segments:language:timings:seekTime:) assembled by the library from segments."""
+    segs, toks, lps = _segments_to_c(segments)
+    st = specialTokens if specialTokens is not None else tokenizer.specialTokens
+    t = L.WhTimings()
+    for k, v in (timings or {}).items():
+        setattr(t, k, v)
+    out = C.c_void_p()
+    _check(L.load().wh_transcription_create(tokenizer.handle if tokenizer else None, C.byref(st), segs, len(segments),
+                                            toks.ctypes.data_as(L.PI32), lps.ctypes.data_as(L.PF), len(toks), languageToken,
+                                            int(skipSpecialTokens), float("nan") if seekTime is None else seekTime, C.byref(t), C.byref(out)))
+    return _collect(out)
+
+
+def mergeTranscriptionResults(results: Sequence[Optional[TranscriptionResult]], confirmedWords: Optional[Sequence[str]] = None) -> TranscriptionResult:
+    """TranscriptionUtilities.mergeTranscriptionResults (Utilities/TranscriptionUtilities.swift:76-157)."""
+    hs = (C.c_void_p * max(len(results), 1))(*[r._handle if r is not None else None for r in results])
+    cw, ncw = None, 0
+    if confirmedWords is not None:
+        ncw = len(confirmedWords)
+        cw = (C.c_char_p * max(ncw, 1))(*[w.encode("utf-8") for w in confirmedWords])
+    out = C.c_void_p()
+    _check(L.load().wh_merge_transcriptions(hs, len(results), cw, ncw, C.byref(out)))
+    return _collect(out)
+
+
+def formatTime(seconds: float, alwaysIncludeHours: bool, decimalMarker: str) -> str:
+    """ResultWriting.formatTime (Utilities/ResultWriter.swift:14-26)."""
+    return _string(L.load().wh_format_time, seconds, int(alwaysIncludeHours), decimalMarker.encode()[:1])
+
+
+def convertToMono(channels: np.ndarray, mode: str = "sumChannels", indices: Optional[Sequence[int]] = None) -> np.ndarray:
+    """AudioProcessor.convertToMono (Core/Audio/AudioProcessor.swift:525-625); channels [n_channels][n_frames] float32."""
+    x = np.ascontiguousarray(channels, dtype=np.float32)
+    ptrs = (C.c_void_p * x.shape[0])(*[x[c].ctypes.data for c in range(x.shape[0])])
+    idx = None if indices is None else np.ascontiguousarray(list(indices), dtype=np.int32)
+    out = np.empty(x.shape[1], np.float32)
+    _check(L.load().wh_convert_to_mono(ptrs, x.shape[0], x.shape[1], 0 if mode == "specificChannel" else 1,
+                                       None if idx is None else idx.ctypes.data_as(L.PI32), 0 if idx is None else len(idx), out.ctypes.data_as(L.PF)))
+    return out
+
+
+def resampleAudio(audio: np.ndarray, fromSampleRate: float, toSampleRate: float = 16000.0) -> np.ndarray:
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    lib = L.load()
+    n = lib.wh_resample(a.ctypes.data_as(L.PF), len(a), fromSampleRate, toSampleRate, None, 0)
+    out = np.empty(max(n, 0), np.float32)
+    if n > 0 and lib.wh_resample(a.ctypes.data_as(L.PF), len(a), fromSampleRate, toSampleRate, out.ctypes.data_as(L.PF), n) < 0:
+        raise WhisperError(4, lib.wh_last_error().decode())
+    return out
+
+
+def loadAudio(fromPath: str, channelMode: str = "sumChannels", channels: Optional[Sequence[int]] = None, startTime: float = 0.0,
+              endTime: Optional[float] = None, maxReadFrameSize: int = 0) -> np.ndarray:
+    """AudioProcessor.loadAudio(fromPath:channelMode:startTime:endTime:maxReadFrameSize:) for WAV files -> 16 kHz mono float32."""
+    lib = L.load()
+    idx = None if channels is None else np.ascontiguousarray(list(channels), dtype=np.int32)
+    p, n = L.PF(), C.c_int()
+    _check(lib.wh_load_audio(fromPath.encode(), 0 if channelMode == "specificChannel" else 1, None if idx is None else idx.ctypes.data_as(L.PI32),
+                             0 if idx is None else len(idx), startTime, float("nan") if endTime is None else endTime, maxReadFrameSize,
+                             C.byref(p), C.byref(n)))
+    out = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
+    lib.wh_audio_free(p)
+    return out

@@ -32,6 +32,8 @@ int upload_sampler_cfg(wh_session* s, const wh_decoding_options* opt, const wh_s
                               if (hipSetDevice((s)->m->device) != hipSuccess) return set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
 #define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
 
+// CFAbsoluteTimeGetCurrent(): seconds since 2001-01-01 00:00:00 UTC
+static inline double cf_absolute_time() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - 978307200.0; }
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static inline float f16_round(float v) { return (float)(_Float16)v; }   // FloatType == Float16 on arm64 (ArgmaxCore/FloatType.swift:9-13)
 
@@ -462,15 +464,7 @@ extern "C" int wh_find_seek_point_and_segments(const wh_decoding_result* res, co
 }
 
 // ------------------------------------------------------------------------------------------------ TranscribeTask.run
-struct wh_transcription {
-    std::vector<wh_segment> segments;
-    std::vector<wh_word_timing> words;
-    std::vector<int32_t> tokens;
-    std::vector<float> logprobs;
-    std::vector<int32_t> seeks;
-    int language_token = -1;
-    wh_timings timings{};
-};
+// wh_transcription: text.h
 
 struct AudioJob {
     const float* pcm; int n;
@@ -497,18 +491,20 @@ static bool job_next_window(AudioJob& j, const wh_decoding_options* opt) {
     return false;
 }
 
-static void add_word_timestamps(wh_session* s, int slot, const wh_decoding_result& res, const wh_special_tokens* st, wh_transcription* tr,
-                                size_t seg_begin, int seek) {
-    // SegmentSeeker.addWordTimestamps (:410-496) with the token-per-word splitter: the image has no tokenizer.json, so words
-    // cannot be grouped by text; each text token becomes one word timed by DTW over its alignment row (findAlignment :340-408).
-    std::vector<float> full((size_t)kMaxTok * kCtx);
-    if (wh_get_alignment_weights(s, slot, full.data()) != WH_OK) return;
+namespace whi {
+int add_word_timestamps(const wh_tokenizer* tok, const char* language, int special_begin, wh_segment* segments, int n_segments,
+                        const int32_t* tokens, const float* logprobs, const float* alignment, int alignment_rows, int seek,
+                        float last_speech_timestamp, wh_transcription* tr);   // words.cpp
+}
+
+// Without a tokenizer the words cannot be grouped by text: every text token becomes one word timed by DTW over its alignment row
+// (findAlignment, SegmentSeeker.swift:340-408, with one token per word; no punctuation merge, no duration constraints).
+static void add_token_timestamps(const float* full, const wh_decoding_result& res, const wh_special_tokens* st, wh_segment* segs, int ns,
+                                 int seek, wh_transcription* win) {
     const int n = res.n_tokens;
-    std::vector<float> mat((size_t)n * kCtx);
-    for (int i = 0; i < n; ++i) memcpy(&mat[(size_t)i * kCtx], &full[(size_t)i * kCtx], sizeof(float) * kCtx);   // rows of the result tokens
     int cap = n + kCtx + 8;
     std::vector<int32_t> ti(cap), tj(cap);
-    int len = wh_dynamic_time_warping(mat.data(), n, kCtx, ti.data(), tj.data(), cap);
+    int len = wh_dynamic_time_warping(full, n, kCtx, ti.data(), tj.data(), cap);
     if (len <= 0) return;
     std::vector<float> startT{0.0f}, endT;
     int cur = ti[0];
@@ -516,22 +512,31 @@ static void add_word_timestamps(wh_session* s, int slot, const wh_decoding_resul
         if (ti[k] != cur) { cur = ti[k]; float t = (float)tj[k] * 0.02f; startT.push_back(t); endT.push_back(t); }
     endT.push_back((float)tj[len - 1] * 0.02f);
     const float timeOffset = (float)seek / (float)WH_SAMPLE_RATE;
-    for (size_t si = seg_begin; si < tr->segments.size(); ++si) {
-        wh_segment& g = tr->segments[si];
-        g.word_offset = (int)tr->words.size();
+    for (int si = 0; si < ns; ++si) {
+        wh_segment& g = segs[si];
+        g.word_offset = (int)win->words.size();
         for (int k = 0; k < g.n_tokens; ++k) {
-            int ri = (g.token_offset - (int)(tr->tokens.size() - res.n_tokens)) + k;   // index into the window's token list
+            int ri = g.token_offset + k;   // index into the window's token list == alignment row
             if (ri < 0 || ri >= n || ri >= (int)startT.size() || ri >= (int)endT.size()) continue;
             if (res.tokens[ri] >= st->special_token_begin) continue;
             wh_word_timing w{};
-            w.token_offset = g.token_offset + k; w.n_tokens = 1;
+            w.token_offset = (int)win->word_tokens.size(); w.n_tokens = 1;
+            win->word_tokens.push_back(res.tokens[ri]);
             w.start = roundf((timeOffset + startT[ri]) * 100.0f) / 100.0f;
             w.end = roundf((timeOffset + endT[ri]) * 100.0f) / 100.0f;
             w.probability = roundf(expf(res.token_logprobs[ri]) * 100.0f) / 100.0f;
-            tr->words.push_back(w);
+            win->words.push_back(w);
+            win->word_text.emplace_back();
         }
-        g.n_words = (int)tr->words.size() - g.word_offset;
+        g.n_words = (int)win->words.size() - g.word_offset;
     }
+}
+
+static std::string language_code_of(const wh_tokenizer* tok, int language_token) {
+    // decodeText: language = tokenizer.decode([languageToken]).trimmingSpecialTokenCharacters() (TextDecoder.swift:814), default "en"
+    if (!tok || language_token < 0) return "en";
+    std::string c = whi::trimming_special_token_characters(tok->decode(&language_token, 1, false));
+    return c.empty() ? std::string("en") : c;
 }
 
 static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_decoding_options* opt, const wh_special_tokens* st) {
@@ -539,7 +544,9 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
     const bool multilingual = wh_is_model_multilingual(m) != 0;
     const int detect = opt->detect_language < 0 ? !opt->use_prefill_prompt : opt->detect_language;
     const double t_start = now_s();
-    for (auto& j : jobs) { j.clips = prepare_seek_clips(opt, j.n); j.tr->timings.input_audio_seconds = (double)j.n / WH_SAMPLE_RATE; }
+    const double cf_start = cf_absolute_time();
+    for (auto& j : jobs) { j.clips = prepare_seek_clips(opt, j.n); j.tr->timings.input_audio_seconds = (double)j.n / WH_SAMPLE_RATE - (double)(opt->n_clip_timestamps > 0 && opt->clip_timestamps ? opt->clip_timestamps[0] : 0.0f);
+                          j.tr->timings.pipeline_start = cf_start; }
     // temperature ladder in FloatType (TranscribeTask.swift:327)
     std::vector<float> temps;
     for (int i = 0; i <= opt->temperature_fallback_count; ++i)
@@ -614,14 +621,53 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             int ns = wh_find_seek_point_and_segments(&res[b], opt, st, (int)tr->segments.size(), j.seek, j.cur_size, &new_seek, segs, WH_MAX_RESULT_TOKENS);
             const int prev_seek = j.seek;
             j.seek = std::max(j.seek, new_seek);
-            const size_t seg_begin = tr->segments.size();
             if (ns >= 0) {
-                const int base = (int)tr->tokens.size();
-                for (int i = 0; i < res[b].n_tokens; ++i) { tr->tokens.push_back(res[b].tokens[i]); tr->logprobs.push_back(res[b].token_logprobs[i]); }
-                for (int i = 0; i < ns; ++i) { segs[i].token_offset += base; tr->segments.push_back(segs[i]); }
+                // segments index the window's token list; words are collected window-locally, then both are appended to the
+                // transcription (allSegments / allTokens, TranscribeTask.swift:262-265)
+                wh_transcription win;
+                const int window_language = res[b].language_token >= 0 ? res[b].language_token : lang_tok;
                 if (opt->word_timestamps && s->align) {
-                    add_word_timestamps(s, b, res[b], st, tr, seg_begin, prev_seek);
-                    // TranscribeTask.swift:217-223: drop zero-length segments, refine the seek with the last word end
+                    const double tw0 = now_s();
+                    std::vector<float> full((size_t)kMaxTok * kCtx);
+                    r = wh_get_alignment_weights(s, b, full.data()); if (r) return r;
+                    if (s->tok) {
+                        const std::string code = language_code_of(s->tok, window_language);
+                        r = whi::add_word_timestamps(s->tok, code.c_str(), st->special_token_begin, segs, ns, res[b].tokens, res[b].token_logprobs,
+                                                     full.data(), kMaxTok, prev_seek, (float)((double)prev_seek / (double)WH_SAMPLE_RATE), &win);
+                        if (r) return r;
+                    } else {
+                        add_token_timestamps(full.data(), res[b], st, segs, ns, prev_seek, &win);
+                    }
+                    tr->timings.decoding_word_timestamps += now_s() - tw0;
+                    tr->timings.total_timestamp_alignment_runs += 1;
+                    // "Filter out zero length segments", then "Update seek point with new (more accurate) segments" (TranscribeTask.swift:217-223)
+                    int kept = 0;
+                    for (int i = 0; i < ns; ++i) if (segs[i].end > segs[i].start) segs[kept++] = segs[i];
+                    ns = kept;
+                    if (ns > 0) j.seek = std::max(j.seek, (int)(segs[ns - 1].end * (float)WH_SAMPLE_RATE));
+                }
+                for (int i = 0; i < ns; ++i) {
+                    wh_segment g = segs[i];
+                    const int src = g.token_offset;
+                    g.token_offset = (int)tr->tokens.size();
+                    std::vector<int> text_ids;
+                    for (int k = 0; k < g.n_tokens; ++k) {
+                        const int id = res[b].tokens[src + k];
+                        tr->tokens.push_back(id); tr->logprobs.push_back(res[b].token_logprobs[src + k]);
+                        if (!opt->skip_special_tokens || id < st->special_token_begin) text_ids.push_back(id);
+                    }
+                    const int wsrc = g.word_offset;
+                    g.word_offset = (int)tr->words.size();
+                    for (int k = 0; k < g.n_words; ++k) {
+                        wh_word_timing w = win.words[wsrc + k];
+                        const int tsrc = w.token_offset;
+                        w.token_offset = (int)tr->word_tokens.size();
+                        tr->word_tokens.insert(tr->word_tokens.end(), win.word_tokens.begin() + tsrc, win.word_tokens.begin() + tsrc + w.n_tokens);
+                        tr->words.push_back(w);
+                        tr->word_text.push_back(win.word_text[wsrc + k]);
+                    }
+                    tr->segments.push_back(g);
+                    if (s->tok) tr->segment_text.push_back(s->tok->decode(text_ids));   // SegmentSeeker.swift:118-121,162-165
                 }
                 tr->timings.total_decoding_windows += 1;
                 j.windows += 1;
@@ -629,9 +675,22 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             if (opt->max_window_seek >= 0) j.seek = std::min(j.seek, prev_seek + opt->max_window_seek);
             tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
             tr->timings.decoding_loop += (t4 - t3) / nb; tr->timings.total_logmel_runs += 1; tr->timings.total_encoding_runs += 1;
+            tr->timings.total_audio_processing_runs += 1;
+            tr->timings.decoding_windowing += (now_s() - t4) / nb;
+            if (tr->timings.first_token_time == 0) tr->timings.first_token_time = cf_start + (t4 - t_start);   // first decode of this audio done
         }
     }
-    for (auto& j : jobs) j.tr->timings.full_pipeline = now_s() - t_start;
+    for (auto& j : jobs) {
+        wh_transcription* tr = j.tr;
+        tr->timings.full_pipeline = now_s() - t_start;
+        if (s->tok) {   // finalizeTranscriptionResult (TranscribeTask.swift:297-312)
+            std::vector<int> text_ids;
+            for (int id : tr->tokens) if (id < st->special_token_begin) text_ids.push_back(id);
+            tr->text = whi::trim_swift_whitespaces(s->tok->decode(text_ids));
+            tr->language = language_code_of(s->tok, tr->language_token >= 0 ? tr->language_token : opt->language_token);
+            tr->has_text = true;
+        }
+    }
     return WH_OK;
 }
 
@@ -689,9 +748,16 @@ extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, con
         const int seekIdx = (int)(seekTime * (float)WH_SAMPLE_RATE);
         for (auto& g : out[i]->segments) { g.seek += seekIdx; g.start += seekTime; g.end += seekTime; }
         for (auto& w : out[i]->words) { w.start += seekTime; w.end += seekTime; }
+        out[i]->seek_time = seekTime; out[i]->has_seek_time = true;   // updateSeekOffsetsForResults, AudioChunker.swift:22,30
         if (seek_offsets_out) seek_offsets_out[i] = cs[i];
     }
     *n_out = nc;
+    return WH_OK;
+}
+
+extern "C" int wh_session_set_tokenizer(wh_session* s, const wh_tokenizer* t) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_tokenizer: null session");
+    s->tok = t;
     return WH_OK;
 }
 

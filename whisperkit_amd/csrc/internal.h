@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "text.h"
 #include "whisperhip.h"
 
 struct WhTensor {
@@ -64,6 +65,7 @@ struct wh_session {
     hipEvent_t ev[8]{};
     bool align_enabled = false;
     wh_timings last_timings{};
+    const wh_tokenizer* tok = nullptr;       // TextDecoding.tokenizer; not owned
 };
 
 namespace whi {
