@@ -311,6 +311,17 @@ int wh_add_word_timestamps(const wh_tokenizer* tok, const char* language_code, c
 int wh_transcription_create(const wh_tokenizer* tok, const wh_special_tokens* st, const wh_segment* segments, int n_segments,
                             const int32_t* tokens, const float* logprobs, int n_tokens, int language_token,
                             int skip_special_tokens, float seek_time, const wh_timings* timings, wh_transcription** out);
+/* The "Windowing" block of TranscribeTask.run (Core/TranscribeTask.swift:175-265) for one decoded window, as a host
+ * function (wh_transcribe* use it; the CPU tests drive it with synthetic decoding results): findSeekPointAndSegments, seek
+ * never moves backward, optional addWordTimestamps from `alignment` ([224][1500], NULL = none; without a tokenizer every
+ * text token is its own word), zero-length segments dropped, seek refined by the last word, maxWindowSeek clamp, segments
+ * appended.  *seek_inout: this window's seek in, the next seek out. */
+int wh_transcription_add_window(wh_transcription* t, const wh_tokenizer* tok, const wh_decoding_options* opt,
+                                const wh_special_tokens* st, const wh_decoding_result* res, const float* alignment,
+                                int default_language_token, int segment_size, int32_t* seek_inout);
+/* finalizeTranscriptionResult (Core/TranscribeTask.swift:297-312): result text and language code (needs a tokenizer) */
+int wh_transcription_finalize(wh_transcription* t, const wh_tokenizer* tok, const wh_decoding_options* opt,
+                              const wh_special_tokens* st);
 /* TranscriptionUtilities.mergeTranscriptionResults (Utilities/TranscriptionUtilities.swift:76-157); results[i] may be NULL
  * (a failed chunk); confirmed_words != NULL replaces the joined text by the concatenation of those words */
 int wh_merge_transcriptions(const wh_transcription* const* results, int n, const char* const* confirmed_words, int n_confirmed,

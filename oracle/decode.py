@@ -900,6 +900,29 @@ class TranscriptionResult:
     fallbacks: int = 0
     seeks: List[int] = dataclasses.field(default_factory=list)
     temperatures: List[float] = dataclasses.field(default_factory=list)
+    text: str = ""
+
+
+def windowing(res: DecodingResult, options: DecodingOptions, allSegmentsCount: int, seek: int, segmentSize: int, st: SpecialTokens,
+              tokenizer=None, language: str = "en"):
+    """The "Windowing" block of TranscribeTask.run, Core/TranscribeTask.swift:175-241: findSeekPointAndSegments, seek never moves
+    backward, optional addWordTimestamps (then zero-length segments are dropped and the seek is refined with the last word's
+    end), maxWindowSeek clamp.  `tokenizer` is an oracle.tokenizer.Tokenizer (None: no text, no word timestamps).
+    Returns (seek, segments or None)."""
+    f32 = np.float32
+    previousSeek = seek
+    decode_fn = tokenizer.decode if tokenizer is not None else None
+    newSeek, cur = find_seek_point_and_segments(res, options, allSegmentsCount, seek, segmentSize, st, decode_fn)
+    seek = max(seek, newSeek)
+    if options.wordTimestamps and res.alignment is not None and tokenizer is not None:
+        cur = add_word_timestamps(cur or [], res.alignment, lambda ids: tokenizer.splitToWordTokens(ids, language), tokenizer.decode,
+                                  previousSeek, float(f32(np.float64(previousSeek) / np.float64(SAMPLE_RATE))), st.specialTokenBegin)
+        cur = [g for g in cur if f32(g.end) > f32(g.start)]
+        if cur:
+            seek = max(seek, int(f32(cur[-1].end) * f32(SAMPLE_RATE)))
+    if options.maxWindowSeek is not None:
+        seek = min(seek, previousSeek + options.maxWindowSeek)
+    return seek, cur
 
 
 def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], st: SpecialTokens,
@@ -907,7 +930,7 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                         encode_window: Callable[[np.ndarray], object],
                         make_step: Callable[[object], StepFn],
                         seed: int = 0, get_alignment: Optional[Callable[[], np.ndarray]] = None,
-                        split_fn: Optional[Callable] = None) -> TranscriptionResult:
+                        split_fn: Optional[Callable] = None, tokenizer=None) -> TranscriptionResult:
     """Core/TranscribeTask.swift:57-296 (window loop) + :316-411 (decodeWithFallback).
 
     encode_window(pcm[480000]) -> opaque encoder output (padOrTrim + logMel + encode, :126-151)
@@ -939,7 +962,7 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                 step = make_step(enc)
                 if isModelMultilingual and options.language is None and options.detectLanguage:
                     ltok, _ = detect_language(step, sampler, st, languageTokens, logitsSize)
-                    detectedLanguage = f"<lang:{ltok}>"
+                    detectedLanguage = f"<lang:{ltok}>" if tokenizer is None else (tokenizer.decode([ltok]).strip("<|>") or "en")
                     if options.usePrefillPrompt:
                         prompt = prefill_prompt(curOptions, st, isModelMultilingual, languageToken=ltok)
                     step = make_step(enc)
@@ -950,16 +973,20 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                 result.temperatures.append(res.temperature)
                 if detectedLanguage is None:
                     detectedLanguage = res.language
+                    if tokenizer is not None:     # decodeText: first language token of the result, decoded (TextDecoder.swift:805-822)
+                        lt = next((t for t in res.tokens if t in set(languageTokens)), None)
+                        detectedLanguage = (tokenizer.decode([lt]).strip("<|>") if lt is not None else "") or "en"
                 if res.fallback is not None and res.fallback.needsFallback:
                     result.fallbacks += 1
                 else:
                     break
             # ---- windowing
-            previousSeek = seek
-            newSeek, cur = find_seek_point_and_segments(res, options, len(allSegments), seek, segmentSize, st)
-            seek = max(seek, newSeek)
-            if options.maxWindowSeek is not None:
-                seek = min(seek, previousSeek + options.maxWindowSeek)
+            language = "en"
+            if tokenizer is not None:
+                lt = next((t for t in res.tokens if t in set(languageTokens)), None)
+                if lt is not None:
+                    language = tokenizer.decode([lt]).strip("<|>") or "en"
+            seek, cur = windowing(res, options, len(allSegments), seek, segmentSize, st, tokenizer, language)
             if cur is None:
                 continue
             allSegments += cur
@@ -967,6 +994,8 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                 allTokens += s.tokens
             result.windows += 1
     result.segments, result.tokens, result.language = allSegments, allTokens, detectedLanguage or "en"
+    if tokenizer is not None:      # finalizeTranscriptionResult, TranscribeTask.swift:297-312
+        result.text = trim_whitespaces(tokenizer.decode([t for t in allTokens if t < st.specialTokenBegin]))
     return result
 
 
@@ -1019,6 +1048,8 @@ def add_word_timestamps(segments: List[TranscriptionSegment], alignmentWeights: 
             lp = g.tokenLogProbs[i]
             logProbs.append(lp[t] if isinstance(lp, dict) else lp)
     filtered = np.asarray(alignmentWeights, dtype=np.float32)[:len(wordTokenIds)]
+    if len(filtered) < len(wordTokenIds):      # the appended EOT can be token 225 of a 224-row matrix: zero rows
+        filtered = np.vstack([filtered, np.zeros((len(wordTokenIds) - len(filtered), filtered.shape[1]), np.float32)])
     alignment = find_alignment(wordTokenIds, filtered, logProbs, split_fn) if wordTokenIds else []
     median, maxDuration = calculate_word_duration_constraints(alignment)
     alignment = truncate_long_words_at_sentence_boundaries(alignment, maxDuration)

@@ -666,3 +666,58 @@ def test_word_timestamps_alignment_and_dtw(micro):
     n = len(res.tokens)
     ti, tj = api.dynamicTimeWarping(al[:n])
     assert (ti, tj) == OD.dynamic_time_warping(al[:n])
+
+
+@pytest.mark.gpu
+def test_transcribe_with_tokenizer_words_text_and_formats(micro, tmp_path):
+    """With a tokenizer attached (TextDecoding.tokenizer) wh_transcribe produces segment / result text, the language code and the
+    reference's full word timestamps (word grouping, duration constraints, punctuation merge).  The host post-processing is
+    deterministic given the decoded tokens and the device's alignment matrix, so: decode the same window through the step API,
+    read the alignment weights, run the oracle's windowing on them and require identical segments, words, text and SRT."""
+    from oracle import tokenizer as OT
+    from whisperkit_amd import synth
+    dims, _, model, om = micro
+    tj = synth.write_kat_tokenizer(str(tmp_path), dims.n_vocab)
+    ntok, otok = api.Tokenizer(tj), OT.Tokenizer(tj)
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+    assert otok.specialTokens() == st
+    x = synthetic_chunk(82)
+    kw = dict(**NOFALLBACK, sampleLength=40, wordTimestamps=True)
+    opts = api.DecodingOptions(**kw)
+    sess = api.Session(model, 1)
+    sess.setTokenizer(ntok)
+    got = sess.transcribe([x], opts)[0]
+    assert got.text is not None and got.language == "en" and len(got.segments) >= 1
+    assert all(g.text == otok.decode(g.tokens) for g in got.segments)
+    assert got.text == OD.trim_whitespaces(otok.decode([t for t in got.tokens if t < st.specialTokenBegin]))
+    # the same window through the stage API -> oracle windowing on the device's alignment matrix
+    s2 = api.Session(model, 1)
+    s2.padOrTrim(x); s2.logMelSpectrogram(1); s2.encodeFeatures(1); s2.prepareDecoderInputs(1)
+    r = s2.decodeText(s2.prefillPrompt(opts), opts, batch=1)[0]
+    al = s2.getAlignmentWeights(0)
+    ores = OD.DecodingResult(language="en", tokens=r.tokens, tokenLogProbs=[{t: l} for t, l in zip(r.tokens, r.tokenLogProbs)],
+                             avgLogProb=r.avgLogProb, noSpeechProb=r.noSpeechProb, temperature=r.temperature,
+                             compressionRatio=r.compressionRatio, fallback=None, alignment=al)
+    seek, want = OD.windowing(ores, OD.DecodingOptions(**kw), 0, 0, 480000, st, otok, "en")
+    k = len(want)                       # the audio may need further windows; the first window's segments come first
+    assert k >= 1 and [g.tokens for g in got.segments[:k]] == [g.tokens for g in want]
+    assert got.seeks[0] == 0 and (len(got.seeks) == 1 or got.seeks[1] == seek)
+    n_words = 0
+    for g, w in zip(got.segments[:k], want):
+        assert np.float32(g.start) == np.float32(w.start) and np.float32(g.end) == np.float32(w.end)
+        assert [a.word for a in g.words] == [b.word for b in w.words] and [a.tokens for a in g.words] == [b.tokens for b in w.words]
+        assert all(np.float32(a.start) == np.float32(b.start) and np.float32(a.end) == np.float32(b.end) for a, b in zip(g.words, w.words))
+        n_words += len(g.words)
+    assert n_words >= 1
+    got.writeSRT(str(tmp_path / "t.srt"))
+    got.writeJSON(str(tmp_path / "t.json"))
+    osegs = [OD.TranscriptionSegment(g.id, g.seek, g.start, g.end, g.text, g.tokens, [], 0, 0, 0, 0,
+                                     [OD.WordTiming(w.word, w.tokens, w.start, w.end, w.probability) for w in g.words]) for g in got.segments]
+    assert (tmp_path / "t.srt").read_text(encoding="utf-8") == OD.srt_text(osegs)
+    import json
+    j = json.loads((tmp_path / "t.json").read_text(encoding="utf-8"))
+    assert j["text"] == got.text and len(j["segments"]) == len(got.segments) and j["timings"]["totalDecodingWindows"] == len(got.seeks)
+    # detaching the tokenizer restores the token-only result
+    sess.setTokenizer(None)
+    plain = sess.transcribe([x], opts)[0]
+    assert plain.text is None and plain.language is None and all(w.word == "" for w in plain.allWords)

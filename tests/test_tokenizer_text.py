@@ -246,3 +246,69 @@ def test_native_add_word_timestamps_equals_oracle(ntoks, otoks, language):
                 compared += 1
             assert g.text == o.decode(w.tokens)
     assert compared > 250
+
+
+def _decoded_window(rng, st, kind):
+    """Result tokens SOT..EOT of one window in the shapes findSeekPointAndSegments distinguishes."""
+    tb = st.timeTokenBegin
+    prompt = [st.startOfTranscriptToken, st.englishToken, st.transcribeToken]
+    text = lambda k: [rng.choice([11, 13, 0, 30, 220, 6, 1]) if rng.random() < 0.25 else rng.randrange(256, 50000) for _ in range(k)]
+    t = sorted(rng.sample(range(2, 1400, 2), 4))
+    if kind == "pairs":          # two complete segments, consecutive timestamp pairs
+        body = [tb] + text(rng.randrange(2, 9)) + [tb + t[0], tb + t[0]] + text(rng.randrange(2, 9)) + [tb + t[1], tb + t[1]] + text(3) + [tb + t[2]]
+    elif kind == "single":       # single timestamp ending
+        body = [tb] + text(rng.randrange(2, 9)) + [tb + t[0], tb + t[0]] + text(rng.randrange(2, 6)) + [tb + t[1]]
+    elif kind == "none":         # no timestamp at the end
+        body = [tb] + text(rng.randrange(2, 9)) + [tb + t[0], tb + t[0]] + text(rng.randrange(2, 6))
+    else:                        # no consecutive timestamps at all
+        body = [tb] + text(rng.randrange(3, 12)) + ([tb + t[3]] if rng.random() < 0.5 else [])
+    toks = prompt + body + [st.endToken]
+    return toks, [-rng.random() * 1.5 for _ in toks]
+
+
+@pytest.mark.parametrize("word_timestamps,skip_special", [(False, False), (True, False), (True, True)])
+def test_native_window_assembly_equals_oracle(ntoks, otoks, word_timestamps, skip_special):
+    """TranscribeTask.run windowing over a sequence of decoded windows (Core/TranscribeTask.swift:175-312): segments, texts, seek
+    chain (never backward, refined by word timings, maxWindowSeek), zero-length filter, result text and language."""
+    n, o = ntoks[51865], otoks[51865]
+    st = o.specialTokens()
+    rng = random.Random(31 + word_timestamps + 2 * skip_special)
+    rng_np = np.random.default_rng(8)
+    for trial in range(12):
+        mws = rng.choice([None, None, 200000])
+        oopt = od.DecodingOptions(wordTimestamps=word_timestamps, skipSpecialTokens=skip_special, maxWindowSeek=mws,
+                                  noSpeechThreshold=rng.choice([None, 0.6]))
+        aopt = api.DecodingOptions(wordTimestamps=word_timestamps, skipSpecialTokens=skip_special, maxWindowSeek=mws,
+                                   noSpeechThreshold=oopt.noSpeechThreshold)
+        asm = api.WindowAssembler(aopt, n)
+        seek_o = seek_n = 0
+        all_segments, all_tokens = [], []
+        for w in range(rng.randrange(1, 5)):
+            toks, lps = _decoded_window(rng, st, rng.choice(["pairs", "single", "none", "lump"]))
+            nsp = rng.choice([0.0, 0.0, 0.9])
+            avg = -0.4 if nsp == 0.0 else rng.choice([-0.4, -2.0])       # a silent window is skipped unless avgLogProb is high
+            align = _alignment(rng_np, len(toks)) if word_timestamps else None
+            ores = od.DecodingResult(language="en", tokens=toks, tokenLogProbs=[{t: l} for t, l in zip(toks, lps)], avgLogProb=avg, noSpeechProb=nsp,
+                                     temperature=0.0, compressionRatio=1.3, fallback=None, alignment=align)
+            ares = api.DecodingResult(toks, lps, avg, nsp, 0.0, 1.3, st.englishToken, None, False, False, len(toks))
+            seg_size = rng.choice([480000, 300000])
+            seek_o, cur = od.windowing(ores, oopt, len(all_segments), seek_o, seg_size, st, o, "en")
+            seek_n = asm.addWindow(ares, seek_n, seg_size, align)
+            assert seek_n == seek_o, (trial, w)
+            if cur is not None:
+                all_segments += cur
+                for g in cur:
+                    all_tokens += g.tokens
+        got = asm.result()
+        assert [g.tokens for g in got.segments] == [g.tokens for g in all_segments]
+        assert [g.text for g in got.segments] == [g.text for g in all_segments]
+        assert [g.id for g in got.segments] == [g.id for g in all_segments]
+        assert [g.seek for g in got.segments] == [g.seek for g in all_segments]
+        for g, w in zip(got.segments, all_segments):
+            assert np.float32(g.start) == np.float32(w.start) and np.float32(g.end) == np.float32(w.end)
+            ww = w.words or []
+            assert [x.word for x in g.words] == [x.word for x in ww] and [x.tokens for x in g.words] == [x.tokens for x in ww]
+            assert all(np.float32(x.start) == np.float32(y.start) and np.float32(x.end) == np.float32(y.end) for x, y in zip(g.words, ww))
+        assert got.tokens == all_tokens
+        assert got.text == od.trim_whitespaces(o.decode([t for t in all_tokens if t < st.specialTokenBegin]))
+        assert got.language == "en"

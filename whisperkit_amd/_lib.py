@@ -144,6 +144,8 @@ SYMBOLS = {
     "wh_transcription_seek_time": (I, [VP, PF]),
     "wh_add_word_timestamps": (I, [VP, C.c_char_p, PST, C.POINTER(WhSegment), I, PI32, PF, I, PF, I, I, F, I, PVP]),
     "wh_transcription_create": (I, [VP, PST, C.POINTER(WhSegment), I, PI32, PF, I, I, I, F, C.POINTER(WhTimings), PVP]),
+    "wh_transcription_add_window": (I, [VP, VP, POPT, PST, C.POINTER(WhDecodingResult), PF, I, I, PI32]),
+    "wh_transcription_finalize": (I, [VP, VP, POPT, PST]),
     "wh_merge_transcriptions": (I, [PVP, I, C.POINTER(C.c_char_p), I, PVP]),
     "wh_format_time": (I, [F, I, C.c_char, C.c_char_p, I]),
     "wh_write_srt": (I, [VP, C.c_char_p]),

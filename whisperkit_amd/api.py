@@ -638,3 +638,41 @@ def loadAudio(fromPath: str, channelMode: str = "sumChannels", channels: Optiona
     out = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
     lib.wh_audio_free(p)
     return out
+
+
+class WindowAssembler:
+    """The windowing half of TranscribeTask.run (Core/TranscribeTask.swift:175-312) on already decoded windows: feeds
+    DecodingResults (+ alignment weights) to wh_transcription_add_window and finalises the TranscriptionResult.  Host only."""
+
+    def __init__(self, options: Optional[DecodingOptions] = None, tokenizer: Optional[Tokenizer] = None, specialTokens=None):
+        self.lib = L.load()
+        self.options = options or DecodingOptions()
+        self.tokenizer = tokenizer
+        self.st = specialTokens if specialTokens is not None else tokenizer.specialTokens
+        self.handle = C.c_void_p()
+        _check(self.lib.wh_transcription_create(None, C.byref(self.st), None, 0, None, None, 0, -1, 0, float("nan"), None, C.byref(self.handle)))
+
+    def addWindow(self, result: DecodingResult, seek: int, segmentSize: int, alignmentWeights: Optional[np.ndarray] = None,
+                  defaultLanguageToken: int = -1) -> int:
+        r = L.WhDecodingResult()
+        r.n_tokens = len(result.tokens)
+        for i, (t, l) in enumerate(zip(result.tokens, result.tokenLogProbs)):
+            r.tokens[i], r.token_logprobs[i] = t, l
+        r.avg_logprob, r.no_speech_prob, r.temperature = result.avgLogProb, result.noSpeechProb, result.temperature
+        r.compression_ratio, r.language_token = result.compressionRatio, result.languageToken
+        o = self.options.to_c()
+        a = None
+        if alignmentWeights is not None:
+            a = np.zeros((L.MAX_TOKEN_CONTEXT, L.AUDIO_CTX), np.float32)
+            a[:len(alignmentWeights)] = alignmentWeights[:L.MAX_TOKEN_CONTEXT]
+        sk = C.c_int32(seek)
+        _check(self.lib.wh_transcription_add_window(self.handle, self.tokenizer.handle if self.tokenizer else None, C.byref(o), C.byref(self.st),
+                                                    C.byref(r), None if a is None else a.ctypes.data_as(L.PF), defaultLanguageToken, segmentSize,
+                                                    C.byref(sk)))
+        return sk.value
+
+    def result(self) -> TranscriptionResult:
+        o = self.options.to_c()
+        _check(self.lib.wh_transcription_finalize(self.handle, self.tokenizer.handle if self.tokenizer else None, C.byref(o), C.byref(self.st)))
+        h, self.handle = self.handle, None
+        return _collect(h)

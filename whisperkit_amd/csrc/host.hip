@@ -491,54 +491,6 @@ static bool job_next_window(AudioJob& j, const wh_decoding_options* opt) {
     return false;
 }
 
-namespace whi {
-int add_word_timestamps(const wh_tokenizer* tok, const char* language, int special_begin, wh_segment* segments, int n_segments,
-                        const int32_t* tokens, const float* logprobs, const float* alignment, int alignment_rows, int seek,
-                        float last_speech_timestamp, wh_transcription* tr);   // words.cpp
-}
-
-// Without a tokenizer the words cannot be grouped by text: every text token becomes one word timed by DTW over its alignment row
-// (findAlignment, SegmentSeeker.swift:340-408, with one token per word; no punctuation merge, no duration constraints).
-static void add_token_timestamps(const float* full, const wh_decoding_result& res, const wh_special_tokens* st, wh_segment* segs, int ns,
-                                 int seek, wh_transcription* win) {
-    const int n = res.n_tokens;
-    int cap = n + kCtx + 8;
-    std::vector<int32_t> ti(cap), tj(cap);
-    int len = wh_dynamic_time_warping(full, n, kCtx, ti.data(), tj.data(), cap);
-    if (len <= 0) return;
-    std::vector<float> startT{0.0f}, endT;
-    int cur = ti[0];
-    for (int k = 0; k < len; ++k)
-        if (ti[k] != cur) { cur = ti[k]; float t = (float)tj[k] * 0.02f; startT.push_back(t); endT.push_back(t); }
-    endT.push_back((float)tj[len - 1] * 0.02f);
-    const float timeOffset = (float)seek / (float)WH_SAMPLE_RATE;
-    for (int si = 0; si < ns; ++si) {
-        wh_segment& g = segs[si];
-        g.word_offset = (int)win->words.size();
-        for (int k = 0; k < g.n_tokens; ++k) {
-            int ri = g.token_offset + k;   // index into the window's token list == alignment row
-            if (ri < 0 || ri >= n || ri >= (int)startT.size() || ri >= (int)endT.size()) continue;
-            if (res.tokens[ri] >= st->special_token_begin) continue;
-            wh_word_timing w{};
-            w.token_offset = (int)win->word_tokens.size(); w.n_tokens = 1;
-            win->word_tokens.push_back(res.tokens[ri]);
-            w.start = roundf((timeOffset + startT[ri]) * 100.0f) / 100.0f;
-            w.end = roundf((timeOffset + endT[ri]) * 100.0f) / 100.0f;
-            w.probability = roundf(expf(res.token_logprobs[ri]) * 100.0f) / 100.0f;
-            win->words.push_back(w);
-            win->word_text.emplace_back();
-        }
-        g.n_words = (int)win->words.size() - g.word_offset;
-    }
-}
-
-static std::string language_code_of(const wh_tokenizer* tok, int language_token) {
-    // decodeText: language = tokenizer.decode([languageToken]).trimmingSpecialTokenCharacters() (TextDecoder.swift:814), default "en"
-    if (!tok || language_token < 0) return "en";
-    std::string c = whi::trimming_special_token_characters(tok->decode(&language_token, 1, false));
-    return c.empty() ? std::string("en") : c;
-}
-
 static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_decoding_options* opt, const wh_special_tokens* st) {
     const wh_model* m = s->m;
     const bool multilingual = wh_is_model_multilingual(m) != 0;
@@ -616,63 +568,19 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             AudioJob& j = jobs[slot_job[b]];
             wh_transcription* tr = j.tr;
             if (tr->language_token < 0 && res[b].language_token >= 0) tr->language_token = res[b].language_token;
-            wh_segment segs[WH_MAX_RESULT_TOKENS];
-            int new_seek = j.seek;
-            int ns = wh_find_seek_point_and_segments(&res[b], opt, st, (int)tr->segments.size(), j.seek, j.cur_size, &new_seek, segs, WH_MAX_RESULT_TOKENS);
-            const int prev_seek = j.seek;
-            j.seek = std::max(j.seek, new_seek);
-            if (ns >= 0) {
-                // segments index the window's token list; words are collected window-locally, then both are appended to the
-                // transcription (allSegments / allTokens, TranscribeTask.swift:262-265)
-                wh_transcription win;
-                const int window_language = res[b].language_token >= 0 ? res[b].language_token : lang_tok;
-                if (opt->word_timestamps && s->align) {
-                    const double tw0 = now_s();
-                    std::vector<float> full((size_t)kMaxTok * kCtx);
-                    r = wh_get_alignment_weights(s, b, full.data()); if (r) return r;
-                    if (s->tok) {
-                        const std::string code = language_code_of(s->tok, window_language);
-                        r = whi::add_word_timestamps(s->tok, code.c_str(), st->special_token_begin, segs, ns, res[b].tokens, res[b].token_logprobs,
-                                                     full.data(), kMaxTok, prev_seek, (float)((double)prev_seek / (double)WH_SAMPLE_RATE), &win);
-                        if (r) return r;
-                    } else {
-                        add_token_timestamps(full.data(), res[b], st, segs, ns, prev_seek, &win);
-                    }
-                    tr->timings.decoding_word_timestamps += now_s() - tw0;
-                    tr->timings.total_timestamp_alignment_runs += 1;
-                    // "Filter out zero length segments", then "Update seek point with new (more accurate) segments" (TranscribeTask.swift:217-223)
-                    int kept = 0;
-                    for (int i = 0; i < ns; ++i) if (segs[i].end > segs[i].start) segs[kept++] = segs[i];
-                    ns = kept;
-                    if (ns > 0) j.seek = std::max(j.seek, (int)(segs[ns - 1].end * (float)WH_SAMPLE_RATE));
-                }
-                for (int i = 0; i < ns; ++i) {
-                    wh_segment g = segs[i];
-                    const int src = g.token_offset;
-                    g.token_offset = (int)tr->tokens.size();
-                    std::vector<int> text_ids;
-                    for (int k = 0; k < g.n_tokens; ++k) {
-                        const int id = res[b].tokens[src + k];
-                        tr->tokens.push_back(id); tr->logprobs.push_back(res[b].token_logprobs[src + k]);
-                        if (!opt->skip_special_tokens || id < st->special_token_begin) text_ids.push_back(id);
-                    }
-                    const int wsrc = g.word_offset;
-                    g.word_offset = (int)tr->words.size();
-                    for (int k = 0; k < g.n_words; ++k) {
-                        wh_word_timing w = win.words[wsrc + k];
-                        const int tsrc = w.token_offset;
-                        w.token_offset = (int)tr->word_tokens.size();
-                        tr->word_tokens.insert(tr->word_tokens.end(), win.word_tokens.begin() + tsrc, win.word_tokens.begin() + tsrc + w.n_tokens);
-                        tr->words.push_back(w);
-                        tr->word_text.push_back(win.word_text[wsrc + k]);
-                    }
-                    tr->segments.push_back(g);
-                    if (s->tok) tr->segment_text.push_back(s->tok->decode(text_ids));   // SegmentSeeker.swift:118-121,162-165
-                }
-                tr->timings.total_decoding_windows += 1;
-                j.windows += 1;
+            // "Windowing" (TranscribeTask.swift:175-265) is host-only code shared with the CPU tests: wh_transcription_add_window
+            std::vector<float> full;
+            const float* alignment = nullptr;
+            if (opt->word_timestamps && s->align) {
+                full.resize((size_t)kMaxTok * kCtx);
+                r = wh_get_alignment_weights(s, b, full.data()); if (r) return r;
+                alignment = full.data();
             }
-            if (opt->max_window_seek >= 0) j.seek = std::min(j.seek, prev_seek + opt->max_window_seek);
+            const double windows_before = tr->timings.total_decoding_windows;
+            int32_t seek = j.seek;
+            r = wh_transcription_add_window(tr, s->tok, opt, st, &res[b], alignment, lang_tok, j.cur_size, &seek); if (r) return r;
+            j.seek = seek;
+            if (tr->timings.total_decoding_windows > windows_before) j.windows += 1;
             tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
             tr->timings.decoding_loop += (t4 - t3) / nb; tr->timings.total_logmel_runs += 1; tr->timings.total_encoding_runs += 1;
             tr->timings.total_audio_processing_runs += 1;
@@ -683,13 +591,7 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
     for (auto& j : jobs) {
         wh_transcription* tr = j.tr;
         tr->timings.full_pipeline = now_s() - t_start;
-        if (s->tok) {   // finalizeTranscriptionResult (TranscribeTask.swift:297-312)
-            std::vector<int> text_ids;
-            for (int id : tr->tokens) if (id < st->special_token_begin) text_ids.push_back(id);
-            tr->text = whi::trim_swift_whitespaces(s->tok->decode(text_ids));
-            tr->language = language_code_of(s->tok, tr->language_token >= 0 ? tr->language_token : opt->language_token);
-            tr->has_text = true;
-        }
+        int fr = wh_transcription_finalize(tr, s->tok, opt, st); if (fr) return fr;
     }
     return WH_OK;
 }

@@ -4,6 +4,7 @@
 //   TranscriptionResult / Segment / WordTiming Codable  Core/Models.swift:447-641, TranscriptionTimings :730-844
 //   AudioProcessor.loadAudio / convertToMono            Core/Audio/AudioProcessor.swift:229-300, 381-456, 525-625
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -90,6 +91,135 @@ extern "C" int wh_transcription_create(const wh_tokenizer* tok, const wh_special
         }
     }
     *out = tr;
+    return WH_OK;
+}
+
+// ---- TranscribeTask.run windowing ------------------------------------------------------------------------------------------
+namespace whi {
+int add_word_timestamps(const wh_tokenizer* tok, const char* language, int special_begin, wh_segment* segments, int n_segments,
+                        const int32_t* tokens, const float* logprobs, const float* alignment, int alignment_rows, int seek,
+                        float last_speech_timestamp, wh_transcription* tr);   // words.cpp
+}
+
+static std::string language_code_of(const wh_tokenizer* tok, int language_token) {
+    // decodeText: language = tokenizer.decode([languageToken]).trimmingSpecialTokenCharacters() (TextDecoder.swift:814), default "en"
+    if (!tok || language_token < 0) return "en";
+    std::string c = whi::trimming_special_token_characters(tok->decode(&language_token, 1, false));
+    return c.empty() ? std::string("en") : c;
+}
+
+// Without a tokenizer the words cannot be grouped by text: every text token becomes one word timed by DTW over its alignment row
+// (findAlignment, SegmentSeeker.swift:340-408, with one token per word; no punctuation merge, no duration constraints).
+static void add_token_timestamps(const float* full, const wh_decoding_result& res, const wh_special_tokens* st, wh_segment* segs, int ns,
+                                 int seek, wh_transcription* win) {
+    const int n = res.n_tokens, cols = WH_AUDIO_CTX;
+    int cap = n + cols + 8;
+    std::vector<int32_t> ti(cap), tj(cap);
+    int len = wh_dynamic_time_warping(full, n, cols, ti.data(), tj.data(), cap);
+    if (len <= 0) return;
+    std::vector<float> startT{0.0f}, endT;
+    int cur = ti[0];
+    for (int k = 0; k < len; ++k)
+        if (ti[k] != cur) { cur = ti[k]; float t = (float)tj[k] * 0.02f; startT.push_back(t); endT.push_back(t); }
+    endT.push_back((float)tj[len - 1] * 0.02f);
+    const float timeOffset = (float)seek / (float)WH_SAMPLE_RATE;
+    for (int si = 0; si < ns; ++si) {
+        wh_segment& g = segs[si];
+        g.word_offset = (int)win->words.size();
+        for (int k = 0; k < g.n_tokens; ++k) {
+            int ri = g.token_offset + k;   // index into the window's token list == alignment row
+            if (ri < 0 || ri >= n || ri >= (int)startT.size() || ri >= (int)endT.size()) continue;
+            if (res.tokens[ri] >= st->special_token_begin) continue;
+            wh_word_timing w{};
+            w.token_offset = (int)win->word_tokens.size(); w.n_tokens = 1;
+            win->word_tokens.push_back(res.tokens[ri]);
+            w.start = whi::rounded2(timeOffset + startT[ri]);
+            w.end = whi::rounded2(timeOffset + endT[ri]);
+            w.probability = whi::rounded2(expf(res.token_logprobs[ri]));
+            win->words.push_back(w);
+            win->word_text.emplace_back();
+        }
+        g.n_words = (int)win->words.size() - g.word_offset;
+    }
+}
+
+// The "Windowing" block of TranscribeTask.run (Core/TranscribeTask.swift:175-265) for one decoded window: findSeekPointAndSegments,
+// seek never moves backward, optional addWordTimestamps (zero-length segments dropped, seek refined with the last word's end),
+// maxWindowSeek clamp, segments / tokens appended to the transcription.  `alignment` = [224][1500] alignment weights of the window
+// or NULL (no word timestamps).  *seek_inout: window seek in, next seek out.
+extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokenizer* tok, const wh_decoding_options* opt,
+                                           const wh_special_tokens* st, const wh_decoding_result* res, const float* alignment,
+                                           int default_language_token, int segment_size, int32_t* seek_inout) {
+    if (!tr || !opt || !st || !res || !seek_inout) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_add_window: null argument");
+    const int prev_seek = *seek_inout;
+    wh_segment segs[WH_MAX_RESULT_TOKENS];
+    int32_t new_seek = prev_seek;
+    int ns = wh_find_seek_point_and_segments(res, opt, st, (int)tr->segments.size(), prev_seek, segment_size, &new_seek, segs, WH_MAX_RESULT_TOKENS);
+    if (ns < -1) return set_error(WH_ERR_SEGMENTING_FAILED, "findSeekPointAndSegments failed");
+    int seek = std::max(prev_seek, (int)new_seek);
+    wh_transcription win;   // window-local words
+    const bool words = opt->word_timestamps && alignment;
+    const auto tw0 = std::chrono::steady_clock::now();
+    if (words) {
+        if (ns < 0) ns = 0;   // `currentSegments ?? []` (:202)
+        const int window_language = res->language_token >= 0 ? res->language_token : default_language_token;
+        if (tok) {
+            const std::string code = language_code_of(tok, window_language);
+            int r = whi::add_word_timestamps(tok, code.c_str(), st->special_token_begin, segs, ns, res->tokens, res->token_logprobs, alignment,
+                                             WH_MAX_TOKEN_CONTEXT, prev_seek, (float)((double)prev_seek / (double)WH_SAMPLE_RATE), &win);
+            if (r) return r;
+        } else {
+            add_token_timestamps(alignment, *res, st, segs, ns, prev_seek, &win);
+        }
+        tr->timings.total_timestamp_alignment_runs += 1;
+        tr->timings.decoding_word_timestamps += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+        int kept = 0;                                   // "Filter out zero length segments" (:217)
+        for (int i = 0; i < ns; ++i) if (segs[i].end > segs[i].start) segs[kept++] = segs[i];
+        ns = kept;
+        if (ns > 0) seek = std::max(seek, (int)(segs[ns - 1].end * (float)WH_SAMPLE_RATE));   // (:220-222)
+    }
+    if (opt->max_window_seek >= 0) seek = std::min(seek, prev_seek + opt->max_window_seek);   // (:234-237)
+    *seek_inout = seek;
+    if (ns < 0) return WH_OK;                           // no segment for this window: skip to the next (:239-242)
+    for (int i = 0; i < ns; ++i) {
+        wh_segment g = segs[i];
+        const int src = g.token_offset;
+        g.token_offset = (int)tr->tokens.size();
+        std::vector<int> text_ids;
+        for (int k = 0; k < g.n_tokens; ++k) {
+            const int id = res->tokens[src + k];
+            tr->tokens.push_back(id);
+            tr->logprobs.push_back(res->token_logprobs[src + k]);
+            if (!opt->skip_special_tokens || id < st->special_token_begin) text_ids.push_back(id);
+        }
+        const int wsrc = g.word_offset;
+        g.word_offset = (int)tr->words.size();
+        if (!words) g.n_words = 0;
+        for (int k = 0; k < g.n_words; ++k) {
+            wh_word_timing w = win.words[wsrc + k];
+            const int tsrc = w.token_offset;
+            w.token_offset = (int)tr->word_tokens.size();
+            tr->word_tokens.insert(tr->word_tokens.end(), win.word_tokens.begin() + tsrc, win.word_tokens.begin() + tsrc + w.n_tokens);
+            tr->words.push_back(w);
+            tr->word_text.push_back(win.word_text[wsrc + k]);
+        }
+        tr->segments.push_back(g);
+        if (tok) tr->segment_text.push_back(tok->decode(text_ids));   // SegmentSeeker.swift:118-121,162-165
+    }
+    if (tr->language_token < 0 && res->language_token >= 0) tr->language_token = res->language_token;
+    tr->timings.total_decoding_windows += 1;
+    return WH_OK;
+}
+
+// finalizeTranscriptionResult (TranscribeTask.swift:297-312): text = decode(all text tokens) trimmed, language code
+extern "C" int wh_transcription_finalize(wh_transcription* tr, const wh_tokenizer* tok, const wh_decoding_options* opt, const wh_special_tokens* st) {
+    if (!tr || !st) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_finalize: null argument");
+    if (!tok) return WH_OK;
+    std::vector<int> text_ids;
+    for (int id : tr->tokens) if (id < st->special_token_begin) text_ids.push_back(id);
+    tr->text = whi::trim_swift_whitespaces(tok->decode(text_ids));
+    tr->language = language_code_of(tok, tr->language_token >= 0 ? tr->language_token : (opt ? opt->language_token : -1));
+    tr->has_text = true;
     return WH_OK;
 }
 

@@ -184,7 +184,12 @@ int add_word_timestamps(const wh_tokenizer* tok, const char* language, int speci
     std::vector<float> lps;
     for (int s = 0; s < n_segments; ++s)
         for (int k = 0; k < segments[s].n_tokens; ++k) { ids.push_back(tokens[segments[s].token_offset + k]); lps.push_back(logprobs[segments[s].token_offset + k]); }
-    if ((int)ids.size() > alignment_rows) return set_error(WH_ERR_SEGMENTING_FAILED, "alignment has %d rows for %zu tokens", alignment_rows, ids.size());
+    std::vector<float> padded;          // a result may carry one token more than the 224 alignment rows (the appended EOT): zero rows
+    if ((int)ids.size() > alignment_rows) {
+        padded.assign(ids.size() * (size_t)WH_AUDIO_CTX, 0.0f);
+        memcpy(padded.data(), alignment, sizeof(float) * (size_t)alignment_rows * WH_AUDIO_CTX);
+        alignment = padded.data();
+    }
     std::vector<Word> alignment_words;
     if (!ids.empty()) {
         int r = find_alignment(tok, language, ids, alignment, (int)ids.size(), lps, alignment_words);
