@@ -687,7 +687,7 @@ def test_transcribe_with_tokenizer_words_text_and_formats(micro, tmp_path):
     sess = api.Session(model, 1)
     sess.setTokenizer(ntok)
     got = sess.transcribe([x], opts)[0]
-    assert got.text is not None and got.language == "en" and len(got.segments) >= 1
+    assert got.text is not None and len(got.segments) >= 1
     assert all(g.text == otok.decode(g.tokens) for g in got.segments)
     assert got.text == OD.trim_whitespaces(otok.decode([t for t in got.tokens if t < st.specialTokenBegin]))
     # the same window through the stage API -> oracle windowing on the device's alignment matrix
@@ -695,6 +695,10 @@ def test_transcribe_with_tokenizer_words_text_and_formats(micro, tmp_path):
     s2.padOrTrim(x); s2.logMelSpectrogram(1); s2.encodeFeatures(1); s2.prepareDecoderInputs(1)
     r = s2.decodeText(s2.prefillPrompt(opts), opts, batch=1)[0]
     al = s2.getAlignmentWeights(0)
+    # decodeText: language = the first language token among the result tokens, decoded and trimmed, else "en" (TextDecoder.swift:805-822);
+    # random weights may well sample one of the 99 language ids
+    lt = next((t for t in r.tokens if t in set(langs)), None)
+    assert got.language == ((otok.decode([lt]).strip("<|>") if lt is not None else "") or "en")
     ores = OD.DecodingResult(language="en", tokens=r.tokens, tokenLogProbs=[{t: l} for t, l in zip(r.tokens, r.tokenLogProbs)],
                              avgLogProb=r.avgLogProb, noSpeechProb=r.noSpeechProb, temperature=r.temperature,
                              compressionRatio=r.compressionRatio, fallback=None, alignment=al)

@@ -542,7 +542,7 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
                 std::vector<int32_t> lt(nb); std::vector<float> ll(nb);
                 r = wh_detect_language(s, nb, st, lt.data(), ll.data()); if (r) return r;
                 for (int b = 0; b < nb; ++b) if (active[b]) { lang_tok = lt[b]; break; }
-                for (int b = 0; b < nb; ++b) if (jobs[slot_job[b]].tr->language_token < 0) jobs[slot_job[b]].tr->language_token = lt[b];
+                for (int b = 0; b < nb; ++b) { wh_transcription* t = jobs[slot_job[b]].tr; if (!t->language_set) { t->language_token = lt[b]; t->language_set = true; } }
             }
             if (opt->use_prefill_prompt) {
                 n_prompt = wh_prefill_prompt(m, opt, st, lang_tok, prompt.data(), (int)prompt.size());
@@ -567,7 +567,6 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
         for (int b = 0; b < nb; ++b) {
             AudioJob& j = jobs[slot_job[b]];
             wh_transcription* tr = j.tr;
-            if (tr->language_token < 0 && res[b].language_token >= 0) tr->language_token = res[b].language_token;
             // "Windowing" (TranscribeTask.swift:175-265) is host-only code shared with the CPU tests: wh_transcription_add_window
             std::vector<float> full;
             const float* alignment = nullptr;

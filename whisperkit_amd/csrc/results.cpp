@@ -151,6 +151,7 @@ extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokeni
                                            const wh_special_tokens* st, const wh_decoding_result* res, const float* alignment,
                                            int default_language_token, int segment_size, int32_t* seek_inout) {
     if (!tr || !opt || !st || !res || !seek_inout) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_add_window: null argument");
+    if (!tr->language_set) { tr->language_token = res->language_token; tr->language_set = true; }   // "Use the predicted language if it was not detected ahead of time"
     const int prev_seek = *seek_inout;
     wh_segment segs[WH_MAX_RESULT_TOKENS];
     int32_t new_seek = prev_seek;
@@ -206,7 +207,6 @@ extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokeni
         tr->segments.push_back(g);
         if (tok) tr->segment_text.push_back(tok->decode(text_ids));   // SegmentSeeker.swift:118-121,162-165
     }
-    if (tr->language_token < 0 && res->language_token >= 0) tr->language_token = res->language_token;
     tr->timings.total_decoding_windows += 1;
     return WH_OK;
 }

@@ -68,5 +68,6 @@ struct wh_transcription {
     bool has_seek_time = false;
     float seek_time = 0;
     int language_token = -1;
+    bool language_set = false;       // detectedLanguage is fixed by the first detection / first decoded window (TranscribeTask.swift:352,375-377)
     wh_timings timings{};
 };
