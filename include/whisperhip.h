@@ -224,6 +224,20 @@ int wh_filter_logits(wh_session* s, const wh_decoding_options* opt, const wh_spe
 int wh_sample_token(wh_session* s, const float* logits_host, int n_logits, float temperature, int top_k,
                     uint64_t seed, int counter, int32_t* token_out, float* logprob_out);
 
+/* TranscriptionCallback (Core/Models.swift:728; invoked per token by decodeText, Core/TextDecoder.swift:723-741, early stop via
+ * earlyStopActor :752-755).  The token loop runs on the device, so the callback fires on the calling thread each time the host
+ * looks at the device state - every 8 decoder steps - once per unfinished slot, with the slot's currentTokens.  Return 0 to
+ * stop that slot early (its result is finalised with the tokens decoded so far), non-zero to continue.  `text` is the current
+ * transcript when a tokenizer is attached, else NULL.  NULL fn removes the callback. */
+typedef struct wh_progress {
+    int32_t slot, n_tokens;
+    const int32_t* tokens;
+    float avg_logprob, compression_ratio;
+    const char* text;
+} wh_progress;
+typedef int (*wh_progress_fn)(void* user, const wh_progress* progress);
+int wh_session_set_progress_callback(wh_session* s, wh_progress_fn fn, void* user);
+
 /* TextDecoding.decodeText (Core/TextDecoder.swift:541-855) for slots [0, batch), whole token loop on device.
  * temperatures[b] is the sampler temperature of slot b; active[b]==0 skips the slot (may be NULL = all active). */
 int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,

@@ -725,3 +725,46 @@ def test_transcribe_with_tokenizer_words_text_and_formats(micro, tmp_path):
     sess.setTokenizer(None)
     plain = sess.transcribe([x], opts)[0]
     assert plain.text is None and plain.language is None and all(w.word == "" for w in plain.allWords)
+
+
+@pytest.mark.gpu
+def test_progress_callback_and_early_stop(micro):
+    """TranscriptionCallback (TextDecoder.swift:723-741) and early stopping (:752-755): the callback sees growing prefixes of the
+    slot's tokens every 8 steps and does not change the result; returning False ends the slot with the tokens decoded so far
+    plus the EOT that GreedyTokenSampler.finalize appends (TokenSampler.swift:242-251)."""
+    dims, _, model, om = micro
+    st, _ = OD.special_tokens_for_vocab(dims.n_vocab)
+    sess = api.Session(model, 2)
+    for b in range(2):
+        sess.padOrTrim(synthetic_chunk(70 + b), b)
+    sess.logMelSpectrogram(2); sess.encodeFeatures(2); sess.prepareDecoderInputs(2)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=40)
+    prompt = sess.prefillPrompt(opts)
+    base = sess.decodeText(prompt, opts, batch=2)
+    calls = []
+    sess.setProgressCallback(lambda slot, tokens, avg, cr, text: calls.append((slot, tokens, avg, cr, text)))
+    sess.resetDecoderInputs(2)
+    seen = sess.decodeText(prompt, opts, batch=2)
+    assert [r.tokens for r in seen] == [r.tokens for r in base]
+    assert {c[0] for c in calls} == {0, 1} and all(c[4] is None for c in calls)
+    for slot, tokens, avg, cr, _ in calls:
+        assert tokens == base[slot].tokens[:len(tokens)] and len(tokens) >= len(prompt)
+        assert cr == pytest.approx(api.compressionRatio(tokens), rel=1e-6) and avg <= 0.0
+    lens = [len(c[1]) for c in calls if c[0] == 0]
+    assert lens == sorted(lens) and len(set(lens)) == len(lens)          # strictly growing per slot
+    # stop slot 1 at its first report, let slot 0 run
+    stopped = {}
+
+    def stop_slot_1(slot, tokens, avg, cr, text):
+        if slot == 1 and slot not in stopped:
+            stopped[slot] = list(tokens)
+            return False
+        return None
+    sess.setProgressCallback(stop_slot_1)
+    sess.resetDecoderInputs(2)
+    cut = sess.decodeText(prompt, opts, batch=2)
+    assert cut[0].tokens == base[0].tokens
+    assert cut[1].tokens == stopped[1] + [st.endToken] and len(cut[1].tokens) < len(base[1].tokens)
+    sess.setProgressCallback(None)
+    sess.resetDecoderInputs(2)
+    assert [r.tokens for r in sess.decodeText(prompt, opts, batch=2)] == [r.tokens for r in base]

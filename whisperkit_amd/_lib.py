@@ -62,6 +62,14 @@ class WhWordTiming(C.Structure):
     _fields_ = [("token_offset", C.c_int32), ("n_tokens", C.c_int32), ("start", C.c_float), ("end", C.c_float), ("probability", C.c_float)]
 
 
+class WhProgress(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("n_tokens", C.c_int32), ("tokens", C.POINTER(C.c_int32)), ("avg_logprob", C.c_float),
+                ("compression_ratio", C.c_float), ("text", C.c_char_p)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(WhProgress))
+
+
 class WhTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "audio_processing", "logmels", "encoding", "decoding_init", "decoding_predictions", "decoding_filtering",
@@ -135,6 +143,7 @@ SYMBOLS = {
     "wh_tokenizer_special_tokens": (I, [VP, PST]),
     "wh_tokenizer_split_to_word_tokens": (I, [VP, PI32, I, C.c_char_p, PI32, PI32, I, C.c_char_p, I, C.POINTER(I)]),
     "wh_session_set_tokenizer": (I, [VP, VP]),
+    "wh_session_set_progress_callback": (I, [VP, PROGRESS_FN, VP]),
     "wh_transcription_has_text": (I, [VP]),
     "wh_transcription_text": (I, [VP, C.c_char_p, I]),
     "wh_transcription_language": (I, [VP, C.c_char_p, I]),

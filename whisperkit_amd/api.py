@@ -357,6 +357,22 @@ class Session:
         self.tokenizer = tokenizer      # keep it alive
         _check(self.lib.wh_session_set_tokenizer(self.handle, tokenizer.handle if tokenizer is not None else None))
 
+    def setProgressCallback(self, callback):
+        """TranscriptionCallback (Core/Models.swift:728): callback(slot, tokens, avgLogprob, compressionRatio, text) -> bool | None, called
+        every 8 decoder steps per unfinished slot; returning False stops that slot early (TextDecoder.swift:731-737,752-755)."""
+        if callback is None:
+            self._progress = None
+            _check(self.lib.wh_session_set_progress_callback(self.handle, L.PROGRESS_FN(0), None))
+            return
+
+        def tramp(_user, p):
+            p = p.contents
+            r = callback(p.slot, [p.tokens[i] for i in range(p.n_tokens)], p.avg_logprob, p.compression_ratio,
+                         p.text.decode("utf-8") if p.text is not None else None)
+            return 0 if r is False else 1
+        self._progress = L.PROGRESS_FN(tramp)      # keep the thunk alive
+        _check(self.lib.wh_session_set_progress_callback(self.handle, self._progress, None))
+
     # ---- AudioProcessing.padOrTrimAudio
     def padOrTrim(self, audio, slot: int = 0):
         a = np.ascontiguousarray(audio, dtype=np.float32)

@@ -298,10 +298,57 @@ void drop_session_graphs(wh_session* s) {
 }
 }
 
+// TranscriptionCallback on a consistent snapshot of the slot states (the stream is idle): one call per unfinished slot; a zero
+// return marks the slot done on the device (stream-ordered, before the next step graph) - earlyStopActor semantics.
+static int report_progress(wh_session* s, int batch) {
+    static const int kOne = 1;
+    for (int b = 0; b < batch; ++b) {
+        SeqState& q = s->seq_host[b];
+        if (!q.active || q.done || q.n_tokens <= 0) continue;
+        wh_progress p{};
+        p.slot = b; p.n_tokens = q.n_tokens; p.tokens = q.tokens;
+        float sum = 0;
+        for (int i = 0; i < q.n_tokens; ++i) sum += q.logprobs[i];
+        p.avg_logprob = sum / (float)q.n_tokens;
+        p.compression_ratio = wh_compression_ratio(q.tokens, q.n_tokens);
+        std::string text;
+        if (s->tok) {
+            std::vector<int> ids;
+            for (int i = 0; i < q.n_tokens; ++i) if (!s->skip_special_in_progress || q.tokens[i] < s->special_begin_in_progress) ids.push_back(q.tokens[i]);
+            text = s->tok->decode(ids);
+            p.text = text.c_str();
+        }
+        if (!s->progress_cb(s->progress_user, &p)) {
+            q.done = 1;
+            WH_HIP(hipMemcpyAsync(&s->seq[b].done, &kOne, sizeof(int), hipMemcpyHostToDevice, s->st));
+        }
+    }
+    return WH_OK;
+}
+
 static int run_token_loop(wh_session* s, int batch, int loop_count) {
     // every slot's state lives on the device; the host only replays step graphs and polls the done flags
     const size_t bytes = sizeof(SeqState) * batch;
     auto all_done = [&]() { for (int b = 0; b < batch; ++b) if (s->seq_host[b].active && !s->seq_host[b].done) return false; return true; };
+    if (s->progress_cb) {
+        // with a callback installed the host needs whole snapshots: no run-ahead, one synchronisation per 8 steps
+        hipGraphExec_t exec = nullptr;
+        DecodeBuffers db = whi::decode_buffers(s, batch);
+        if (use_graphs()) { int r = get_step_graph(s, batch, &exec); if (r) return r; }
+        for (int step = 0; step < loop_count; step += kStepsPerGraph) {
+            if (exec) WH_HIP(hipGraphLaunch(exec, s->st));
+            else for (int i = 0; i < kStepsPerGraph && step + i < loop_count; ++i) { launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st); WH_CHECK_LAUNCH(); }
+            WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
+            WH_HIP(hipStreamSynchronize(s->st));
+            if (all_done()) break;
+            int r = report_progress(s, batch);
+            if (r) return r;
+            if (all_done()) break;
+        }
+        WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
+        WH_HIP(hipStreamSynchronize(s->st));
+        return WH_OK;
+    }
     if (use_graphs()) {
         hipGraphExec_t exec;
         int r = get_step_graph(s, batch, &exec);
@@ -367,6 +414,8 @@ extern "C" int wh_decode_text(wh_session* s, int batch, const wh_decoding_option
     WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
     launch_rules_init(s->cfg_dev, s->seq, batch, s->st);
     const int loop_count = std::min(opt->sample_length, kMaxTok - 1);
+    s->skip_special_in_progress = opt->skip_special_tokens != 0;
+    s->special_begin_in_progress = st->special_token_begin;
     r = run_token_loop(s, batch, std::max(loop_count, 0));
     if (r) return r;
     for (int b = 0; b < batch; ++b) {
@@ -653,6 +702,13 @@ extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, con
         if (seek_offsets_out) seek_offsets_out[i] = cs[i];
     }
     *n_out = nc;
+    return WH_OK;
+}
+
+extern "C" int wh_session_set_progress_callback(wh_session* s, wh_progress_fn fn, void* user) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_progress_callback: null session");
+    s->progress_cb = fn;
+    s->progress_user = user;
     return WH_OK;
 }
 

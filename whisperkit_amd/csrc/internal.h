@@ -66,6 +66,10 @@ struct wh_session {
     bool align_enabled = false;
     wh_timings last_timings{};
     const wh_tokenizer* tok = nullptr;       // TextDecoding.tokenizer; not owned
+    wh_progress_fn progress_cb = nullptr;    // TranscriptionCallback
+    void* progress_user = nullptr;
+    bool skip_special_in_progress = false;
+    int special_begin_in_progress = 1 << 30;
 };
 
 namespace whi {
