@@ -319,6 +319,22 @@ int wh_add_word_timestamps(const wh_tokenizer* tok, const char* language_code, c
                            const wh_segment* segments, int n_segments, const int32_t* tokens, const float* logprobs, int n_tokens,
                            const float* alignment, int alignment_rows, int seek, float last_speech_timestamp,
                            int skip_special_tokens, wh_transcription** out);
+/* SegmentSeeker.mergePunctuations(alignment:prepended:appended:) (Core/Text/SegmentSeeker.swift:280-338) on a caller-supplied
+ * word list: words[i] (UTF-8) owns word_token_counts[i] consecutive ids of word_tokens.  NULL punctuation sets = the
+ * reference defaults.  The merged words are returned as the words of a new transcription (wh_transcription_word*). */
+int wh_merge_punctuations(const char* const* words, const int32_t* word_token_counts, const int32_t* word_tokens,
+                          const float* start, const float* end, const float* probability, int n_words,
+                          const char* prepended, const char* appended, wh_transcription** out);
+/* The tail of addWordTimestamps after findAlignment (Core/Text/SegmentSeeker.swift:472-495) on a caller-supplied alignment:
+ * calculateWordDurationConstraints (:498-507, returned through median_out / max_duration_out), truncateLongWordsAtSentenceBoundaries
+ * (:509-526), mergePunctuations, updateSegmentsWithWordTimings (:528-659).  tok may be NULL unless a merged word mixes special
+ * and text tokens (its text is then re-decoded). */
+int wh_update_segments_with_word_timings(const wh_tokenizer* tok, int special_token_begin, const wh_segment* segments, int n_segments,
+                                         const int32_t* tokens, int n_tokens, const char* const* words,
+                                         const int32_t* word_token_counts, const int32_t* word_tokens, const float* start,
+                                         const float* end, const float* probability, int n_words, int seek,
+                                         float last_speech_timestamp, float* median_out, float* max_duration_out,
+                                         wh_transcription** out);
 
 /* ---- result assembly and on-disk formats ------------------------------------------------------------ */
 /* TranscriptionResult(text:segments:language:timings:seekTime:) from parts (tok may be NULL: no text); seek_time NAN = nil */

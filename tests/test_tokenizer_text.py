@@ -312,3 +312,111 @@ def test_native_window_assembly_equals_oracle(ntoks, otoks, word_timestamps, ski
         assert got.tokens == all_tokens
         assert got.text == od.trim_whitespaces(o.decode([t for t in all_tokens if t < st.specialTokenBegin]))
         assert got.language == "en"
+
+
+# ---------------------------------------------------------------------------------------------- reference word KATs on the native code
+def _nw(word, tokens, start, end, prob=1.0):
+    return api.WordTiming(list(tokens), float(start), float(end), float(prob), word)
+
+
+def _same_words(got, expected):
+    assert [(g.word, g.tokens, np.float32(g.start), np.float32(g.end), np.float32(g.probability)) for g in got] == \
+        [(e.word, e.tokens, np.float32(e.start), np.float32(e.end), np.float32(e.probability)) for e in expected]
+
+
+def test_native_kat_merge_punctuations():
+    """UnitTests.swift:2484-2667 testMergePunctuations{,Spanish,SpanishStartWithPrepend,Japanese} through wh_merge_punctuations."""
+    assert api.mergePunctuations([]) == []
+    words = [_nw("<|0.00|>", [50364], 0, 1), _nw(" Hello", [2425], 1, 2), _nw(",", [11], 2, 3), _nw(" world", [1002], 3, 4),
+             _nw("!", [0], 4, 5), _nw("<|1.00|>", [50414], 5, 6), _nw("<|1.00|>", [50414], 6, 7), _nw(" This", [639], 7, 8),
+             _nw(" is", [307], 8, 9), _nw(" a", [257], 9, 10), _nw(" test", [220, 31636], 10, 11), _nw(",", [11], 11, 12),
+             _nw(" isn't", [1943, 380], 12, 13), _nw(" it", [309], 13, 14), _nw("?", [30], 14, 15), _nw("<|endoftext|>", [50257], 15, 16)]
+    _same_words(api.mergePunctuations(words, prepended="\"'“¿([{-", appended="\"'.。,，!！?？:：”)]}、"),
+                [_nw("<|0.00|>", [50364], 0, 1), _nw(" Hello,", [2425, 11], 1, 2), _nw(" world!", [1002, 0], 3, 4),
+                 _nw("<|1.00|>", [50414], 5, 6), _nw("<|1.00|>", [50414], 6, 7), _nw(" This", [639], 7, 8), _nw(" is", [307], 8, 9),
+                 _nw(" a", [257], 9, 10), _nw(" test,", [220, 31636, 11], 10, 11), _nw(" isn't", [1943, 380], 12, 13),
+                 _nw(" it?", [309, 30], 13, 14), _nw("<|endoftext|>", [50257], 15, 16)])
+    words = [_nw("<|notimestamps|>", [50363], 0, 1), _nw(" ¡", [24364], 0, 1), _nw("Hola", [48529], 1, 2), _nw(" Mundo", [376, 6043], 2, 3),
+             _nw("!", [0], 3, 4), _nw(" Esta", [20547], 4, 5), _nw(" es", [785], 5, 6), _nw(" una", [2002], 6, 7),
+             _nw(" prueba", [48241], 7, 8), _nw(",", [11], 8, 9), _nw(" ¿", [3841], 9, 10), _nw("no", [1771], 10, 11), _nw("?", [30], 11, 12),
+             _nw("<|endoftext|>", [50257], 12, 13)]
+    _same_words(api.mergePunctuations(words),
+                [_nw("<|notimestamps|>", [50363], 0, 1), _nw(" ¡Hola", [24364, 48529], 1, 2), _nw(" Mundo!", [376, 6043, 0], 2, 3),
+                 _nw(" Esta", [20547], 4, 5), _nw(" es", [785], 5, 6), _nw(" una", [2002], 6, 7), _nw(" prueba,", [48241, 11], 7, 8),
+                 _nw(" ¿no?", [3841, 1771, 30], 10, 11), _nw("<|endoftext|>", [50257], 12, 13)])
+    words = [_nw(" ¿", [1201], 0, 1), _nw("Que", [1202], 1, 2, 0.9), _nw(" pasa", [1203], 2, 3), _nw(" mundo", [1204], 3, 4, 0.6),
+             _nw("?", [1205], 4, 5, 0.4)]
+    _same_words(api.mergePunctuations(words), [_nw(" ¿Que", [1201, 1202], 1, 2, 0.9), _nw(" pasa", [1203], 2, 3), _nw(" mundo?", [1204, 1205], 3, 4, 0.6)])
+    words = [_nw("<|0.00|>", [50364], 0, 1), _nw("こんにちは", [38088], 1, 2), _nw("、", [1231], 2, 3), _nw("世界", [24486], 3, 4),
+             _nw("！", [171, 120, 223], 4, 5), _nw("これは", [25212], 5, 6), _nw("テ", [22985], 6, 7), _nw("スト", [40498], 7, 8),
+             _nw("です", [4767], 8, 9), _nw("よね", [30346], 9, 10), _nw("？", [171, 120, 253], 10, 11), _nw("<|endoftext|>", [50257], 11, 12)]
+    _same_words(api.mergePunctuations(words),
+                [_nw("<|0.00|>", [50364], 0, 1), _nw("こんにちは、", [38088, 1231], 1, 2), _nw("世界！", [24486, 171, 120, 223], 3, 4),
+                 _nw("これは", [25212], 5, 6), _nw("テ", [22985], 6, 7), _nw("スト", [40498], 7, 8), _nw("です", [4767], 8, 9),
+                 _nw("よね？", [30346, 171, 120, 253], 9, 10), _nw("<|endoftext|>", [50257], 11, 12)])
+
+
+def _nseg(i, start, end, tokens):
+    return api.TranscriptionSegment(i, 0, start, end, list(tokens), [0.0] * len(tokens), 0.0, 0.0, 1.0, 0.0, [])
+
+
+def test_native_kat_long_word_durations():
+    """UnitTests.swift:2754-2867 testLongWordDurations through wh_update_segments_with_word_timings, and equal to the oracle."""
+    words = [_nw(" The", [264], 0.5, 1.0), _nw(" first", [4589], 1.0, 2.0), _nw(" segment", [234], 2.0, 3.0), _nw(" with", [567], 3.0, 4.0),
+             _nw(" a", [257], 4.0, 5.0), _nw(" long", [890], 5.0, 6.0), _nw(" ending", [123], 6.0, 35.0), _nw(".", [13], 35.0, 35.0)]
+    upd, med, mx = api.updateSegmentsWithWordTimings([_nseg(0, 0.0, 6.0, [264, 4589, 234, 567, 257, 890]), _nseg(1, 6.5, 30.0, [123, 13])],
+                                                     words, 0, 0.0, 50257)
+    assert med == pytest.approx(0.7, abs=1e-7) and mx == pytest.approx(1.4, abs=1e-6)
+    allw = [w for g in upd for w in g.words]
+    assert len(upd) == 2
+    assert allw[-1].end - allw[-1].start == pytest.approx(mx, abs=1e-4)
+    assert upd[-1].end - upd[-1].start <= 19.5
+    k = next(i for i, w in enumerate(allw) if w.word == " ending.")
+    assert allw[k].end - allw[k].start == pytest.approx(mx, abs=1e-4) and allw[k].start == pytest.approx(33.6, abs=1e-5)
+    assert all(a.end <= b.start for a, b in zip(allw, allw[1:]))
+    ow = [od.WordTiming(w.word, w.tokens, w.start, w.end, w.probability) for w in words]
+    osegs = [od.TranscriptionSegment(0, 0, 0.0, 6.0, "", [264, 4589, 234, 567, 257, 890], [], 0, 0, 1, 0),
+             od.TranscriptionSegment(1, 0, 6.5, 30.0, "", [123, 13], [], 0, 0, 1, 0)]
+    omed, omx = od.calculate_word_duration_constraints(ow)
+    want = od.update_segments_with_word_timings(osegs, od.merge_punctuations(od.truncate_long_words_at_sentence_boundaries(ow, omx)), 0, 0.0,
+                                                omed, omx, 50257)
+    for g, w in zip(upd, want):
+        assert np.float32(g.start) == np.float32(w.start) and np.float32(g.end) == np.float32(w.end)
+        _same_words(g.words, [_nw(x.word, x.tokens, x.start, x.end, x.probability) for x in w.words])
+
+
+def test_native_kat_single_token_segment_word_duration(ntoks):
+    """UnitTests.swift:2869-2937 testSingleTokenSegmentWordDuration."""
+    words = [_nw("<|notimestamps|>", [50363], 0, 0.5), _nw(" Hello", [314], 0.5, 20.5), _nw("<|endoftext|>", [50257], 20.5, 30)]
+    upd, med, mx = api.updateSegmentsWithWordTimings([_nseg(0, 0.0, 30.0, [314])], words, 0, 0.0, 50257, ntoks[51865])
+    assert med == pytest.approx(0.7, abs=1e-7) and mx == pytest.approx(1.4, abs=1e-6)
+    ws = upd[0].words
+    hello = next(w for w in ws if w.word == " Hello")
+    assert hello.end - hello.start <= mx + 1e-6
+    prev_end = 0.0
+    for w in ws:
+        assert w.start >= prev_end and w.end - w.start <= mx + 1e-6
+        prev_end = w.end
+
+
+def test_native_text_entry_points_reject_bad_arguments(tmp_path, ntoks):
+    """Error behaviour of the host-only entry points: status codes mirror WhisperError, nothing aborts."""
+    with pytest.raises(api.WhisperError) as e:
+        api.Tokenizer(str(tmp_path / "missing.json"))
+    assert e.value.code == 1                                             # tokenizerUnavailable
+    bad = tmp_path / "tokenizer.json"
+    bad.write_text('{"model": {"type": "WordPiece", "vocab": {}}, "decoder": {"type": "WordPiece"}}')
+    with pytest.raises(api.WhisperError) as e:
+        api.Tokenizer(str(bad))
+    assert e.value.code == 1
+    bad.write_text('{"model": ')
+    with pytest.raises(api.WhisperError):
+        api.Tokenizer(str(bad))
+    seg = _nseg(0, 0.0, 1.0, [50363, 314])
+    with pytest.raises(api.WhisperError) as e:                           # mixed special + text word needs a tokenizer to re-decode
+        api.updateSegmentsWithWordTimings([seg], [_nw("<|notimestamps|> Hello", [50363, 314], 0, 1), _nw(" x", [400], 1, 2)], 0, 0.0, 50257)
+    assert e.value.code == 1
+    plain = api.makeTranscriptionResult([seg], None, specialTokens=ntoks[51865].specialTokens)
+    assert plain.text is None
+    with pytest.raises(api.WhisperError):
+        plain.writeSRT(str(tmp_path / "x.srt"))                          # no text without a tokenizer

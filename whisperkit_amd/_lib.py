@@ -152,6 +152,9 @@ SYMBOLS = {
     "wh_transcription_word_tokens": (I, [VP, C.POINTER(PI32), C.POINTER(I)]),
     "wh_transcription_seek_time": (I, [VP, PF]),
     "wh_add_word_timestamps": (I, [VP, C.c_char_p, PST, C.POINTER(WhSegment), I, PI32, PF, I, PF, I, I, F, I, PVP]),
+    "wh_merge_punctuations": (I, [C.POINTER(C.c_char_p), PI32, PI32, PF, PF, PF, I, C.c_char_p, C.c_char_p, PVP]),
+    "wh_update_segments_with_word_timings": (I, [VP, I, C.POINTER(WhSegment), I, PI32, I, C.POINTER(C.c_char_p), PI32, PI32, PF, PF, PF, I, I, F,
+                                                 PF, PF, PVP]),
     "wh_transcription_create": (I, [VP, PST, C.POINTER(WhSegment), I, PI32, PF, I, I, I, F, C.POINTER(WhTimings), PVP]),
     "wh_transcription_add_window": (I, [VP, VP, POPT, PST, C.POINTER(WhDecodingResult), PF, I, I, PI32]),
     "wh_transcription_finalize": (I, [VP, VP, POPT, PST]),

@@ -185,6 +185,8 @@ class TranscriptionResult:
     def allWords(self) -> List[WordTiming]:
         return [w for g in self.segments for w in g.words]
 
+    allWordsFlat: List[WordTiming] = dataclasses.field(default_factory=list, repr=False, compare=False)   # every word of the C object
+
 
 def _string(fn, *args) -> str:
     n = fn(*args, None, 0)
@@ -227,11 +229,12 @@ def _collect(h) -> TranscriptionResult:
     _check(lib.wh_transcription_window_seeks(h, C.byref(sp), C.byref(sn)))
     sk = C.c_float()
     has_seek = lib.wh_transcription_seek_time(h, C.byref(sk))
+    flat = list(words)
     res = TranscriptionResult(segs, toks, lib.wh_transcription_language_token(h),
                               {k: getattr(t, k) for k, _ in L.WhTimings._fields_}, [sp[i] for i in range(sn.value)],
                               _string(lib.wh_transcription_text, h) if has_text else None,
                               _string(lib.wh_transcription_language, h) if has_text else None,
-                              sk.value if has_seek else None, h)
+                              sk.value if has_seek else None, h, flat)
     weakref.finalize(res, lib.wh_transcription_free, h)
     return res
 
@@ -692,3 +695,39 @@ class WindowAssembler:
         _check(self.lib.wh_transcription_finalize(self.handle, self.tokenizer.handle if self.tokenizer else None, C.byref(o), C.byref(self.st)))
         h, self.handle = self.handle, None
         return _collect(h)
+
+
+def _words_to_c(words: Sequence[WordTiming]):
+    n = len(words)
+    texts = (C.c_char_p * max(n, 1))(*[w.word.encode("utf-8") for w in words])
+    counts = np.ascontiguousarray([len(w.tokens) for w in words], dtype=np.int32)
+    toks = np.ascontiguousarray([t for w in words for t in w.tokens], dtype=np.int32)
+    st = np.ascontiguousarray([w.start for w in words], dtype=np.float32)
+    en = np.ascontiguousarray([w.end for w in words], dtype=np.float32)
+    pr = np.ascontiguousarray([w.probability for w in words], dtype=np.float32)
+    keep = (texts, counts, toks, st, en, pr)
+    return keep, (texts, counts.ctypes.data_as(L.PI32), toks.ctypes.data_as(L.PI32), st.ctypes.data_as(L.PF), en.ctypes.data_as(L.PF),
+                  pr.ctypes.data_as(L.PF), n)
+
+
+def mergePunctuations(alignment: Sequence[WordTiming], prepended: Optional[str] = None, appended: Optional[str] = None) -> List[WordTiming]:
+    """SegmentSeeker.mergePunctuations (Core/Text/SegmentSeeker.swift:280-338)."""
+    keep, args = _words_to_c(alignment)
+    out = C.c_void_p()
+    _check(L.load().wh_merge_punctuations(*args, None if prepended is None else prepended.encode("utf-8"),
+                                          None if appended is None else appended.encode("utf-8"), C.byref(out)))
+    return _collect(out).allWordsFlat
+
+
+def updateSegmentsWithWordTimings(segments: Sequence[TranscriptionSegment], alignment: Sequence[WordTiming], seek: int,
+                                  lastSpeechTimestamp: float, specialTokenBegin: int, tokenizer: Optional[Tokenizer] = None):
+    """calculateWordDurationConstraints + truncateLongWordsAtSentenceBoundaries + mergePunctuations + updateSegmentsWithWordTimings
+    (Core/Text/SegmentSeeker.swift:472-659).  Returns (segments with words, constrainedMedianDuration, maxDuration)."""
+    segs, toks, _ = _segments_to_c(segments)
+    keep, args = _words_to_c(alignment)
+    med, mx = C.c_float(), C.c_float()
+    out = C.c_void_p()
+    _check(L.load().wh_update_segments_with_word_timings(tokenizer.handle if tokenizer else None, specialTokenBegin, segs, len(segments),
+                                                         toks.ctypes.data_as(L.PI32), len(toks), *args, seek, lastSpeechTimestamp,
+                                                         C.byref(med), C.byref(mx), C.byref(out)))
+    return _collect(out).segments, med.value, mx.value

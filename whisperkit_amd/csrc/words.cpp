@@ -250,3 +250,94 @@ extern "C" int wh_add_word_timestamps(const wh_tokenizer* tok, const char* langu
     *out = tr;
     return WH_OK;
 }
+
+using namespace whi;
+
+// ---- the reference's public SegmentSeeker helpers on caller-supplied word lists (known-answer tests, callers that bring their
+// own alignment) ----------------------------------------------------------------------------------------------------------------
+static bool words_from_c(const char* const* words, const int32_t* token_counts, const int32_t* tokens, const float* start,
+                         const float* end, const float* probability, int n, std::vector<Word>& out) {
+    if (n < 0 || (n && (!words || !token_counts || !tokens || !start || !end || !probability))) return false;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!words[i] || token_counts[i] < 0) return false;
+        Word w;
+        w.word = words[i];
+        w.tokens.assign(tokens + off, tokens + off + token_counts[i]);
+        off += (size_t)token_counts[i];
+        w.start = start[i]; w.end = end[i]; w.probability = probability[i];
+        out.push_back(std::move(w));
+    }
+    return true;
+}
+
+static void words_into(wh_transcription* tr, const std::vector<Word>& ws) {
+    for (auto& w : ws) {
+        wh_word_timing wt{};
+        wt.token_offset = (int)tr->word_tokens.size(); wt.n_tokens = (int)w.tokens.size();
+        wt.start = w.start; wt.end = w.end; wt.probability = w.probability;
+        tr->word_tokens.insert(tr->word_tokens.end(), w.tokens.begin(), w.tokens.end());
+        tr->words.push_back(wt);
+        tr->word_text.push_back(w.word);
+    }
+    tr->has_text = true;
+}
+
+// SegmentSeeker.mergePunctuations(alignment:prepended:appended:) (SegmentSeeker.swift:280-338); NULL punctuation sets = the defaults
+extern "C" int wh_merge_punctuations(const char* const* words, const int32_t* word_token_counts, const int32_t* word_tokens,
+                                     const float* start, const float* end, const float* probability, int n_words,
+                                     const char* prepended, const char* appended, wh_transcription** out) {
+    std::vector<Word> in;
+    if (!out || !words_from_c(words, word_token_counts, word_tokens, start, end, probability, n_words, in))
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_merge_punctuations: invalid argument");
+    auto tr = new wh_transcription();
+    words_into(tr, whi::merge_punctuations(in, prepended ? prepended : whi::kDefaultPrependPunctuations,
+                                           appended ? appended : whi::kDefaultAppendPunctuations));
+    *out = tr;
+    return WH_OK;
+}
+
+// The tail of addWordTimestamps after findAlignment (SegmentSeeker.swift:472-495) on a caller-supplied alignment:
+// calculateWordDurationConstraints, truncateLongWordsAtSentenceBoundaries, mergePunctuations, updateSegmentsWithWordTimings.
+// `tok` is only needed when a merged word loses special tokens (its text is re-decoded) and may be NULL otherwise.
+extern "C" int wh_update_segments_with_word_timings(const wh_tokenizer* tok, int special_token_begin, const wh_segment* segments, int n_segments,
+                                                    const int32_t* tokens, int n_tokens, const char* const* words,
+                                                    const int32_t* word_token_counts, const int32_t* word_tokens, const float* start,
+                                                    const float* end, const float* probability, int n_words, int seek,
+                                                    float last_speech_timestamp, float* median_out, float* max_duration_out,
+                                                    wh_transcription** out) {
+    std::vector<Word> alignment;
+    if (!out || n_segments < 0 || (n_segments && !segments) || (n_tokens && !tokens) ||
+        !words_from_c(words, word_token_counts, word_tokens, start, end, probability, n_words, alignment))
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_update_segments_with_word_timings: invalid argument");
+    for (int s = 0; s < n_segments; ++s)
+        if (segments[s].token_offset < 0 || segments[s].n_tokens < 0 || segments[s].token_offset + segments[s].n_tokens > n_tokens)
+            return set_error(WH_ERR_INVALID_ARGUMENT, "wh_update_segments_with_word_timings: segment %d indexes outside the token array", s);
+    float median = 0, max_duration = 0;
+    word_duration_constraints(alignment, &median, &max_duration);
+    if (median_out) *median_out = median;
+    if (max_duration_out) *max_duration_out = max_duration;
+    truncate_long_words(alignment, max_duration);
+    if (!alignment.empty()) alignment = whi::merge_punctuations(alignment, whi::kDefaultPrependPunctuations, whi::kDefaultAppendPunctuations);
+    for (auto& w : alignment) {
+        bool loses = false, keeps = false;
+        for (int t : w.tokens) (t < special_token_begin ? keeps : loses) = true;
+        if (loses && keeps && !tok) return set_error(WH_ERR_TOKENIZER_UNAVAILABLE, "a merged word lost special tokens: a tokenizer is needed to re-decode it");
+    }
+    auto tr = new wh_transcription();
+    tr->tokens.assign(tokens, tokens + n_tokens);
+    tr->logprobs.assign((size_t)n_tokens, 0.0f);
+    tr->segments.assign(segments, segments + n_segments);
+    std::vector<SegWords> per_segment;
+    update_segments_with_word_timings(tok, special_token_begin, tr->segments, tr->tokens.data(), alignment, seek, last_speech_timestamp, median,
+                                      max_duration, per_segment);
+    for (int s = 0; s < n_segments; ++s) {
+        tr->segments[s].word_offset = (int)tr->words.size();
+        words_into(tr, per_segment[s].words);
+        tr->segments[s].n_words = (int)tr->words.size() - tr->segments[s].word_offset;
+        tr->segment_text.emplace_back();
+    }
+    tr->has_text = true;
+    *out = tr;
+    return WH_OK;
+}
