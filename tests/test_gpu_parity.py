@@ -443,6 +443,7 @@ def _assert_tokens_match(got_tokens, ores, record, start=0):
 
 @pytest.mark.parametrize("which,kw", [
     ("micro", dict(sampleLength=40)),
+    ("micro", dict(sampleLength=224)),        # full context: 223 decoder steps, every KV-cache position written
     ("micro", dict(sampleLength=24, withoutTimestamps=True)),
     ("micro", dict(sampleLength=30, prefixTokens=[400, 370, 452], promptTokens=[11, 12, 13, 60000])),
     ("micro_ml", dict(sampleLength=32, suppressBlank=True, suppressTokens=[5, 6, 7])),
@@ -768,3 +769,84 @@ def test_progress_callback_and_early_stop(micro):
     sess.setProgressCallback(None)
     sess.resetDecoderInputs(2)
     assert [r.tokens for r in sess.decodeText(prompt, opts, batch=2)] == [r.tokens for r in base]
+
+
+def test_transcribe_edge_case_audio(micro):
+    """Empty audio, audio shorter than windowClipTime (no window is ever decoded: `seek < clipEnd - windowPadding` fails at once,
+    TranscribeTask.swift:105-116), a silent window and a ragged batch (0.5 s, 1.5 s, 30 s, 31 s in one device batch)."""
+    dims, _, model, om = micro
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=8)
+    sess = api.Session(model, 4)
+    for r in sess.transcribe([np.zeros(0, np.float32), synthetic_chunk(5)[:8000]], opts):
+        assert r.segments == [] and r.tokens == [] and r.seeks == [] and r.timings["total_decoding_windows"] == 0
+    never = lambda *a: (_ for _ in ()).throw(AssertionError("no window may be decoded"))
+    o = OD.transcribe_task_run(synthetic_chunk(5)[:8000], OD.DecodingOptions(**NOFALLBACK, sampleLength=8), st, False, langs, dims.n_vocab, never, never)
+    assert o.segments == [] and o.seeks == []
+    audios = [synthetic_chunk(5)[:8000], synthetic_chunk(6)[:24000], np.zeros(480000, np.float32),
+              np.concatenate([synthetic_chunk(7), synthetic_chunk(8)[:16000]])]
+    rb = sess.transcribe(audios, opts)
+    s1 = api.Session(model, 1)
+    for a, r in zip(audios, rb):
+        r1 = s1.transcribe([a], opts)[0]
+        assert r.tokens == r1.tokens and r.seeks == r1.seeks
+        assert [(g.start, g.end, g.seek) for g in r.segments] == [(g.start, g.end, g.seek) for g in r1.segments]
+        assert all(0 <= k < max(len(a), 1) for k in r.seeks)
+    assert rb[0].seeks == [] and rb[1].seeks[0] == 0 and rb[2].seeks[0] == 0 and rb[3].seeks[0] == 0 and len(rb[2].segments) >= 1
+    assert all(np.isfinite(g.start) and np.isfinite(g.end) and np.isfinite(g.avgLogprob) for r in rb for g in r.segments)
+
+
+def test_transcribe_chunked_with_tokenizer_and_merge(micro, tmp_path):
+    """.vad chunking with a tokenizer attached: every chunk result carries seekTime = offset / 16000 (AudioChunker.swift:22,30), its
+    segment texts, shifted word times; mergeTranscriptionResults joins the chunk texts with " " and keeps the segments in order."""
+    from oracle import tokenizer as OT
+    from whisperkit_amd import synth
+    dims, _, model, _ = micro
+    tj = synth.write_kat_tokenizer(str(tmp_path), dims.n_vocab)
+    ntok, otok = api.Tokenizer(tj), OT.Tokenizer(tj)
+    gap = np.zeros(24000, np.float32)
+    audio = np.concatenate([synthetic_chunk(91)[:400000], gap, synthetic_chunk(92)[:350000], gap, synthetic_chunk(93)[:320000]])
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12, wordTimestamps=True)
+    sess = api.Session(model, 4)
+    sess.setTokenizer(ntok)
+    got = sess.transcribeChunked(audio, opts)
+    chunks = OD.vad_chunk_all(audio)
+    assert [off for off, _ in got] == [off for off, _ in chunks] and len(got) >= 3
+    for off, r in got:
+        assert r.seekTime == float(np.float32(off) / np.float32(16000)) and r.text is not None and r.language is not None
+        for g in r.segments:
+            assert g.text == otok.decode(g.tokens)
+            assert g.start >= off / 16000 - 1e-3 and all(w.start >= off / 16000 - 1e-3 for w in g.words)
+            assert all(w.word != "" for w in g.words)
+    merged = api.mergeTranscriptionResults([r for _, r in got])
+    assert merged.text == " ".join(r.text for _, r in got)
+    assert [g.tokens for g in merged.segments] == [g.tokens for _, r in got for g in r.segments]
+    assert [g.text for g in merged.segments] == [g.text for _, r in got for g in r.segments]
+    assert [w.word for w in merged.allWords] == [w.word for _, r in got for w in r.allWords]
+    assert merged.timings["input_audio_seconds"] == pytest.approx(sum(len(s) for _, s in chunks) / 16000.0)
+    assert merged.timings["total_decoding_windows"] == sum(r.timings["total_decoding_windows"] for _, r in got)
+    merged.writeVTT(str(tmp_path / "m.vtt"))
+    assert (tmp_path / "m.vtt").read_text(encoding="utf-8").startswith("WEBVTT\n\n")
+
+
+def test_transcribe_detect_language_reports_language_code(micro_ml, tmp_path):
+    """Multilingual model, detectLanguage on: the language token sampled by detectLanguage (TextDecoder.swift:420-539) enters the
+    prefill prompt (TranscribeTask.swift:341-356) and its decoded, trimmed text is the result's language."""
+    from oracle import tokenizer as OT
+    from whisperkit_amd import synth
+    dims, _, model, _ = micro_ml
+    tj = synth.write_kat_tokenizer(str(tmp_path), dims.n_vocab)
+    ntok, otok = api.Tokenizer(tj), OT.Tokenizer(tj)
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+    x = synthetic_chunk(52)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=8, detectLanguage=True)
+    sess = api.Session(model, 1)
+    sess.setTokenizer(ntok)
+    res = sess.transcribe([x], opts)[0]
+    s2 = api.Session(model, 1)
+    s2.padOrTrim(x); s2.logMelSpectrogram(1); s2.encodeFeatures(1); s2.prepareDecoderInputs(1)
+    lt, _ = s2.detectLanguage(1)
+    assert lt[0] in langs and res.languageToken == lt[0]
+    assert res.language == otok.decode([lt[0]]).strip("<|>") and res.language in synth.LANGUAGE_CODES
+    first = res.segments[0].tokens
+    assert first[0] == st.startOfTranscriptToken and first[1] == lt[0] and first[2] == st.transcribeToken
