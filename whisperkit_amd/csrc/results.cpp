@@ -151,6 +151,8 @@ extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokeni
                                            const wh_special_tokens* st, const wh_decoding_result* res, const float* alignment,
                                            int default_language_token, int segment_size, int32_t* seek_inout) {
     if (!tr || !opt || !st || !res || !seek_inout) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_add_window: null argument");
+    if (res->n_tokens < 0 || res->n_tokens > WH_MAX_RESULT_TOKENS)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_add_window: n_tokens %d outside [0, %d]", res->n_tokens, WH_MAX_RESULT_TOKENS);
     if (!tr->language_set) { tr->language_token = res->language_token; tr->language_set = true; }   // "Use the predicted language if it was not detected ahead of time"
     const int prev_seek = *seek_inout;
     wh_segment segs[WH_MAX_RESULT_TOKENS];
@@ -456,6 +458,7 @@ extern "C" int wh_convert_to_mono(const float* const* channels, int n_channels, 
 extern "C" int wh_resample(const float* in, int n_in, double in_rate, double out_rate, float* out, int capacity) {
     if (!in || n_in < 0 || in_rate <= 0 || out_rate <= 0) { set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "wh_resample: invalid argument"); return -1; }
     const long long n_out = (long long)((double)n_in / in_rate * out_rate);   // AVAudioFrameCount(inputDuration * sampleRate)
+    if (n_out > 0x7fffffffLL) { set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "wh_resample: output too long"); return -1; }
     if (!out) return (int)n_out;
     if (n_out > capacity) { set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "wh_resample: %lld frames do not fit", n_out); return -1; }
     if (in_rate == out_rate) { memcpy(out, in, sizeof(float) * (size_t)n_out); return (int)n_out; }
@@ -549,9 +552,11 @@ extern "C" int wh_load_audio(const char* path, int channel_mode, const int32_t* 
     Wav w;
     if (!parse_wav(file, w, err)) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "%s: %s", path, err.c_str());
     const long long length = (long long)(w.data_bytes / (size_t)w.block);
+    if (std::isnan(start_time) || start_time < 0) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "start time must be a non-negative number");
     const long long start = (long long)(start_time * w.rate);
     const long long end = std::isnan(end_time) ? length : std::min((long long)(end_time * w.rate), length);
-    if (start < 0 || start > end) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "start time %.3f s is outside the file", start_time);
+    if (start > end) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "start time %.3f s is outside the file", start_time);
+    if (end - start > 0x7fffffffLL) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "audio too long for one buffer");
     const long long frames = end - start;
     const int bps = w.bits / 8;
     std::vector<float> mono;

@@ -215,7 +215,7 @@ extern "C" int wh_tokenizer_load(const char* tokenizer_json_path, wh_tokenizer**
         return set_error(WH_ERR_TOKENIZER_UNAVAILABLE, "%s: not a ByteLevel BPE tokenizer", tokenizer_json_path);
     auto t = new wh_tokenizer();
     auto put = [&](const std::string& tok, int id, bool added, bool special) {
-        if (id < 0 || id > (1 << 24)) return;
+        if (id < 0 || id > (1 << 22)) return;   // ids far beyond any Whisper vocabulary are ignored
         if (id >= (int)t->has.size()) {
             t->has.resize(id + 1, 0); t->is_added.resize(id + 1, 0); t->is_special.resize(id + 1, 0);
             t->id_to_token.resize(id + 1); t->id_bytes.resize(id + 1);
