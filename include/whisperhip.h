@@ -356,6 +356,13 @@ int wh_transcription_finalize(wh_transcription* t, const wh_tokenizer* tok, cons
  * (a failed chunk); confirmed_words != NULL replaces the joined text by the concatenation of those words */
 int wh_merge_transcriptions(const wh_transcription* const* results, int n, const char* const* confirmed_words, int n_confirmed,
                             wh_transcription** out);
+/* AudioChunking.updateSeekOffsetsForResults (Core/Audio/AudioChunker.swift:14-39) for one chunk result: every segment / word
+ * shifted by seek_offset_samples / 16000 (TranscriptionUtilities.updateSegmentTimings, Float), result.seekTime set */
+int wh_transcription_apply_seek_offset(wh_transcription* t, int seek_offset_samples);
+/* The Codable JSON document of TranscriptionResult as a string (= what wh_write_json writes; also the wire format of the
+ * multi-GPU result gather, whisperkit_amd/parallel.py) and its decoder (JSONDecoder: unknown keys ignored). */
+int wh_transcription_to_json(const wh_transcription* t, char* out, int capacity);
+int wh_transcription_from_json(const char* json, int nbytes, wh_transcription** out);
 /* ResultWriting.formatTime (Utilities/ResultWriter.swift:14-26) */
 int wh_format_time(float seconds, int always_include_hours, char decimal_marker, char* out, int capacity);
 /* WriteSRT / WriteVTT / WriteJSON (Utilities/ResultWriter.swift:40-134); `path` is the full file name */

@@ -233,3 +233,31 @@ def test_wav_encodings(tmp_path):
     bad.write_bytes(b"RIFF\x00\x00\x00\x00WAVEfmt ")
     with pytest.raises(api.WhisperError):
         api.loadAudio(str(bad))
+
+
+def test_json_document_round_trip(toks):
+    """wh_transcription_to_json -> wh_transcription_from_json reproduces every field of the Codable document bit for bit (floats
+    are written with 9 significant digits, doubles with 17), including words, seekTime and the 33 timing fields."""
+    rng = random.Random(4)
+    res, _ = _result_with_words(toks, rng)
+    shifted = res.withSeekOffset(123456)
+    assert shifted.seekTime == float(np.float32(123456) / np.float32(16000))
+    for a, b in zip(shifted.segments, res.segments):
+        st = np.float32(123456) / np.float32(16000)
+        assert a.seek == b.seek + int(st * np.float32(16000))
+        assert np.float32(a.start) == np.float32(b.start) + st and np.float32(a.end) == np.float32(b.end) + st
+        assert all(np.float32(x.start) == np.float32(y.start) + st for x, y in zip(a.words, b.words))
+    for r in (res, shifted):
+        back = api.TranscriptionResult.fromJSON(r.toJSON())
+        assert back.text == r.text and back.language == r.language and back.seekTime == r.seekTime
+        assert back.timings == r.timings
+        assert [dataclasses_astuple(g) for g in back.segments] == [dataclasses_astuple(g) for g in r.segments]
+        assert json.loads(back.toJSON()) == json.loads(r.toJSON())
+    with pytest.raises(api.WhisperError):
+        api.TranscriptionResult.fromJSON("[1, 2")
+    assert api.TranscriptionResult.fromJSON("{}").segments == []
+
+
+def dataclasses_astuple(g):
+    import dataclasses
+    return dataclasses.astuple(g)

@@ -158,6 +158,9 @@ SYMBOLS = {
     "wh_transcription_create": (I, [VP, PST, C.POINTER(WhSegment), I, PI32, PF, I, I, I, F, C.POINTER(WhTimings), PVP]),
     "wh_transcription_add_window": (I, [VP, VP, POPT, PST, C.POINTER(WhDecodingResult), PF, I, I, PI32]),
     "wh_transcription_finalize": (I, [VP, VP, POPT, PST]),
+    "wh_transcription_apply_seek_offset": (I, [VP, I]),
+    "wh_transcription_to_json": (I, [VP, C.c_char_p, I]),
+    "wh_transcription_from_json": (I, [C.c_char_p, I, PVP]),
     "wh_merge_transcriptions": (I, [PVP, I, C.POINTER(C.c_char_p), I, PVP]),
     "wh_format_time": (I, [F, I, C.c_char, C.c_char_p, I]),
     "wh_write_srt": (I, [VP, C.c_char_p]),

@@ -181,6 +181,23 @@ class TranscriptionResult:
     def writeJSON(self, path: str):
         _check(L.load().wh_write_json(self._handle, path.encode()))
 
+    def toJSON(self) -> str:
+        """The Codable document (JSONEncoder on TranscriptionResult) as a string."""
+        return _string(L.load().wh_transcription_to_json, self._handle)
+
+    @staticmethod
+    def fromJSON(document: str) -> "TranscriptionResult":
+        b = document.encode("utf-8")
+        out = C.c_void_p()
+        _check(L.load().wh_transcription_from_json(b, len(b), C.byref(out)))
+        return _collect(out)
+
+    def withSeekOffset(self, seekOffsetSamples: int) -> "TranscriptionResult":
+        """AudioChunking.updateSeekOffsetsForResults for one chunk result: a shifted copy with seekTime set."""
+        shifted = TranscriptionResult.fromJSON(self.toJSON())
+        _check(L.load().wh_transcription_apply_seek_offset(shifted._handle, seekOffsetSamples))
+        return _collect_again(shifted)
+
     @property
     def allWords(self) -> List[WordTiming]:
         return [w for g in self.segments for w in g.words]
@@ -237,6 +254,15 @@ def _collect(h) -> TranscriptionResult:
                               sk.value if has_seek else None, h, flat)
     weakref.finalize(res, lib.wh_transcription_free, h)
     return res
+
+
+def _collect_again(res: TranscriptionResult) -> TranscriptionResult:
+    """Re-reads the Python mirror after the C object was modified in place (the handle moves to the new mirror)."""
+    lib = L.load()
+    out = C.c_void_p()
+    b = _string(lib.wh_transcription_to_json, res._handle).encode("utf-8")
+    _check(lib.wh_transcription_from_json(b, len(b), C.byref(out)))
+    return _collect(out)
 
 
 class Tokenizer:

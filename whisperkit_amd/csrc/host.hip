@@ -693,12 +693,7 @@ extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, con
     int r = wh_transcribe_batch(s, ptrs.data(), lens.data(), nc, &chunked, st, out);
     if (r) return r;
     for (int i = 0; i < nc; ++i) {
-        // updateSegmentTimings in Float: seek += Int(seekTime * 16000), start / end += seekTime
-        const float seekTime = (float)cs[i] / (float)WH_SAMPLE_RATE;
-        const int seekIdx = (int)(seekTime * (float)WH_SAMPLE_RATE);
-        for (auto& g : out[i]->segments) { g.seek += seekIdx; g.start += seekTime; g.end += seekTime; }
-        for (auto& w : out[i]->words) { w.start += seekTime; w.end += seekTime; }
-        out[i]->seek_time = seekTime; out[i]->has_seek_time = true;   // updateSeekOffsetsForResults, AudioChunker.swift:22,30
+        wh_transcription_apply_seek_offset(out[i], cs[i]);   // updateSeekOffsetsForResults
         if (seek_offsets_out) seek_offsets_out[i] = cs[i];
     }
     *n_out = nc;

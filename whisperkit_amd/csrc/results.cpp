@@ -358,9 +358,7 @@ static void numd(std::string& o, double v) {
 
 // WriteJSON: the Codable encoding of TranscriptionResult (keys = property names; tokenLogProbs = [{"<id>": logprob}];
 // words omitted when nil; seekTime null when nil).  Key order and float spelling are not fixed by JSONEncoder - compare as JSON.
-extern "C" int wh_write_json(const wh_transcription* t, const char* path) {
-    if (!t || !path) return set_error(WH_ERR_INVALID_ARGUMENT, "null argument");
-    if (!t->has_text) return set_error(WH_ERR_TOKENIZER_UNAVAILABLE, "transcription has no text (no tokenizer attached)");
+static std::string transcription_json(const wh_transcription* t) {
     std::string o = "{\n  \"text\" : ";
     wh::json_escape(o, t->text);
     o += ",\n  \"language\" : ";
@@ -420,7 +418,110 @@ extern "C" int wh_write_json(const wh_transcription* t, const char* path) {
     bool first = true;
     for (auto& kv : tv) { o += first ? "\n    \"" : ",\n    \""; first = false; o += kv.first; o += "\" : "; numd(o, kv.second); }
     o += "\n  }\n}\n";
-    return write_file(path, o);
+    return o;
+}
+
+extern "C" int wh_write_json(const wh_transcription* t, const char* path) {
+    if (!t || !path) return set_error(WH_ERR_INVALID_ARGUMENT, "null argument");
+    if (!t->has_text) return set_error(WH_ERR_TOKENIZER_UNAVAILABLE, "transcription has no text (no tokenizer attached)");
+    return write_file(path, transcription_json(t));
+}
+
+// The same document as a string (the wire format of the multi-GPU result gather); works without text too (empty strings).
+extern "C" int wh_transcription_to_json(const wh_transcription* t, char* out, int capacity) {
+    if (!t) { set_error(WH_ERR_INVALID_ARGUMENT, "null transcription"); return -1; }
+    wh_transcription padded;
+    const wh_transcription* src = t;
+    if (t->segment_text.size() < t->segments.size() || t->word_text.size() < t->words.size()) {
+        padded = *t;
+        padded.segment_text.resize(t->segments.size());
+        padded.word_text.resize(t->words.size());
+        src = &padded;
+    }
+    return copy_out(transcription_json(src), out, capacity);
+}
+
+// JSONDecoder on TranscriptionResult: rebuilds the flat container from the Codable document (unknown keys ignored, missing keys default)
+extern "C" int wh_transcription_from_json(const char* json, int nbytes, wh_transcription** out) {
+    if (!json || nbytes < 0 || !out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_from_json: null argument");
+    wh::JsonValue root;
+    std::string err;
+    if (!wh::JsonParser(json, (size_t)nbytes).parse(root, err) || root.kind != wh::JsonValue::Object)
+        return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcription_from_json: %s", err.empty() ? "not a JSON object" : err.c_str());
+    auto numv = [](const wh::JsonValue* v, double d) { return v && v->kind == wh::JsonValue::Number ? v->num : d; };
+    auto strv = [](const wh::JsonValue* v) { return v && v->kind == wh::JsonValue::String ? v->str : std::string(); };
+    auto tr = new wh_transcription();
+    tr->has_text = true;
+    tr->text = strv(root.get("text"));
+    tr->language = strv(root.get("language"));
+    if (const wh::JsonValue* sk = root.get("seekTime")) if (sk->kind == wh::JsonValue::Number) { tr->seek_time = (float)sk->num; tr->has_seek_time = true; }
+    if (const wh::JsonValue* segs = root.get("segments")) {
+        for (auto& g : segs->arr) {
+            if (g.kind != wh::JsonValue::Object) { delete tr; return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcription_from_json: segment is not an object"); }
+            wh_segment c{};
+            c.id = (int)numv(g.get("id"), 0); c.seek = (int)numv(g.get("seek"), 0);
+            c.start = (float)numv(g.get("start"), 0); c.end = (float)numv(g.get("end"), 0);
+            c.temperature = (float)numv(g.get("temperature"), 1.0); c.avg_logprob = (float)numv(g.get("avgLogprob"), 0);
+            c.compression_ratio = (float)numv(g.get("compressionRatio"), 1.0); c.no_speech_prob = (float)numv(g.get("noSpeechProb"), 0);
+            c.token_offset = (int)tr->tokens.size();
+            const wh::JsonValue* toks = g.get("tokens");
+            const wh::JsonValue* lps = g.get("tokenLogProbs");
+            if (toks) for (size_t k = 0; k < toks->arr.size(); ++k) {
+                tr->tokens.push_back((int)numv(&toks->arr[k], 0));
+                float lp = 0;
+                if (lps && k < lps->arr.size() && lps->arr[k].kind == wh::JsonValue::Object && !lps->arr[k].obj.empty()) lp = (float)numv(&lps->arr[k].obj[0].second, 0);
+                tr->logprobs.push_back(lp);
+            }
+            c.n_tokens = (int)tr->tokens.size() - c.token_offset;
+            c.word_offset = (int)tr->words.size();
+            if (const wh::JsonValue* ws = g.get("words")) for (auto& w : ws->arr) {
+                wh_word_timing wt{};
+                wt.token_offset = (int)tr->word_tokens.size();
+                if (const wh::JsonValue* wtok = w.get("tokens")) for (auto& x : wtok->arr) tr->word_tokens.push_back((int)numv(&x, 0));
+                wt.n_tokens = (int)tr->word_tokens.size() - wt.token_offset;
+                wt.start = (float)numv(w.get("start"), 0); wt.end = (float)numv(w.get("end"), 0); wt.probability = (float)numv(w.get("probability"), 0);
+                tr->words.push_back(wt);
+                tr->word_text.push_back(strv(w.get("word")));
+            }
+            c.n_words = (int)tr->words.size() - c.word_offset;
+            tr->segments.push_back(c);
+            tr->segment_text.push_back(strv(g.get("text")));
+        }
+    }
+    if (const wh::JsonValue* tm = root.get("timings")) {
+        wh_timings& m = tr->timings;
+        const std::pair<const char*, double*> tv[] = {
+            {"pipelineStart", &m.pipeline_start}, {"firstTokenTime", &m.first_token_time}, {"inputAudioSeconds", &m.input_audio_seconds},
+            {"modelLoading", &m.model_loading}, {"prewarmLoadTime", &m.prewarm_load_time}, {"encoderLoadTime", &m.encoder_load_time},
+            {"decoderLoadTime", &m.decoder_load_time}, {"encoderSpecializationTime", &m.encoder_specialization_time},
+            {"decoderSpecializationTime", &m.decoder_specialization_time}, {"tokenizerLoadTime", &m.tokenizer_load_time},
+            {"audioLoading", &m.audio_loading}, {"audioProcessing", &m.audio_processing}, {"logmels", &m.logmels}, {"encoding", &m.encoding},
+            {"decodingInit", &m.decoding_init}, {"decodingLoop", &m.decoding_loop}, {"decodingPredictions", &m.decoding_predictions},
+            {"decodingFiltering", &m.decoding_filtering}, {"decodingSampling", &m.decoding_sampling}, {"decodingFallback", &m.decoding_fallback},
+            {"decodingWindowing", &m.decoding_windowing}, {"decodingKvCaching", &m.decoding_kv_caching},
+            {"decodingWordTimestamps", &m.decoding_word_timestamps}, {"decodingNonPrediction", &m.decoding_non_prediction},
+            {"totalAudioProcessingRuns", &m.total_audio_processing_runs}, {"totalLogmelRuns", &m.total_logmel_runs},
+            {"totalEncodingRuns", &m.total_encoding_runs}, {"totalDecodingLoops", &m.total_decoding_loops},
+            {"totalKVUpdateRuns", &m.total_kv_update_runs}, {"totalTimestampAlignmentRuns", &m.total_timestamp_alignment_runs},
+            {"totalDecodingFallbacks", &m.total_decoding_fallbacks}, {"totalDecodingWindows", &m.total_decoding_windows},
+            {"fullPipeline", &m.full_pipeline}};
+        for (auto& kv : tv) *kv.second = numv(tm->get(kv.first), 0.0);
+    }
+    *out = tr;
+    return WH_OK;
+}
+
+// TranscriptionUtilities.updateSegmentTimings for every segment + result.seekTime (AudioChunking.updateSeekOffsetsForResults,
+// Core/Audio/AudioChunker.swift:14-39): shifts a chunk's result to the time base of the full audio, Float arithmetic.
+extern "C" int wh_transcription_apply_seek_offset(wh_transcription* t, int seek_offset_samples) {
+    if (!t) return set_error(WH_ERR_INVALID_ARGUMENT, "null transcription");
+    const float seekTime = (float)seek_offset_samples / (float)WH_SAMPLE_RATE;
+    const int seekIdx = (int)(seekTime * (float)WH_SAMPLE_RATE);
+    for (auto& g : t->segments) { g.seek += seekIdx; g.start += seekTime; g.end += seekTime; }
+    for (auto& w : t->words) { w.start += seekTime; w.end += seekTime; }
+    t->seek_time = seekTime;
+    t->has_seek_time = true;
+    return WH_OK;
 }
 
 // ---- audio ingest ----------------------------------------------------------------------------------------------------------

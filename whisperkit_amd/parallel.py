@@ -60,3 +60,62 @@ def gather_records(local_records: np.ndarray, max_per_rank: int, device=None, gr
         out = t
     recs = [unpack_record(r) for r in out.cpu().numpy()]
     return sorted((r for r in recs if r["chunk_index"] >= 0), key=lambda r: r["chunk_index"])
+
+
+# ------------------------------------------------------------------------------------------------ long audio across GPUs
+def gather_results(local: Sequence[Tuple[int, object]], device=None, group=None) -> List[Tuple[int, object]]:
+    """All-gather of whole TranscriptionResults: `local` = [(chunk_index, TranscriptionResult)] of this rank; every rank receives
+    every (chunk_index, result) sorted by chunk index.  The wire format is the reference's own Codable JSON document
+    (`TranscriptionResult.toJSON`), so two collectives of a few KB: the payload lengths, then the padded payloads."""
+    import json
+
+    import torch
+    import torch.distributed as dist
+
+    from .api import TranscriptionResult
+    payload = json.dumps([[int(i), r.toJSON()] for i, r in local]).encode("utf-8")
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return sorted(((i, r) for i, r in local), key=lambda x: x[0])
+    world = dist.get_world_size(group)
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    sizes = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    cap = int(sizes.max().item())
+    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+    buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(buf.device)
+    out = torch.empty(world * cap, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.cpu().numpy()
+    results = []
+    for r in range(world):
+        doc = bytes(out[r * cap:r * cap + int(sizes[r].item())]).decode("utf-8")
+        results += [(int(i), TranscriptionResult.fromJSON(j)) for i, j in json.loads(doc)]
+    return sorted(results, key=lambda x: x[0])
+
+
+def transcribe_chunked_sharded(session, audio: np.ndarray, options=None, device=None, group=None):
+    """WhisperKit.transcribe(audioArray:) with `.vad` chunking (Core/WhisperKit.swift:867-931) over the GPUs of a node: every rank
+    cuts the audio at the same places (VADAudioChunker, host code), transcribes its contiguous block of chunks as one device batch
+    per `session.B` (clipTimestamps reset, :889-891), shifts the results by the chunk offsets (updateSeekOffsetsForResults), and one
+    gather hands every rank all chunk results in order.  Returns ([(seekOffsetSamples, TranscriptionResult)], merged result)
+    where merged = mergeTranscriptionResults over the chunks (Utilities/TranscriptionUtilities.swift:76-157)."""
+    import dataclasses
+
+    import torch.distributed as dist
+
+    from . import api
+    options = options or api.DecodingOptions()
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    chunks = api.vadChunkAll(audio, options=options) if len(audio) > 480000 else [(0, len(audio))]
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    s, e = partition_chunks(len(chunks), world, rank)
+    chunk_options = dataclasses.replace(options, clipTimestamps=()) if len(chunks) > 1 else options
+    local = []
+    for b0 in range(s, e, session.B):
+        block = chunks[b0:min(b0 + session.B, e)]
+        res = session.transcribe([audio[c0:c1] for c0, c1 in block], chunk_options)
+        local += [(b0 + k, r.withSeekOffset(block[k][0]) if len(chunks) > 1 else r) for k, r in enumerate(res)]
+    everything = gather_results(local, device=device, group=group)
+    ordered = [(chunks[i][0], r) for i, r in everything]
+    return ordered, api.mergeTranscriptionResults([r for _, r in ordered])
