@@ -850,3 +850,27 @@ def test_transcribe_detect_language_reports_language_code(micro_ml, tmp_path):
     assert res.language == otok.decode([lt[0]]).strip("<|>") and res.language in synth.LANGUAGE_CODES
     first = res.segments[0].tokens
     assert first[0] == st.startOfTranscriptToken and first[1] == lt[0] and first[2] == st.transcribeToken
+
+
+def test_transcribe_chunked_sharded_single_rank_equals_transcribe_chunked(micro, tmp_path):
+    """parallel.transcribe_chunked_sharded (the multi-GPU form of the .vad branch) with one rank must reproduce
+    wh_transcribe_chunked: same chunk offsets, tokens, shifted times, texts; the merged result joins the chunk texts."""
+    from whisperkit_amd import parallel, synth
+    dims, _, model, _ = micro
+    ntok = api.Tokenizer(synth.write_kat_tokenizer(str(tmp_path), dims.n_vocab))
+    gap = np.zeros(24000, np.float32)
+    audio = np.concatenate([synthetic_chunk(91)[:400000], gap, synthetic_chunk(92)[:350000], gap, synthetic_chunk(93)[:320000]])
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=10)
+    sess = api.Session(model, 2)            # fewer slots than chunks: the block is transcribed in two device batches
+    sess.setTokenizer(ntok)
+    ordered, merged = parallel.transcribe_chunked_sharded(sess, audio, opts)
+    s4 = api.Session(model, 4)
+    s4.setTokenizer(ntok)
+    want = s4.transcribeChunked(audio, opts)
+    assert [off for off, _ in ordered] == [off for off, _ in want] and len(want) >= 3
+    for (_, a), (_, b) in zip(ordered, want):
+        assert a.seekTime == b.seekTime and a.text == b.text and a.language == b.language
+        assert [(g.id, g.seek, g.tokens, g.text) for g in a.segments] == [(g.id, g.seek, g.tokens, g.text) for g in b.segments]
+        assert all(np.float32(x.start) == np.float32(y.start) and np.float32(x.end) == np.float32(y.end) for x, y in zip(a.segments, b.segments))
+    assert merged.text == " ".join(r.text for _, r in want)
+    assert [g.tokens for g in merged.segments] == [g.tokens for _, r in want for g in r.segments]
