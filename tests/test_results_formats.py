@@ -261,3 +261,25 @@ def test_json_document_round_trip(toks):
 def dataclasses_astuple(g):
     import dataclasses
     return dataclasses.astuple(g)
+
+
+def test_json_words_key_follows_the_optional(toks):
+    """TranscriptionSegment.words is Optional: nil (key absent) unless addWordTimestamps ran, then an array that may be empty
+    (updateSegmentsWithWordTimings always assigns it, SegmentSeeker.swift:655)."""
+    n, o = toks
+    st = o.specialTokens()
+    toks_ = [st.startOfTranscriptToken, st.englishToken, st.transcribeToken, st.timeTokenBegin, st.timeTokenBegin + 100, st.endToken]
+    r = api.DecodingResult(toks_, [0, 0, 0, -0.1, -0.2, -0.3], -0.1, 0.0, 0.0, 1.0, st.englishToken, None, False, False, 6)
+    plain = api.WindowAssembler(api.DecodingOptions(), n)
+    plain.addWindow(r, 0, 480000)
+    j = json.loads(plain.result().toJSON())
+    assert len(j["segments"]) == 1 and "words" not in j["segments"][0]
+    lump = [st.startOfTranscriptToken, st.englishToken, st.transcribeToken, st.timeTokenBegin, st.noSpeechToken, st.timeTokenBegin + 100,
+            st.timeTokenBegin + 100, st.endToken]
+    r2 = api.DecodingResult(lump, [0.0] * 8, -0.1, 0.0, 0.0, 1.0, st.englishToken, None, False, False, 8)
+    timed = api.WindowAssembler(api.DecodingOptions(wordTimestamps=True), n)
+    timed.addWindow(r2, 0, 480000, np.random.default_rng(0).random((8, 1500)).astype(np.float32))
+    res = timed.result()
+    j = json.loads(res.toJSON())
+    assert len(j["segments"]) >= 1 and all(g["words"] == [] for g in j["segments"])      # no text tokens -> no words, but not nil
+    assert json.loads(api.TranscriptionResult.fromJSON(res.toJSON()).toJSON()) == j

@@ -175,6 +175,7 @@ extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokeni
             add_token_timestamps(alignment, *res, st, segs, ns, prev_seek, &win);
         }
         tr->timings.total_timestamp_alignment_runs += 1;
+        tr->words_enabled = true;
         tr->timings.decoding_word_timestamps += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
         int kept = 0;                                   // "Filter out zero length segments" (:217)
         for (int i = 0; i < ns; ++i) if (segs[i].end > segs[i].start) segs[kept++] = segs[i];
@@ -241,6 +242,7 @@ extern "C" int wh_merge_transcriptions(const wh_transcription* const* results, i
     for (size_t ri = 0; ri < valid.size(); ++ri) {
         const wh_transcription* r = valid[ri];
         if (!r->has_text) m->has_text = false;
+        if (r->words_enabled) m->words_enabled = true;
         for (size_t si = 0; si < r->segments.size(); ++si) {
             wh_segment g = r->segments[si];
             g.id = (int)(ri + si);                                  // "updatedSegment.id = resultIndex + segmentIndex" (:99)
@@ -380,7 +382,7 @@ static std::string transcription_json(const wh_transcription* t) {
         o += ", \"avgLogprob\" : "; num(o, g.avg_logprob);
         o += ", \"compressionRatio\" : "; num(o, g.compression_ratio);
         o += ", \"noSpeechProb\" : "; num(o, g.no_speech_prob);
-        if (g.n_words > 0) {
+        if (g.n_words > 0 || t->words_enabled) {   // `words` is nil unless addWordTimestamps ran, then possibly []
             o += ", \"words\" : [";
             for (int k = 0; k < g.n_words; ++k) {
                 const wh_word_timing& w = t->words[g.word_offset + k];
@@ -474,6 +476,7 @@ extern "C" int wh_transcription_from_json(const char* json, int nbytes, wh_trans
             }
             c.n_tokens = (int)tr->tokens.size() - c.token_offset;
             c.word_offset = (int)tr->words.size();
+            if (const wh::JsonValue* ws = g.get("words")) if (ws->kind == wh::JsonValue::Array) tr->words_enabled = true;
             if (const wh::JsonValue* ws = g.get("words")) for (auto& w : ws->arr) {
                 wh_word_timing wt{};
                 wt.token_offset = (int)tr->word_tokens.size();

@@ -66,6 +66,7 @@ struct wh_transcription {
     std::string text, language;
     bool has_text = false;
     bool has_seek_time = false;
+    bool words_enabled = false;      // word timestamps ran: segments carry `words` (possibly empty) instead of nil
     float seek_time = 0;
     int language_token = -1;
     bool language_set = false;       // detectedLanguage is fixed by the first detection / first decoded window (TranscribeTask.swift:352,375-377)

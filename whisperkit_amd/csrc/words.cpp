@@ -239,6 +239,7 @@ extern "C" int wh_add_word_timestamps(const wh_tokenizer* tok, const char* langu
                                      tr->logprobs.data(), alignment, alignment_rows, seek, last_speech_timestamp, tr);
     if (r) { delete tr; return r; }
     tr->has_text = true;
+    tr->words_enabled = true;
     for (auto& g : tr->segments) {
         std::vector<int> t;
         for (int k = 0; k < g.n_tokens; ++k) {
