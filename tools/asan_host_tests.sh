@@ -1,5 +1,6 @@
 #!/bin/bash
-# Runs the host-only C++ (tokenizer.cpp, words.cpp, results.cpp) under AddressSanitizer + UBSan through the CPU tests.
+# Runs the host-only C++ (tokenizer.cpp, words.cpp, results.cpp: ASan + UBSan) and the host side of host.hip / capi.hip (ASan)
+# through the CPU tests.
 # The three files are rebuilt instrumented and linked with the regular HIP objects into a scratch copy of the library, which
 # replaces whisperkit_amd/libwhisperhip.so for the duration of the run.  Needs no GPU.
 set -e
@@ -9,7 +10,11 @@ make -C $CS -j8 >/dev/null
 for f in tokenizer words results; do
   $CLANG -x c++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include -I$CS -c $CS/$f.cpp -o $OUT/$f.o
 done
-(cd $CS && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 mel.o gemm.o layernorm.o attention.o decoder.o capi.o host.o \
+for f in host capi; do   # host side of the HIP files that carry host logic (device code is left alone)
+  /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$CS -Wno-unused-result -Wno-unused-value \
+    -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -c $CS/$f.hip -o $OUT/$f.o
+done
+(cd $CS && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 mel.o gemm.o layernorm.o attention.o decoder.o $OUT/capi.o $OUT/host.o \
   $OUT/tokenizer.o $OUT/words.o $OUT/results.o -o $OUT/libwhisperhip.so -lz -fsanitize=address,undefined -shared-libsan)
 cp $ROOT/whisperkit_amd/libwhisperhip.so $OUT/libwhisperhip.orig.so
 trap 'cp $OUT/libwhisperhip.orig.so $ROOT/whisperkit_amd/libwhisperhip.so' EXIT
