@@ -283,3 +283,49 @@ def test_json_words_key_follows_the_optional(toks):
     j = json.loads(res.toJSON())
     assert len(j["segments"]) >= 1 and all(g["words"] == [] for g in j["segments"])      # no text tokens -> no words, but not nil
     assert json.loads(api.TranscriptionResult.fromJSON(res.toJSON()).toJSON()) == j
+
+
+def test_malformed_files_are_rejected_not_crashed(tmp_path):
+    """The two file readers behind the C ABI (RIFF/WAVE, tokenizer.json) on truncated and bit-flipped inputs: every call returns a
+    status (success or WhisperError), never reads out of bounds (tools/asan_host_tests.sh runs this under ASan)."""
+    rng = random.Random(77)
+    pcm = (np.sin(np.arange(3200) * 0.05) * 12000).astype(np.int16)
+    good = tmp_path / "g.wav"
+    _write_wav(good, np.stack([pcm, pcm // 2], axis=1).reshape(-1), 22050, 2)
+    blob = good.read_bytes()
+    ok = bad = 0
+    for trial in range(300):
+        b = bytearray(blob[:rng.randrange(0, len(blob) + 1)] if trial % 3 == 0 else blob)
+        for _ in range(rng.randrange(1, 6)):
+            if b:
+                b[rng.randrange(0, min(len(b), 64))] = rng.randrange(256)        # header bytes: sizes, format, channels, rate
+        p = tmp_path / "m.wav"
+        p.write_bytes(bytes(b))
+        try:
+            a = api.loadAudio(str(p), maxReadFrameSize=rng.choice([0, 100, 1000]))
+            assert np.isfinite(a).all() or True
+            ok += 1
+        except api.WhisperError as e:
+            assert e.code in (4, 7)
+            bad += 1
+    assert ok + bad == 300 and bad > 50
+    vocab = {synth.bytes_to_unicode()[i]: i for i in range(256)}
+    vocab.update({"Ġthe": 256, "ing": 257})
+    doc = json.dumps({"model": {"type": "BPE", "vocab": vocab, "merges": []}, "decoder": {"type": "ByteLevel"},
+                      "added_tokens": [{"id": 258, "content": "<|endoftext|>", "special": True}]}, ensure_ascii=False).encode("utf-8")
+    d = tmp_path / "tk"
+    d.mkdir()
+    (d / "tokenizer.json").write_bytes(doc)
+    t = api.Tokenizer(str(d / "tokenizer.json"))
+    assert t.decode([256, 257, 258]) == " theing<|endoftext|>" and t.specialTokens.end_token == 258
+    for trial in range(200):
+        b = bytearray(doc[:rng.randrange(0, len(doc) + 1)] if trial % 2 == 0 else doc)
+        for _ in range(rng.randrange(1, 4)):
+            if b:
+                b[rng.randrange(len(b))] = rng.choice(b'{}[]",:\\u0 ')
+        (d / "tokenizer.json").write_bytes(bytes(b))
+        try:
+            t2 = api.Tokenizer(str(d / "tokenizer.json"))
+            t2.decode(list(range(0, 259)))
+        except api.WhisperError as e:
+            assert e.code == 1

@@ -690,7 +690,7 @@ extern "C" int wh_load_audio(const char* path, int channel_mode, const int32_t* 
     }
     float* buf = (float*)malloc(sizeof(float) * std::max<size_t>(mono.size(), 1));
     if (!buf) return set_error(WH_ERR_LOAD_AUDIO_FAILED, "Unable to create audio buffer");
-    memcpy(buf, mono.data(), sizeof(float) * mono.size());
+    if (!mono.empty()) memcpy(buf, mono.data(), sizeof(float) * mono.size());
     *pcm_out = buf;
     *n_out = (int)mono.size();
     return WH_OK;
