@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs the host-only C++ (tokenizer.cpp, words.cpp, results.cpp: ASan + UBSan) and the host side of host.hip / capi.hip (ASan)
+# Runs the host-only C++ (tokenizer.cpp, words.cpp, results.cpp: ASan + UBSan) and the host side of host.hip / capi.hip (ASan + UBSan)
 # through the CPU tests.
 # The three files are rebuilt instrumented and linked with the regular HIP objects into a scratch copy of the library, which
 # replaces whisperkit_amd/libwhisperhip.so for the duration of the run.  Needs no GPU.
@@ -12,7 +12,7 @@ for f in tokenizer words results; do
 done
 for f in host capi; do   # host side of the HIP files that carry host logic (device code is left alone)
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$CS -Wno-unused-result -Wno-unused-value \
-    -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -c $CS/$f.hip -o $OUT/$f.o
+    -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -c $CS/$f.hip -o $OUT/$f.o
 done
 (cd $CS && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 mel.o gemm.o layernorm.o attention.o decoder.o $OUT/capi.o $OUT/host.o \
   $OUT/tokenizer.o $OUT/words.o $OUT/results.o -o $OUT/libwhisperhip.so -lz -fsanitize=address,undefined -shared-libsan)
