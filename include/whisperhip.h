@@ -387,6 +387,9 @@ void wh_audio_free(float* pcm);
 
 /* ---- host utilities restated from the reference -------------------------------------------------- */
 float wh_compression_ratio(const int32_t* tokens, int n);          /* TextUtilities.compressionRatio, Utilities/TextUtilities.swift:14-30 */
+float wh_compression_ratio_text(const char* utf8, int nbytes);      /* TextUtilities.compressionRatio(of: String), :33-52 */
+/* String.trimmingSpecialTokenCharacters (Constants.specialTokenCharacters, Core/Models.swift:1330): "<|en|>" -> "en" */
+int wh_trimming_special_token_characters(const char* text, char* out, int capacity);
 /* SegmentSeeker.dynamicTimeWarping (Core/Text/SegmentSeeker.swift:195-278); returns path length */
 int wh_dynamic_time_warping(const float* matrix, int rows, int cols, int32_t* text_indices, int32_t* time_indices, int capacity);
 /* DecodingFallback.init? (Core/Models.swift:357-381) -> WH_FALLBACK_*; *needs_fallback set */

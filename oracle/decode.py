@@ -1059,6 +1059,16 @@ def add_word_timestamps(segments: List[TranscriptionSegment], alignmentWeights: 
                                              specialTokenBegin, decode_fn)
 
 
+def compression_ratio_text(text: str) -> float:
+    """TextUtilities.compressionRatio(of: String), Utilities/TextUtilities.swift:33-52 (raw DEFLATE level 5 like the token version)."""
+    if text == "":
+        return float("inf")
+    data = text.encode("utf-8")
+    c = zlib.compressobj(5, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    return float(np.float32(len(data)) / np.float32(len(comp)))
+
+
 # ----------------------------------------------------------------------------- result assembly and formats
 def format_time(seconds: float, alwaysIncludeHours: bool, decimalMarker: str) -> str:
     """ResultWriting.formatTime, Utilities/ResultWriter.swift:14-26 (Float arithmetic)."""

@@ -329,3 +329,19 @@ def test_malformed_files_are_rejected_not_crashed(tmp_path):
             t2.decode(list(range(0, 259)))
         except api.WhisperError as e:
             assert e.code == 1
+
+
+def test_kat_compression_ratio_string_and_trimming():
+    """UnitTests.swift:707-717 testCompressionRatioString (ordering), :1959-1966 testTrimmingSpecialTokenCharacters (verbatim)."""
+    for f in (api.compressionRatioOfText, od.compression_ratio_text):
+        unique = f("This is a unique string")
+        repeated = f("Repeated text string" * 5)
+        longer = f("Longer repeated text string" * 10)
+        assert unique < repeated < longer
+        assert f("") == float("inf")
+    for text in ("This is a unique string", "Repeated text string" * 5, "日本語のテキスト" * 7, "x"):
+        assert api.compressionRatioOfText(text) == od.compression_ratio_text(text)
+    cases = {"<|en|>": "en", "<|endoftext|>": "endoftext", "en": "en", "<|end<|of|>text|>": "end<|of|>text", "<|endoftext": "endoftext",
+             "endoftext|>": "endoftext"}
+    for src, want in cases.items():
+        assert api.trimmingSpecialTokenCharacters(src) == want and otok.trimming_special_token_characters(src) == want

@@ -171,6 +171,8 @@ SYMBOLS = {
     "wh_load_audio": (I, [C.c_char_p, I, PI32, I, C.c_double, C.c_double, I, C.POINTER(PF), C.POINTER(I)]),
     "wh_audio_free": (None, [PF]),
     "wh_compression_ratio": (F, [PI32, I]),
+    "wh_compression_ratio_text": (F, [C.c_char_p, I]),
+    "wh_trimming_special_token_characters": (I, [C.c_char_p, C.c_char_p, I]),
     "wh_dynamic_time_warping": (I, [PF, I, I, PI32, PI32, I]),
     "wh_decoding_fallback": (I, [POPT, I, F, F, F, PI32]),
     "wh_find_seek_point_and_segments": (I, [C.POINTER(WhDecodingResult), POPT, PST, I, I, I, PI32, C.POINTER(WhSegment), I]),

@@ -533,6 +533,16 @@ def compressionRatio(tokens: Sequence[int]) -> float:
     return float(L.load().wh_compression_ratio(a.ctypes.data_as(L.PI32), len(a)))
 
 
+def compressionRatioOfText(text: str) -> float:
+    """TextUtilities.compressionRatio(of: String)."""
+    b = text.encode("utf-8")
+    return float(L.load().wh_compression_ratio_text(b, len(b)))
+
+
+def trimmingSpecialTokenCharacters(text: str) -> str:
+    return _string(L.load().wh_trimming_special_token_characters, text.encode("utf-8"))
+
+
 def dynamicTimeWarping(matrix: np.ndarray):
     m = np.ascontiguousarray(matrix, dtype=np.float32)
     cap = m.shape[0] + m.shape[1] + 8

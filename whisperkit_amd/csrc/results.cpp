@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <zlib.h>
+
 #include "json.h"
 #include "text.h"
 
@@ -298,6 +300,29 @@ extern "C" int wh_merge_transcriptions(const wh_transcription* const* results, i
     t.first_token_time = earliest_token;
     *out = m;
     return WH_OK;
+}
+
+// ---- small text utilities -----------------------------------------------------------------------------------------------
+// TextUtilities.compressionRatio(of: String) (Utilities/TextUtilities.swift:33-52): UTF-8 bytes / NSData.compressed(using: .zlib)
+// (raw DEFLATE, level 5 - the same stream wh_compression_ratio produces for token arrays); empty text -> +inf
+extern "C" float wh_compression_ratio_text(const char* utf8, int nbytes) {
+    if (!utf8 || nbytes <= 0) return INFINITY;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 5, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return INFINITY;
+    std::vector<unsigned char> outb(deflateBound(&zs, (uLong)nbytes) + 16);
+    zs.next_in = (Bytef*)utf8; zs.avail_in = (uInt)nbytes; zs.next_out = outb.data(); zs.avail_out = (uInt)outb.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const uLong clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen == 0) return INFINITY;
+    return (float)nbytes / (float)clen;
+}
+
+// String.trimmingSpecialTokenCharacters (Constants.specialTokenCharacters "<|>", Core/Models.swift:1330): "<|en|>" -> "en"
+extern "C" int wh_trimming_special_token_characters(const char* text, char* out, int capacity) {
+    if (!text) { set_error(WH_ERR_INVALID_ARGUMENT, "null text"); return -1; }
+    return copy_out(whi::trimming_special_token_characters(text), out, capacity);
 }
 
 // ---- writers ---------------------------------------------------------------------------------------------------------------
