@@ -328,6 +328,17 @@ class Model:
         self.specialTokens = st
 
     @classmethod
+    def from_pretrained(cls, src: str, device: int = 0):
+        """Loads an openai/whisper `.pt` or a Hugging Face Whisper folder (whisperkit_amd.checkpoint) - the analogue of
+        WhisperKit.loadModels on the CoreML bundles (Core/WhisperKit.swift:358-442)."""
+        from .checkpoint import load_checkpoint
+        dims, sd, heads = load_checkpoint(src)
+        m = cls(dims, sd, device=device)
+        if heads:
+            m.setAlignmentHeads(heads)
+        return m
+
+    @classmethod
     def synthetic(cls, name: str, seed: int = 0, device: int = 0, **kw):
         dims = MODEL_DIMS[name]
         return cls(dims, synthetic_state_dict(dims, seed=seed, **kw), device=device)
