@@ -90,7 +90,8 @@ typedef struct wh_decoding_options {
     int32_t skip_special_tokens;
     int32_t without_timestamps;
     int32_t word_timestamps;
-    float max_initial_timestamp;  /* NAN = nil */
+    float max_initial_timestamp;  /* NAN = nil; carried for API parity only: the rule that would use it is commented out in the
+                                     reference (Core/Text/LogitsFilter.swift:112-122), so it has no effect there or here */
     int32_t max_window_seek;      /* -1 = nil */
     const float* clip_timestamps;
     int32_t n_clip_timestamps;
