@@ -170,6 +170,7 @@ def test_native_decode_and_special_tokens_equal_oracle(ntoks, otoks, n_vocab):
     assert n.vocabSize == n_vocab
     assert n.convertTokenToId("<|startoftranscript|>") == st.startOfTranscriptToken and n.convertTokenToId("nope-not-a-token") is None
     assert n.convertIdToToken(st.endToken) == "<|endoftext|>" and n.convertIdToToken(n_vocab + 5) is None
+    assert n.languageToken("en") == st.englishToken and n.languageToken("xx") is None
     rng = random.Random(7 + n_vocab)
     for trial in range(400):
         ids = _random_ids(rng, n_vocab, rng.randrange(0, 48)) + ([n_vocab + 3] if trial % 50 == 0 else [])   # unknown id is dropped

@@ -292,6 +292,10 @@ class Tokenizer:
             return None
         return _string(self.lib.wh_tokenizer_id_to_token, self.handle, i)
 
+    def languageToken(self, code: str) -> Optional[int]:
+        """Token id of a language code ("en" -> id of "<|en|>") for DecodingOptions.language, or None when the vocabulary has none."""
+        return self.convertTokenToId(f"<|{code}|>")
+
     def splitToWordTokens(self, tokenIds: Sequence[int], language: str = "en") -> Tuple[List[str], List[List[int]]]:
         a = np.ascontiguousarray(list(tokenIds), dtype=np.int32)
         nb = C.c_int()
