@@ -400,6 +400,9 @@ int wh_decoding_fallback(const wh_decoding_options* opt, int is_first_token_logp
 int wh_find_seek_point_and_segments(const wh_decoding_result* res, const wh_decoding_options* opt,
                                     const wh_special_tokens* st, int all_segments_count, int current_seek,
                                     int segment_size, int32_t* new_seek, wh_segment* segments_out, int capacity);
+/* DecodingOptions.prepareSeekClips(contentFrames:) (Utilities/Extensions+Internal.swift:112-130): clipTimestamps (seconds) ->
+ * [start, end) sample pairs; returns the number of clips (negative: -needed when capacity is too small) */
+int wh_prepare_seek_clips(const wh_decoding_options* opt, int content_frames, int32_t* clip_start, int32_t* clip_end, int capacity);
 /* EnergyVAD.voiceActivity (Core/Audio/EnergyVAD.swift:41-57); returns number of frames written */
 int wh_vad_voice_activity(const float* pcm, int n, int frame_length_samples, int frame_overlap_samples,
                           float energy_threshold, uint8_t* out, int capacity);

@@ -168,3 +168,23 @@ def test_bench_knows_every_kernel_kind():
         for n in names:
             bound, amount = bench.algorithmic_work(n, weights.MODEL_DIMS[model], 8, 8.5)
             assert bound in ("hbm", "mfma") and amount > 0
+
+
+def test_prepare_seek_clips_matches_oracle_and_kat(jfk_pcm):
+    """DecodingOptions.prepareSeekClips (Extensions+Internal.swift:112-130) through the C ABI: the literal cases, random clip lists
+    against the oracle, and the reference KAT that feeds it VAD clip timestamps of jfk.wav (UnitTests.swift:2178-2189)."""
+    import random
+    from oracle import decode as OD
+    assert api.prepareSeekClips(api.DecodingOptions(), 1000) == [(0, 1000)]
+    assert api.prepareSeekClips(api.DecodingOptions(clipTimestamps=[1.0]), 48000) == [(16000, 48000)]
+    assert api.prepareSeekClips(api.DecodingOptions(clipTimestamps=[0.5, 1.0, 2.0]), 48000) == [(8000, 16000), (32000, 48000)]
+    rng = random.Random(1)
+    for _ in range(200):
+        ts = sorted(round(rng.random() * 60, rng.choice([1, 2, 3])) for _ in range(rng.randrange(0, 7)))
+        n = rng.randrange(1, 960000)
+        assert api.prepareSeekClips(api.DecodingOptions(clipTimestamps=ts), n) == OD.DecodingOptions(clipTimestamps=ts).prepareSeekClips(n), ts
+    vad = OD.EnergyVAD(frameLength=0.2, frameOverlap=0.1)
+    ts = vad.voiceActivityClipTimestamps(jfk_pcm)
+    clips = api.prepareSeekClips(api.DecodingOptions(clipTimestamps=ts), len(jfk_pcm))
+    assert clips == OD.DecodingOptions(clipTimestamps=ts).prepareSeekClips(len(jfk_pcm))
+    assert [c[0] for c in clips] == [3200, 51200, 83200, 128000, 169600] and [c[1] for c in clips] == [35200, 70400, 121600, 166400, 176000]

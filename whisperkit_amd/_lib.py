@@ -176,6 +176,7 @@ SYMBOLS = {
     "wh_dynamic_time_warping": (I, [PF, I, I, PI32, PI32, I]),
     "wh_decoding_fallback": (I, [POPT, I, F, F, F, PI32]),
     "wh_find_seek_point_and_segments": (I, [C.POINTER(WhDecodingResult), POPT, PST, I, I, I, PI32, C.POINTER(WhSegment), I]),
+    "wh_prepare_seek_clips": (I, [POPT, I, PI32, PI32, I]),
     "wh_vad_voice_activity": (I, [PF, I, I, I, F, PU8, I]),
     "wh_vad_chunk_all": (I, [PF, I, I, POPT, PI32, PI32, I]),
     "wh_kernel_kind_count": (I, []),

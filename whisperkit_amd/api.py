@@ -575,6 +575,15 @@ def decodingFallback(options: DecodingOptions, isFirstTokenLogProbTooLow: bool, 
     return FALLBACK_REASONS[r], bool(need.value)
 
 
+def prepareSeekClips(options: DecodingOptions, contentFrames: int) -> List[Tuple[int, int]]:
+    """DecodingOptions.prepareSeekClips (Utilities/Extensions+Internal.swift:112-130)."""
+    o = options.to_c()
+    cap = max(2, len(options.clipTimestamps) // 2 + 2)
+    cs, ce = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    n = L.load().wh_prepare_seek_clips(C.byref(o), contentFrames, cs, ce, cap)
+    return [(cs[i], ce[i]) for i in range(n)]
+
+
 def voiceActivity(audio, frameLengthSamples: int = 1600, frameOverlapSamples: int = 0, energyThreshold: float = 0.02) -> List[bool]:
     a = np.ascontiguousarray(audio, dtype=np.float32)
     lib = L.load()

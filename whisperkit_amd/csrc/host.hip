@@ -132,6 +132,15 @@ static std::vector<std::pair<int, int>> prepare_seek_clips(const wh_decoding_opt
     return clips;
 }
 
+extern "C" int wh_prepare_seek_clips(const wh_decoding_options* opt, int content_frames, int32_t* clip_start, int32_t* clip_end, int capacity) {
+    auto clips = prepare_seek_clips(opt, content_frames);
+    if (clip_start && clip_end) {
+        if ((int)clips.size() > capacity) return -(int)clips.size();
+        for (size_t i = 0; i < clips.size(); ++i) { clip_start[i] = clips[i].first; clip_end[i] = clips[i].second; }
+    }
+    return (int)clips.size();
+}
+
 static bool longest_silence(const std::vector<uint8_t>& v, int* s0, int* e0) {   // VoiceActivityDetector.findLongestSilence
     int best = 0;
     bool found = false;
