@@ -16,12 +16,21 @@ What it restates (reference paths are relative to /root/reference):
 * `oracle.decode`  - line-by-line restatement of the reference's own Swift host logic:
                      TextDecoder.decodeText / detectLanguage, LogitsFilter.swift,
                      TokenSampler.swift, Models.swift DecodingFallback, TranscribeTask.swift,
-                     SegmentSeeker.swift, EnergyVAD / VADAudioChunker, TextUtilities.swift.
+                     SegmentSeeker.swift (incl. addWordTimestamps), EnergyVAD / VADAudioChunker,
+                     TextUtilities.swift, TranscriptionUtilities.mergeTranscriptionResults,
+                     ResultWriter.swift (formatTime, SRT, VTT), AudioProcessor.convertToMono / WAV read.
+* `oracle.tokenizer` - the vendored swift-transformers ByteLevel decode path
+                     (Sources/ArgmaxCore/External/Tokenizers/Tokenizer.swift:433-525, Decoder.swift:126-165)
+                     and WhisperTokenizerWrapper (Core/Models.swift:1165-1307).
 
 PARITY PINNING STATUS
 ---------------------
 * decode/filter/sampler/DTW/VAD/fallback logic: pinned against the reference's own
   known-answer tests (Tests/WhisperKitTests/UnitTests.swift; ported in tests/test_oracle_kats.py).
+* tokenizer text: the reference's four tokenizer KATs (UnitTests.swift:1288-1375) on a fixture vocabulary that carries
+  the real id -> text pairs those tests disclose (whisperkit_amd.synth.kat_tokenizer_vocab) + the HF `tokenizers`
+  library as a second implementation; no real Whisper tokenizer.json exists in the image, so the rest of the real
+  vocabulary is "parity unpinned".
 * mel / encoder / decoder numerics: the reference pins shapes only
   (UnitTests.swift:676-693,721-732); no value of a mel bin, activation or logit is pinned
   anywhere in /root/reference, the CoreML graphs and weights are not in the repo and cannot
