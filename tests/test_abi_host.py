@@ -188,3 +188,37 @@ def test_prepare_seek_clips_matches_oracle_and_kat(jfk_pcm):
     clips = api.prepareSeekClips(api.DecodingOptions(clipTimestamps=ts), len(jfk_pcm))
     assert clips == OD.DecodingOptions(clipTimestamps=ts).prepareSeekClips(len(jfk_pcm))
     assert [c[0] for c in clips] == [3200, 51200, 83200, 128000, 169600] and [c[1] for c in clips] == [35200, 70400, 121600, 166400, 176000]
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    """include/whisperhip.h must compile as C (the boundary is a C ABI) and every struct the ctypes mirror declares must have the
+    size and field offsets the C compiler gives it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    structs = {"wh_dims": L.WhDims, "wh_special_tokens": L.WhSpecialTokens, "wh_decoding_options": L.WhDecodingOptions,
+               "wh_decoding_result": L.WhDecodingResult, "wh_segment": L.WhSegment, "wh_word_timing": L.WhWordTiming,
+               "wh_timings": L.WhTimings, "wh_progress": L.WhProgress}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "whisperhip.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {}
+    for ln in out:
+        if ln.strip():
+            c, f, v = ln.split()
+            got[(c, f)] = int(v)
+    for cname, ct in structs.items():
+        assert got[(cname, "size")] == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
