@@ -222,3 +222,30 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
         assert got[(cname, "size")] == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
+
+
+def test_plain_c_host_links_and_runs_host_entry_points(tmp_path):
+    """examples/transcribe.c - a C99 program over nothing but include/whisperhip.h - compiles, links against libwhisperhip.so and its
+    --selftest mode (tokenizer, WAV ingest, VAD chunking, time formatting) runs without a GPU."""
+    import shutil
+    import subprocess
+    import wave
+    from whisperkit_amd import synth
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "transcribe"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "transcribe.c"),
+                    "-L", os.path.join(root, "whisperkit_amd"), "-lwhisperhip", "-lm", "-Wl,-rpath," + os.path.join(root, "whisperkit_amd"),
+                    "-o", str(exe)], check=True)
+    tok = synth.write_kat_tokenizer(str(tmp_path), 51865)
+    pcm = (np.sin(np.arange(16000 * 40) * 0.02) * 8000).astype("<i2")
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    r = subprocess.run([str(exe), "--selftest", tok, str(tmp_path / "a.wav")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "decode -> <|startoftranscript|><|1.00|><|endoftext|>" in r.stdout
+    assert "audio 640000 samples = 00:00:40,000, 2 chunk(s)" in r.stdout
+    bad = subprocess.run([str(exe), "--selftest", str(tmp_path / "nope.json"), str(tmp_path / "a.wav")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot read" in bad.stderr
