@@ -249,3 +249,35 @@ def test_plain_c_host_links_and_runs_host_entry_points(tmp_path):
     assert "audio 640000 samples = 00:00:40,000, 2 chunk(s)" in r.stdout
     bad = subprocess.run([str(exe), "--selftest", str(tmp_path / "nope.json"), str(tmp_path / "a.wav")], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot read" in bad.stderr
+
+
+def test_bench_work_formulas_reproduce_the_survey_figures():
+    """SURVEY.md section 8(d) states the algorithmic work per 30 s chunk that `roofline.achieved` must be computed from; the
+    per-launch formulas of bench.py have to add up to those figures (large-v3: encoder 2.274 TFLOP, cross-K/V 314.6 GFLOP, cross-
+    attention K/V stream 245.8 MB per token, decoder weights 1.81 GB; tiny.en: encoder 36.9 GFLOP)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    w = lambda kind, dims, B=1, avg=1.0: bench.algorithmic_work(kind, dims, B, avg)[1]
+    for model, enc_flop, ckv_flop in (("large-v3", 2.274e12, 314.6e9), ("tiny.en", 36.9e9, 3.5e9), ("small", 344e9, 42.5e9)):
+        dims = weights.MODEL_DIMS[model]
+        L_ = dims.n_audio_layer
+        enc = w("gemm_conv1", dims) + w("gemm_conv2", dims) + L_ * (w("gemm_enc_qkv", dims) + w("enc_attention", dims) + w("gemm_enc_o", dims) +
+                                                                    w("gemm_enc_fc1", dims) + w("gemm_enc_fc2", dims))
+        assert enc == pytest.approx(enc_flop, rel=0.01), (model, enc)
+        assert w("gemm_cross_kv", dims) == pytest.approx(ckv_flop, rel=0.02), model
+    dims = weights.MODEL_DIMS["large-v3"]
+    d, L_, V = dims.n_text_state, dims.n_text_layer, dims.n_vocab
+    assert L_ * (w("dec_cross_attn", dims) - 2 * d * 4) == pytest.approx(245.8e6, rel=0.001)          # K and V of 1500 positions, fp16
+    # decoder weights read per step, shared by the batch: SURVEY counts 1.81 GB; the folded cross-query matrices replace W_cq by 4 d^2
+    per_layer_w = (3 * d * d + d * d + 4 * d * d + d * d + 4 * d * d + 4 * d * d) * 2
+    got = L_ * sum(w(k, dims, 1, 0.0) for k in ("dec_gemv_qkv", "dec_gemv_oproj", "dec_gemv_coproj", "dec_gemv_fc1", "dec_gemv_fc2")) + \
+        w("dec_gemv_logits", dims, 1, 0.0)
+    assert got == pytest.approx(L_ * per_layer_w + V * d * 2, rel=0.01)
+    all_decoder = L_ * (4 + 4 + 8) * d * d * 2 + V * d * 2               # SURVEY's 1.81 GB: every decoder matrix incl. the cross K/V projections
+    assert all_decoder == pytest.approx(1.81e9, rel=0.02)
+    per_step_classic = all_decoder - L_ * 2 * d * d * 2                     # ... which run once per window (gemm_cross_kv), not per token
+    assert got - per_step_classic == pytest.approx(L_ * 3 * d * d * 2, rel=0.01)   # the fold trades W_cq (d^2) for 4 d^2 per layer
+    assert w("mel_power", weights.MODEL_DIMS["large-v3"]) + 0 >= 480000 * 4                              # PCM read is in the bill
