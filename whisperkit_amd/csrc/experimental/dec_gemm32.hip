@@ -1,0 +1,132 @@
+// DRAFT - NOT BUILT INTO libwhisperhip.so, NEVER RUN ON HARDWARE.  Round-2 starting point.
+// `make -C whisperkit_amd/csrc experimental` only compiles it for gfx950 so that register use / LDS / ISA can be inspected.
+//
+// Decoder projections as an MFMA skinny GEMM for 16 < B <= 32 sequences per step:
+//     Y[b][n] = sum_k act(b, k) * W[n][k]          b < 32, W f16 [N][K] row-major (K contiguous)
+// Why: at B = 32 the lane-per-K GEMVs of decoder.hip take 18-29 us per launch (0.44 TB/s on 56 MB per layer,
+// profiles/r01g_bench_largev3_b32_kernels.json): their FMA loops grow with the batch.  With the batch as the 32-wide side of a
+// v_mfma_f32_32x32x16_f16 tile the arithmetic is 20 MFMAs per wave and the kernel is a weight stream.
+//
+// Work split: one workgroup (256 threads = 4 waves) owns 32 consecutive output rows n and all 32 batch columns; its 4 waves
+// split K, each keeping one f32x16 accumulator, reduced through LDS at the end (deterministic order: wave 0..3).
+// Fragments need no LDS staging and no transposition (same layout fact gemm.hip relies on):
+//   a = W fragment   : lane l -> row n0 + (l & 31), 8 consecutive k at kb + 8 * (l >> 5): ONE 16-byte global load
+//   b = act fragment : lane l -> batch row (l & 31), same 8 k: 2 x float4 of x (L2 hits), LayerNorm applied on the fly - the row
+//                      statistics are per-LANE scalars because a lane always works on the same batch row
+//   acc              : lane l holds batch row b = l & 31 and W rows n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r = 0..15
+// All W loads of a wave's K range are issued before the first MFMA (<= 20 x 16 B in flight per lane for K = 1280).
+//
+// Modes drafted here: FC1 (LN + W1, GELU, f16 out) and RESID (x += W * in + bias for f32 `att` or f16 `hbuf` input).
+// QKV (cache scatter), the folded cross query and LOGITS (sampler statistics) follow the epilogues of decoder.hip.
+#include "../kernels.h"
+
+namespace wh {
+
+enum { G32_FC1 = 0, G32_RESID_F32 = 1, G32_RESID_F16 = 2 };
+
+struct Gemm32Args {
+    int batch, N, K;              // batch <= 32, N % 32 == 0, K % 64 == 0
+    const f16* W;                 // [N][K]
+    const float* bias;            // [N]
+    const float *ln_g, *ln_b;     // FC1: LayerNorm over K (= d) of x
+    float* x;                     // residual stream [B][d]: FC1 input, RESID in/out
+    const float* ain;             // RESID_F32 input [B][K]
+    f16* hbuf;                    // FC1 output [B][N] / RESID_F16 input [B][K]
+    const SeqState* seq;          // liveness of the slots
+};
+
+// STEPS = K-steps of 16 whose weight loads are in flight at once; K / 4 must be a multiple of 16 * STEPS
+// (d = 1280: 20, d = 1024: 16, d = 768: 12, d = 384: 6; K = 4d runs four such chunks per wave).
+// f32 inputs (x with LayerNorm, att without) are staged ONCE per workgroup as f16 in LDS ([32][K + 8] halves, 82 KB at K = 1280:
+// conflict-free ds_read_b128 per quarter wave), so that the MFMA loop waits on nothing but the weight stream; an f16 input
+// (hbuf, K = 4d) is read straight into fragments together with the weights of the chunk.
+template <int MODE, int STEPS>
+__global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    float (*s_red)[32][33] = reinterpret_cast<float (*)[32][33]>(s_dyn);                    // [4][n_local][b] partial tiles
+    f16* s_act = reinterpret_cast<f16*>(s_dyn + sizeof(float) * 4 * 32 * 33);               // [32][K + 8] (f32-input modes)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kq = a.K >> 2;                    // K range of this wave: [wave * kq, (wave + 1) * kq)
+    const int lda = a.K + 8;
+
+    f32x16 acc = {0};
+    const f16* wrow = a.W + (size_t)(n0 + b) * a.K + (size_t)wave * kq + kh * 8;            // lane's W row (b doubles as n_local here)
+
+    if (MODE != G32_RESID_F16) {
+        // ---- stage the activations: 8 threads per batch row; FC1: statistics first (sum / sum of squares in f32), then normalise
+        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
+        const float* src = (MODE == G32_FC1 ? a.x : a.ain) + (size_t)r * a.K;
+        const bool row_ok = r < a.batch;
+        float mean = 0.f, rstd = 1.f;
+        if (MODE == G32_FC1) {
+            float s = 0.f, ss = 0.f;
+            if (row_ok)
+                for (int i = part; i < a.K / 4; i += 8) { float4 v = reinterpret_cast<const float4*>(src)[i]; s += v.x + v.y + v.z + v.w; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+            mean = s / (float)a.K;
+            rstd = rsqrtf(fmaxf(ss / (float)a.K - mean * mean, 0.f) + 1e-5f);
+        }
+        for (int i = part; i < a.K / 4; i += 8) {
+            float4 v = row_ok ? reinterpret_cast<const float4*>(src)[i] : float4{0, 0, 0, 0};
+            if (MODE == G32_FC1) {
+                const float4 g = reinterpret_cast<const float4*>(a.ln_g)[i], be = reinterpret_cast<const float4*>(a.ln_b)[i];
+                v.x = (v.x - mean) * rstd * g.x + be.x; v.y = (v.y - mean) * rstd * g.y + be.y;
+                v.z = (v.z - mean) * rstd * g.z + be.z; v.w = (v.w - mean) * rstd * g.w + be.w;
+                if (!row_ok) v = float4{0, 0, 0, 0};
+            }
+            *reinterpret_cast<f16x4*>(s_act + (size_t)r * lda + 4 * i) = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        }
+    }
+
+    for (int k0 = 0; k0 < kq; k0 += STEPS * 16) {
+        f16x8 wfrag[STEPS], afrag[MODE == G32_RESID_F16 ? STEPS : 1];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) wfrag[s] = *reinterpret_cast<const f16x8*>(wrow + k0 + s * 16);     // the weight stream
+        if (MODE == G32_RESID_F16) {
+            const f16* arow = a.hbuf + (size_t)(b < a.batch ? b : 0) * a.K + (size_t)wave * kq + kh * 8;     // rows past the batch: any valid row, masked at the store
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) afrag[s] = *reinterpret_cast<const f16x8*>(arow + k0 + s * 16);
+        } else if (k0 == 0) {
+            __syncthreads();                                                                                // s_act complete (the W loads are already in flight)
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep every load of the chunk ahead of its first MFMA (the scheduler would sink them to depth 2)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            f16x8 bfrag;
+            if (MODE == G32_RESID_F16) bfrag = afrag[s];
+            else bfrag = *reinterpret_cast<const f16x8*>(s_act + (size_t)b * lda + wave * kq + k0 + s * 16 + kh * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[s], bfrag, acc, 0, 0, 0);
+        }
+    }
+
+    // ---- reduce the 4 K-quarters: lane holds batch row b, W rows (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_red[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][b] = acc[r];
+    __syncthreads();
+    // thread t: batch row bb = t & 31, four consecutive output rows n0 + 4 * (t >> 5) .. + 3
+    const int bb = threadIdx.x & 31, ng = (threadIdx.x >> 5) * 4;
+    if (bb >= a.batch || !(a.seq[bb].active && !a.seq[bb].done)) return;
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = ((s_red[0][ng + j][bb] + s_red[1][ng + j][bb]) + s_red[2][ng + j][bb]) + s_red[3][ng + j][bb] + a.bias[n0 + ng + j];
+    if (MODE == G32_FC1) {
+        *reinterpret_cast<f16x4*>(a.hbuf + (size_t)bb * a.N + n0 + ng) = f16x4{(f16)gelu_erf(y[0]), (f16)gelu_erf(y[1]), (f16)gelu_erf(y[2]), (f16)gelu_erf(y[3])};
+    } else {
+        float4* xp = reinterpret_cast<float4*>(a.x + (size_t)bb * a.N + n0 + ng);
+        float4 xo = *xp;
+        *xp = float4{xo.x + y[0], xo.y + y[1], xo.z + y[2], xo.w + y[3]};
+    }
+}
+
+// dynamic LDS: partial tiles + (f32-input modes) the staged activations; > 64 KB needs hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+inline size_t dec_gemm32_lds_bytes(int mode, int K) { return sizeof(float) * 4 * 32 * 33 + (mode == G32_RESID_F16 ? 0 : (size_t)32 * (K + 8) * 2); }
+
+template __global__ void dec_gemm32_kernel<G32_FC1, 20>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_RESID_F32, 20>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_RESID_F16, 20>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_FC1, 6>(Gemm32Args);
+
+}  // namespace wh
