@@ -1,7 +1,7 @@
 """Long-running differential fuzz of the native host logic against the oracle (not collected by pytest; run by hand):
     python tests/fuzz_host.py [seed]
 mergePunctuations on unicode-heavy word lists, findSeekPointAndSegments on random token streams, tokenizer decode / word
-splitting, addWordTimestamps on noisy alignment matrices, VAD chunking on piecewise audio.  Last run: 0 mismatches in 46 000 cases."""
+splitting, addWordTimestamps on noisy alignment matrices, VAD chunking on piecewise audio.  Last run: 0 mismatches in 46 000 cases + 600 multi-window assemblies."""
 import sys, random, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
@@ -100,3 +100,41 @@ for trial in range(60):
         bad += 1
         if bad < 4: print("VAD MISMATCH", len(audio), ts, want, got)
 print("vad chunk mismatches", bad, time.time() - t0)
+
+# multi-window assembly (TranscribeTask windowing) with and without word timestamps
+rng = random.Random(99); rng_np = np.random.default_rng(99); T = __import__("test_tokenizer_text")
+bad = 0
+for trial in range(600):
+    wt = rng.random() < 0.7; skip = rng.random() < 0.3
+    mws = rng.choice([None, None, 200000, 50000])
+    nst = rng.choice([None, 0.6])
+    oopt = od.DecodingOptions(wordTimestamps=wt, skipSpecialTokens=skip, maxWindowSeek=mws, noSpeechThreshold=nst)
+    aopt = api.DecodingOptions(wordTimestamps=wt, skipSpecialTokens=skip, maxWindowSeek=mws, noSpeechThreshold=nst)
+    asm = api.WindowAssembler(aopt, n)
+    so = sn = rng.choice([0, 0, 123456])
+    segs, toks_all = [], []
+    ok = True
+    for w in range(rng.randrange(1, 6)):
+        toks, lps = T._decoded_window(rng, st, rng.choice(["pairs", "single", "none", "lump"]))
+        nsp = rng.choice([0.0, 0.0, 0.9]); avg = rng.choice([-0.4, -2.0])
+        align = (T._alignment(rng_np, len(toks)) if rng.random() < 0.8 else rng_np.random((len(toks), 1500)).astype(np.float32)) if wt else None
+        ores = od.DecodingResult(language="en", tokens=toks, tokenLogProbs=[{t: l} for t, l in zip(toks, lps)], avgLogProb=avg, noSpeechProb=nsp, temperature=0.0, compressionRatio=1.3, fallback=None, alignment=align)
+        ares = api.DecodingResult(toks, lps, avg, nsp, 0.0, 1.3, st.englishToken, None, False, False, len(toks))
+        size = rng.choice([480000, 300000, 16000])
+        so, cur = od.windowing(ores, oopt, len(segs), so, size, st, o, "en")
+        sn = asm.addWindow(ares, sn, size, align)
+        ok = ok and so == sn
+        if cur is not None:
+            segs += cur
+            for g in cur: toks_all += g.tokens
+    got = asm.result()
+    ok = ok and [g.tokens for g in got.segments] == [g.tokens for g in segs] and [g.text for g in got.segments] == [g.text for g in segs] and [g.id for g in got.segments] == [g.id for g in segs]
+    for g, w_ in zip(got.segments, segs):
+        ww = w_.words or []
+        ok = ok and np.float32(g.start) == np.float32(w_.start) and np.float32(g.end) == np.float32(w_.end)
+        ok = ok and [(x.word, x.tokens, np.float32(x.start), np.float32(x.end)) for x in g.words] == [(x.word, x.tokens, np.float32(x.start), np.float32(x.end)) for x in ww]
+    ok = ok and got.tokens == toks_all
+    if not ok:
+        bad += 1
+        if bad < 4: print("MISMATCH trial", trial)
+print("window assembly mismatches", bad)
