@@ -16,13 +16,14 @@
 //   acc              : lane l holds batch row b = l & 31 and W rows n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r = 0..15
 // All W loads of a wave's K range are issued before the first MFMA (<= 20 x 16 B in flight per lane for K = 1280).
 //
-// Modes drafted here: FC1 (LN + W1, GELU, f16 out) and RESID (x += W * in + bias for f32 `att` or f16 `hbuf` input).
-// QKV (cache scatter), the folded cross query and LOGITS (sampler statistics) follow the epilogues of decoder.hip.
+// Modes drafted here: FC1 (LN + W1, GELU, f16 out), RESID (x += W * in + bias for f32 `att` or f16 `hbuf` input), QKV (LN, layer-0
+// embedding prologue, q out + K/V cache scatter at token_index) and LOGITS (final LN, tied embedding, partial last tile; the sampler
+// statistics stay in sampler_kernel for now).  The folded cross query (K = 4d hi|lo pairs of [x ; att]) is not drafted yet.
 #include "../kernels.h"
 
 namespace wh {
 
-enum { G32_FC1 = 0, G32_RESID_F32 = 1, G32_RESID_F16 = 2 };
+enum { G32_FC1 = 0, G32_RESID_F32 = 1, G32_RESID_F16 = 2, G32_QKV = 3, G32_LOGITS = 4 };
 
 struct Gemm32Args {
     int batch, N, K;              // batch <= 32, N % 32 == 0, K % 64 == 0
@@ -32,7 +33,12 @@ struct Gemm32Args {
     float* x;                     // residual stream [B][d]: FC1 input, RESID in/out
     const float* ain;             // RESID_F32 input [B][K]
     f16* hbuf;                    // FC1 output [B][N] / RESID_F16 input [B][K]
-    const SeqState* seq;          // liveness of the slots
+    const SeqState* seq;          // liveness of the slots, token_index (QKV cache position), next_token (layer-0 embedding)
+    // QKV: q f32 [B][d], this layer's self-attention cache [Bmax][H][224][64] f16; layer 0 builds x = emb[token] + pos[position] first
+    int d, n_head, n_vocab, layer;
+    float* q; f16* self_k; f16* self_v;
+    const f16* emb; const float* pos;
+    float* logits;                // LOGITS: [B][N] f32 (N = n_vocab, last tile partial)
 };
 
 // STEPS = K-steps of 16 whose weight loads are in flight at once; K / 4 must be a multiple of 16 * STEPS
@@ -52,26 +58,40 @@ __global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
     const int lda = a.K + 8;
 
     f32x16 acc = {0};
-    const f16* wrow = a.W + (size_t)(n0 + b) * a.K + (size_t)wave * kq + kh * 8;            // lane's W row (b doubles as n_local here)
+    const f16* wrow = a.W + (size_t)min(n0 + b, a.N - 1) * a.K + (size_t)wave * kq + kh * 8;   // lane's W row (b doubles as n_local; rows past N are clamped, masked at the store)
 
+    constexpr bool kLN = MODE == G32_FC1 || MODE == G32_QKV || MODE == G32_LOGITS;
     if (MODE != G32_RESID_F16) {
         // ---- stage the activations: 8 threads per batch row; FC1: statistics first (sum / sum of squares in f32), then normalise
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
-        const float* src = (MODE == G32_FC1 ? a.x : a.ain) + (size_t)r * a.K;
+        const float* src = (kLN ? a.x : a.ain) + (size_t)r * a.K;
         const bool row_ok = r < a.batch;
+        const bool embed = MODE == G32_QKV && a.layer == 0;     // x = token embedding + learned position (decoder.hip MODE_QKV prologue)
+        int tok = 0, tpos = 0;
+        if (embed && row_ok) { tok = min(max(a.seq[r].next_token, 0), a.n_vocab - 1); tpos = min(max(a.seq[r].token_index, 0), kMaxTok - 1); }
+        auto load_x = [&](int i) -> float4 {
+            if (!row_ok) return float4{0, 0, 0, 0};
+            if (embed) {
+                const f16x4 e = *reinterpret_cast<const f16x4*>(a.emb + (size_t)tok * a.K + 4 * i);
+                const float4 pz = *reinterpret_cast<const float4*>(a.pos + (size_t)tpos * a.K + 4 * i);
+                return float4{(float)e[0] + pz.x, (float)e[1] + pz.y, (float)e[2] + pz.z, (float)e[3] + pz.w};
+            }
+            return reinterpret_cast<const float4*>(src)[i];
+        };
         float mean = 0.f, rstd = 1.f;
-        if (MODE == G32_FC1) {
+        if (kLN) {
             float s = 0.f, ss = 0.f;
             if (row_ok)
-                for (int i = part; i < a.K / 4; i += 8) { float4 v = reinterpret_cast<const float4*>(src)[i]; s += v.x + v.y + v.z + v.w; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+                for (int i = part; i < a.K / 4; i += 8) { float4 v = load_x(i); s += v.x + v.y + v.z + v.w; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
             mean = s / (float)a.K;
             rstd = rsqrtf(fmaxf(ss / (float)a.K - mean * mean, 0.f) + 1e-5f);
         }
         for (int i = part; i < a.K / 4; i += 8) {
-            float4 v = row_ok ? reinterpret_cast<const float4*>(src)[i] : float4{0, 0, 0, 0};
-            if (MODE == G32_FC1) {
+            float4 v = load_x(i);
+            if (embed && row_ok && blockIdx.x == 0) reinterpret_cast<float4*>(a.x + (size_t)r * a.K)[i] = v;      // the residual stream starts here
+            if (kLN) {
                 const float4 g = reinterpret_cast<const float4*>(a.ln_g)[i], be = reinterpret_cast<const float4*>(a.ln_b)[i];
                 v.x = (v.x - mean) * rstd * g.x + be.x; v.y = (v.y - mean) * rstd * g.y + be.y;
                 v.z = (v.z - mean) * rstd * g.z + be.z; v.w = (v.w - mean) * rstd * g.w + be.w;
@@ -111,8 +131,22 @@ __global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
     if (bb >= a.batch || !(a.seq[bb].active && !a.seq[bb].done)) return;
     float y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = ((s_red[0][ng + j][bb] + s_red[1][ng + j][bb]) + s_red[2][ng + j][bb]) + s_red[3][ng + j][bb] + a.bias[n0 + ng + j];
-    if (MODE == G32_FC1) {
+    for (int j = 0; j < 4; ++j)
+        y[j] = ((s_red[0][ng + j][bb] + s_red[1][ng + j][bb]) + s_red[2][ng + j][bb]) + s_red[3][ng + j][bb] + (a.bias && n0 + ng + j < a.N ? a.bias[n0 + ng + j] : 0.f);
+    if (MODE == G32_QKV) {            // decoder.hip MODE_QKV epilogue: q stays f32, k / v go to the cache row of this step
+        const int n = n0 + ng, d = a.d;
+        if (n < d) *reinterpret_cast<float4*>(a.q + (size_t)bb * d + n) = float4{y[0], y[1], y[2], y[3]};
+        else {
+            int c = n - d;
+            f16* dst = a.self_k;
+            if (c >= d) { c -= d; dst = a.self_v; }
+            const int tp = min(max(a.seq[bb].token_index, 0), kMaxTok - 1);
+            *reinterpret_cast<f16x4*>(dst + (((size_t)bb * a.n_head + (c >> 6)) * kMaxTok + tp) * kHeadDim + (c & 63)) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+        }
+    } else if (MODE == G32_LOGITS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n0 + ng + j < a.N) a.logits[(size_t)bb * a.N + n0 + ng + j] = y[j];
+    } else if (MODE == G32_FC1) {
         *reinterpret_cast<f16x4*>(a.hbuf + (size_t)bb * a.N + n0 + ng) = f16x4{(f16)gelu_erf(y[0]), (f16)gelu_erf(y[1]), (f16)gelu_erf(y[2]), (f16)gelu_erf(y[3])};
     } else {
         float4* xp = reinterpret_cast<float4*>(a.x + (size_t)bb * a.N + n0 + ng);
@@ -128,5 +162,7 @@ template __global__ void dec_gemm32_kernel<G32_FC1, 20>(Gemm32Args);
 template __global__ void dec_gemm32_kernel<G32_RESID_F32, 20>(Gemm32Args);
 template __global__ void dec_gemm32_kernel<G32_RESID_F16, 20>(Gemm32Args);
 template __global__ void dec_gemm32_kernel<G32_FC1, 6>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_QKV, 20>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_LOGITS, 20>(Gemm32Args);
 
 }  // namespace wh
