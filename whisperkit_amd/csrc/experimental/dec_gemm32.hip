@@ -19,6 +19,14 @@
 // Modes drafted here: FC1 (LN + W1, GELU, f16 out), RESID (x += W * in + bias for f32 `att` or f16 `hbuf` input), QKV (LN, layer-0
 // embedding prologue, q out + K/V cache scatter at token_index) and LOGITS (final LN, tied embedding, partial last tile; the sampler
 // statistics stay in sampler_kernel for now).  The folded cross query (K = 4d hi|lo pairs of [x ; att]) is not drafted yet.
+//
+// Wiring plan (round 2): launch_decoder_step (decoder.hip) picks this path when batch > 16:
+//   grid = (N + 31) / 32 workgroups of 256 threads, dynamic LDS = dec_gemm32_lds_bytes(mode, K) (99 KB at K = 1280: set
+//   hipFuncAttributeMaxDynamicSharedMemorySize once per instantiation, as mel.hip does), STEPS = d / 64;
+//   QKV: N = 3d, K = d | out-proj / cross-out-proj: RESID_F32, N = K = d | FC1: N = 4d, K = d | FC2: RESID_F16, N = d, K = 4d
+//   (four chunks per wave; double-buffer the chunks if the gaps show in the trace) | LOGITS: N = n_vocab, K = d, bias = null.
+//   First validation: tests/test_gpu_parity.py at batch 32 against the existing GEMV path (batch-invariance tests compare B = 10
+//   with single slots - extend them to 32), then tools/probe_decode.py for the per-kernel times.
 #include "../kernels.h"
 
 namespace wh {
