@@ -14,7 +14,8 @@
 //   b = act fragment : lane l -> batch row (l & 31), same 8 k: 2 x float4 of x (L2 hits), LayerNorm applied on the fly - the row
 //                      statistics are per-LANE scalars because a lane always works on the same batch row
 //   acc              : lane l holds batch row b = l & 31 and W rows n0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r = 0..15
-// All W loads of a wave's K range are issued before the first MFMA (<= 20 x 16 B in flight per lane for K = 1280).
+// All W loads of a wave's K range are issued before anything else (20 x 16 B in flight per lane for K = 1280): the LayerNorm
+// statistics and the activation staging run underneath the weight stream.
 //
 // Modes drafted here: FC1 (LN + W1, GELU, f16 out), RESID (x += W * in + bias for f32 `att` or f16 `hbuf` input), QKV (LN, layer-0
 // embedding prologue, q out + K/V cache scatter at token_index) and LOGITS (final LN, tied embedding, partial last tile; the sampler
@@ -56,28 +57,39 @@ struct Gemm32Args {
     float* logits;                // LOGITS: [B][N] f32 (N = n_vocab, last tile partial)
 };
 
-// STEPS = K-steps of 16 whose weight loads are in flight at once; K / 4 must be a multiple of 16 * STEPS
-// (d = 1280: 20, d = 1024: 16, d = 768: 12, d = 384: 6; K = 4d runs four such chunks per wave).
-// f32 inputs (x with LayerNorm, att without) are staged ONCE per workgroup as f16 in LDS ([32][K + 8] halves, 82 KB at K = 1280:
-// conflict-free ds_read_b128 per quarter wave), so that the MFMA loop waits on nothing but the weight stream; an f16 input
-// (hbuf, K = 4d) is read straight into fragments together with the weights of the chunk.
+// f32 inputs (x with LayerNorm, att without) keep f32-level accuracy as an f16 hi | lo pair (a = hi + lo: two MFMAs per K-step).  They
+// are staged per workgroup in LDS in ROUNDS = 2 K-rounds: round h holds, for each of the 4 waves, columns [w kq + h kq/2, + kq/2) of
+// all 32 rows as hi and lo planes ([32][2 kq + 8] halves each: 2 planes x 32 x 648 x 2 B = 83 KB at K = 1280),
+// read back as conflict-free ds_read_b128.  STEPS = K-steps of 16 per round (d = 1280: 10, 1024: 8, 768: 6, 384: 3); every weight
+// load of the wave's K quarter (ROUNDS x STEPS x 16 B per lane) is issued before the first barrier, so the MFMA loop waits on nothing
+// but the weight stream.  An f16 input (hbuf, K = 4d; already f16 in the GEMV path too) is read straight into fragments together
+// with the weights, in chunks of ROUNDS x STEPS steps.
 template <int MODE, int STEPS>
 __global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
+    constexpr int ROUNDS = 2;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     float (*s_red)[32][33] = reinterpret_cast<float (*)[32][33]>(s_dyn);                    // [4][n_local][b] partial tiles
-    f16* s_act = reinterpret_cast<f16*>(s_dyn + sizeof(float) * 4 * 32 * 33);               // [32][K + 8] (f32-input modes)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.x * 32;
     const int kq = a.K >> 2;                    // K range of this wave: [wave * kq, (wave + 1) * kq)
-    const int lda = a.K + 8;
+    constexpr int RK = STEPS * 16;              // columns per wave and round
+    constexpr int LDA = 4 * RK + 8;             // halves per staged row (4 waves' slices + 16 B pad)
+    f16* s_hi = reinterpret_cast<f16*>(s_dyn + sizeof(float) * 4 * 32 * 33);                // [32][LDA]
+    f16* s_lo = s_hi + 32 * LDA;
 
     f32x16 acc = {0};
     const f16* wrow = a.W + (size_t)min(n0 + b, a.N - 1) * a.K + (size_t)wave * kq + kh * 8;   // lane's W row (b doubles as n_local; rows past N are clamped, masked at the store)
-
     constexpr bool kLN = MODE == G32_FC1 || MODE == G32_QKV || MODE == G32_LOGITS;
+
     if (MODE != G32_RESID_F16) {
-        // ---- stage the activations: 8 threads per batch row; FC1: statistics first (sum / sum of squares in f32), then normalise
+        // the wave's whole K quarter of weights goes in flight now (kq == ROUNDS * RK is a launch precondition)
+        f16x8 wfrag[ROUNDS][STEPS];
+#pragma unroll
+        for (int h = 0; h < ROUNDS; ++h)
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) wfrag[h][s] = *reinterpret_cast<const f16x8*>(wrow + h * RK + s * 16);
+        // ---- activations: 8 threads per batch row; LayerNorm statistics first (sum / sum of squares in f32)
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
         const float* src = (kLN ? a.x : a.ain) + (size_t)r * a.K;
         const bool row_ok = r < a.batch;
@@ -97,43 +109,57 @@ __global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
         if (kLN) {
             float s = 0.f, ss = 0.f;
             if (row_ok)
-                for (int i = part; i < a.K / 4; i += 8) { float4 v = load_x(i); s += v.x + v.y + v.z + v.w; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+                for (int i = part; i < a.K / 4; i += 8) {
+                    float4 v = load_x(i);
+                    s += v.x + v.y + v.z + v.w; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    if (embed && blockIdx.x == 0) reinterpret_cast<float4*>(a.x + (size_t)r * a.K)[i] = v;     // the residual stream starts here
+                }
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
             mean = s / (float)a.K;
             rstd = rsqrtf(fmaxf(ss / (float)a.K - mean * mean, 0.f) + 1e-5f);
         }
-        for (int i = part; i < a.K / 4; i += 8) {
-            float4 v = load_x(i);
-            if (embed && row_ok && blockIdx.x == 0) reinterpret_cast<float4*>(a.x + (size_t)r * a.K)[i] = v;      // the residual stream starts here
-            if (kLN) {
-                const float4 g = reinterpret_cast<const float4*>(a.ln_g)[i], be = reinterpret_cast<const float4*>(a.ln_b)[i];
-                v.x = (v.x - mean) * rstd * g.x + be.x; v.y = (v.y - mean) * rstd * g.y + be.y;
-                v.z = (v.z - mean) * rstd * g.z + be.z; v.w = (v.w - mean) * rstd * g.w + be.w;
-                if (!row_ok) v = float4{0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < ROUNDS; ++h) {
+            if (h) __syncthreads();                                           // everyone is done reading round h - 1
+            // stage round h: float4 index j of the staged row <-> wave slice w = j / (RK / 4), column w kq + h RK + 4 (j % (RK / 4))
+            for (int j = part; j < RK; j += 8) {                              // RK float4 per row (4 waves x RK / 4)
+                const int w = j / (RK / 4), c4 = j - w * (RK / 4);
+                const int col = w * kq + h * RK + 4 * c4;
+                float4 v = load_x(col >> 2);
+                if (kLN) {
+                    const float4 g = *reinterpret_cast<const float4*>(a.ln_g + col), be = *reinterpret_cast<const float4*>(a.ln_b + col);
+                    v.x = (v.x - mean) * rstd * g.x + be.x; v.y = (v.y - mean) * rstd * g.y + be.y;
+                    v.z = (v.z - mean) * rstd * g.z + be.z; v.w = (v.w - mean) * rstd * g.w + be.w;
+                    if (!row_ok) v = float4{0, 0, 0, 0};
+                }
+                const f16x4 hi = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                const f16x4 lo = {(f16)(v.x - (float)hi[0]), (f16)(v.y - (float)hi[1]), (f16)(v.z - (float)hi[2]), (f16)(v.w - (float)hi[3])};
+                *reinterpret_cast<f16x4*>(s_hi + (size_t)r * LDA + 4 * j) = hi;
+                *reinterpret_cast<f16x4*>(s_lo + (size_t)r * LDA + 4 * j) = lo;
             }
-            *reinterpret_cast<f16x4*>(s_act + (size_t)r * lda + 4 * i) = f16x4{(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const size_t off = (size_t)b * LDA + wave * RK + s * 16 + kh * 8;
+                const f16x8 bhi = *reinterpret_cast<const f16x8*>(s_hi + off), blo = *reinterpret_cast<const f16x8*>(s_lo + off);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[h][s], bhi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[h][s], blo, acc, 0, 0, 0);
+            }
         }
-    }
-
-    for (int k0 = 0; k0 < kq; k0 += STEPS * 16) {
-        f16x8 wfrag[STEPS], afrag[MODE == G32_RESID_F16 ? STEPS : 1];
+    } else {
+        constexpr int CH = ROUNDS * STEPS;                                    // K-steps per chunk
+        const f16* arow = a.hbuf + (size_t)(b < a.batch ? b : 0) * a.K + (size_t)wave * kq + kh * 8;   // rows past the batch: any valid row, masked at the store
+        for (int k0 = 0; k0 < kq; k0 += CH * 16) {
+            f16x8 wfrag[CH], afrag[CH];
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) wfrag[s] = *reinterpret_cast<const f16x8*>(wrow + k0 + s * 16);     // the weight stream
-        if (MODE == G32_RESID_F16) {
-            const f16* arow = a.hbuf + (size_t)(b < a.batch ? b : 0) * a.K + (size_t)wave * kq + kh * 8;     // rows past the batch: any valid row, masked at the store
+            for (int s = 0; s < CH; ++s) wfrag[s] = *reinterpret_cast<const f16x8*>(wrow + k0 + s * 16);    // the weight stream
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) afrag[s] = *reinterpret_cast<const f16x8*>(arow + k0 + s * 16);
-        } else if (k0 == 0) {
-            __syncthreads();                                                                                // s_act complete (the W loads are already in flight)
-        }
-        __builtin_amdgcn_sched_barrier(0);      // keep every load of the chunk ahead of its first MFMA (the scheduler would sink them to depth 2)
+            for (int s = 0; s < CH; ++s) afrag[s] = *reinterpret_cast<const f16x8*>(arow + k0 + s * 16);
+            __builtin_amdgcn_sched_barrier(0);      // keep every load of the chunk ahead of its first MFMA (the scheduler would sink them to depth 2)
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            f16x8 bfrag;
-            if (MODE == G32_RESID_F16) bfrag = afrag[s];
-            else bfrag = *reinterpret_cast<const f16x8*>(s_act + (size_t)b * lda + wave * kq + k0 + s * 16 + kh * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[s], bfrag, acc, 0, 0, 0);
+            for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[s], afrag[s], acc, 0, 0, 0);
         }
     }
 
@@ -170,14 +196,15 @@ __global__ __launch_bounds__(256) void dec_gemm32_kernel(Gemm32Args a) {
     }
 }
 
-// dynamic LDS: partial tiles + (f32-input modes) the staged activations; > 64 KB needs hipFuncSetAttribute(MaxDynamicSharedMemorySize)
-inline size_t dec_gemm32_lds_bytes(int mode, int K) { return sizeof(float) * 4 * 32 * 33 + (mode == G32_RESID_F16 ? 0 : (size_t)32 * (K + 8) * 2); }
+// dynamic LDS: partial tiles + (f32-input modes) one round of staged hi | lo activations; > 64 KB needs
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize).  steps = STEPS of the instantiation = K / 128.
+inline size_t dec_gemm32_lds_bytes(int mode, int steps) { return sizeof(float) * 4 * 32 * 33 + (mode == G32_RESID_F16 ? 0 : (size_t)2 * 32 * (4 * steps * 16 + 8) * 2); }
 
-template __global__ void dec_gemm32_kernel<G32_FC1, 20>(Gemm32Args);
-template __global__ void dec_gemm32_kernel<G32_RESID_F32, 20>(Gemm32Args);
-template __global__ void dec_gemm32_kernel<G32_RESID_F16, 20>(Gemm32Args);
-template __global__ void dec_gemm32_kernel<G32_FC1, 6>(Gemm32Args);
-template __global__ void dec_gemm32_kernel<G32_QKV, 20>(Gemm32Args);
-template __global__ void dec_gemm32_kernel<G32_LOGITS, 20>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_FC1, 10>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_RESID_F32, 10>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_RESID_F16, 10>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_QKV, 10>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_LOGITS, 10>(Gemm32Args);
+template __global__ void dec_gemm32_kernel<G32_FC1, 3>(Gemm32Args);
 
 }  // namespace wh
