@@ -930,7 +930,8 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                         encode_window: Callable[[np.ndarray], object],
                         make_step: Callable[[object], StepFn],
                         seed: int = 0, get_alignment: Optional[Callable[[], np.ndarray]] = None,
-                        split_fn: Optional[Callable] = None, tokenizer=None) -> TranscriptionResult:
+                        split_fn: Optional[Callable] = None, tokenizer=None,
+                        records: Optional[list] = None) -> TranscriptionResult:
     """Core/TranscribeTask.swift:57-296 (window loop) + :316-411 (decodeWithFallback).
 
     encode_window(pcm[480000]) -> opaque encoder output (padOrTrim + logMel + encode, :126-151)
@@ -966,8 +967,12 @@ def transcribe_task_run(audio: np.ndarray, options: Optional[DecodingOptions], s
                     if options.usePrefillPrompt:
                         prompt = prefill_prompt(curOptions, st, isModelMultilingual, languageToken=ltok)
                     step = make_step(enc)
+                rec = [] if records is not None else None
                 res = decode_text(step, prompt, sampler, curOptions, st, isModelMultilingual, languageTokens,
-                                  alignment=None)
+                                  alignment=None, record_logits=rec)
+                if records is not None:     # test hook: the filtered logits of every sampling step of this decode
+                    records.append(dict(seek=seek, temperature=sampler.temperature, seed=sampler.seed, prompt=list(prompt),
+                                        record=rec, result=res))
                 if get_alignment is not None:
                     res.alignment = get_alignment()
                 result.temperatures.append(res.temperature)

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
+from neartie import assert_tokens_or_proven_near_tie
 from oracle import decode as OD
 from oracle import mel as omel
 from oracle.model import OracleWhisper
@@ -428,17 +429,38 @@ def _oracle_decode(om, enc, dims, oopts, prompt, temperature=0.0, seed=0, record
                           oopts, st, dims.n_vocab >= 51865, langs, record_logits=record), state
 
 
-def _assert_tokens_match(got_tokens, ores, record, start=0):
-    """Greedy ids must be identical; a divergence is tolerated (and reported as xfail) only at a flagged near-tie."""
-    if got_tokens == ores.tokens:
-        return
-    k = next(i for i, (a, b) in enumerate(zip(got_tokens, ores.tokens)) if a != b)
-    # result token k is currentTokens[start + k], sampled by decode step start + k - 1 from the filtered logits
-    filtered = record[start + k - 1][3]
-    top2 = np.sort(filtered[np.isfinite(filtered)])[-2:]
-    gap = float(top2[1] - top2[0])
-    assert gap < 2e-3, f"token mismatch at result index {k} with top-2 gap {gap} (not a near-tie)"
-    pytest.xfail(f"near-tie at result index {k} (gap {gap:.2e}) flipped the greedy choice")
+def _assert_tokens_match(got_tokens, ores, record, start=0, **kw):
+    """Greedy ids must be identical; a divergence is accepted only when the oracle's own filtered logits prove a near-tie
+    at that step (tests/neartie.py: no skip, no xfail).  Returns how many leading result tokens are comparable."""
+    return assert_tokens_or_proven_near_tie(got_tokens, ores.tokens, record, start=start, **kw)
+
+
+def _window_tokens(segments):
+    """result tokens per decoding window (segments of one window share `seek`), in window order"""
+    out = []
+    for g in segments:
+        if not out or out[-1][0] != g.seek:
+            out.append((g.seek, []))
+        out[-1][1].extend(g.tokens)
+    return out
+
+
+def _assert_windows_match(got_segments, ores, records, st, seek_shift=0):
+    """Window by window: identical tokens, or a proven near-tie in the first differing window (later windows are then not
+    comparable: the seek point depends on the sampled timestamps).  Returns the number of fully equal leading windows
+    (== the oracle's window count when everything matched).  `seek_shift`: chunk offset already added to both sides' seeks."""
+    gw, ow = _window_tokens(got_segments), _window_tokens(ores.segments)
+    for i, ((gs, gt), (os_, ot)) in enumerate(zip(gw, ow)):
+        assert gs == os_, f"window {i}: seek {gs} vs oracle {os_}"
+        if gt != ot:
+            rec = [r for r in records if r["seek"] == os_ - seek_shift][-1]      # the accepted decode of that window
+            assert rec["result"].tokens == ot
+            k = assert_tokens_or_proven_near_tie(gt, ot, rec["record"], start=rec["prompt"].index(st.startOfTranscriptToken),
+                                                 temperature=rec["temperature"], seed=rec["seed"])
+            assert k < len(ot)
+            return i
+    assert len(gw) == len(ow)
+    return len(ow)
 
 
 @pytest.mark.parametrize("which,kw", [
@@ -463,11 +485,12 @@ def test_decode_text_greedy_vs_oracle(which, kw, request):
     res = sess.decodeText(prompt, opts)[0]
     rec = []
     ores, _ = _oracle_decode(om, enc, dims, oopts, prompt, record=rec)
-    _assert_tokens_match(res.tokens, ores, rec, start=prompt.index(st.startOfTranscriptToken))
-    assert res.steps == ores.steps
-    np.testing.assert_allclose(res.tokenLogProbs, [list(d.values())[0] for d in ores.tokenLogProbs], atol=2e-3)
-    assert res.avgLogProb == pytest.approx(ores.avgLogProb, abs=2e-3)
-    assert res.compressionRatio == pytest.approx(ores.compressionRatio, rel=1e-6)
+    n = _assert_tokens_match(res.tokens, ores, rec, start=prompt.index(st.startOfTranscriptToken))
+    np.testing.assert_allclose(res.tokenLogProbs[:n], [list(d.values())[0] for d in ores.tokenLogProbs][:n], atol=2e-3)
+    if n == len(ores.tokens):
+        assert res.steps == ores.steps
+        assert res.avgLogProb == pytest.approx(ores.avgLogProb, abs=2e-3)
+        assert res.compressionRatio == pytest.approx(ores.compressionRatio, rel=1e-6)
     assert res.temperature == ores.temperature == 0.0
     assert res.needsFallback is False and res.fallbackReason is None
 
@@ -515,9 +538,8 @@ def test_decode_text_temperature_sampling_is_seeded_and_matches_oracle(micro):
     assert a.temperature == pytest.approx(0.6, abs=1e-3)
     rec = []
     ores, _ = _oracle_decode(om, enc, dims, oopts, prompt, temperature=0.6, seed=77, record=rec)
-    if a.tokens != ores.tokens:
-        pytest.xfail("T>0: a top-5 boundary near-tie changed the candidate set")
-    np.testing.assert_allclose(a.tokenLogProbs, [list(d.values())[0] for d in ores.tokenLogProbs], atol=5e-3)
+    n = _assert_tokens_match(a.tokens, ores, rec, start=prompt.index(st.startOfTranscriptToken), temperature=0.6, seed=77)
+    np.testing.assert_allclose(a.tokenLogProbs[:n], [list(d.values())[0] for d in ores.tokenLogProbs][:n], atol=5e-3)
 
 
 def test_decode_text_batched_matches_single(micro):
@@ -574,13 +596,16 @@ def test_transcribe_multi_window_vs_oracle(micro):
     def make_step(enc):
         state = om.new_state(enc)
         return lambda t, p: state.step(t, p)
-    ores = OD.transcribe_task_run(audio, OD.DecodingOptions(**okw), st, False, langs, dims.n_vocab, encode_window, make_step, seed=seed)
-    assert res.seeks == ores.seeks
+    records = []
+    ores = OD.transcribe_task_run(audio, OD.DecodingOptions(**okw), st, False, langs, dims.n_vocab, encode_window, make_step, seed=seed,
+                                  records=records)
     assert len(res.seeks) == 3 and res.timings["total_decoding_fallbacks"] == 3     # every window falls back once
-    if [t for g in res.segments for t in g.tokens] != ores.tokens:      # oracle result tokens = concatenated segment tokens
-        pytest.xfail("near-tie / top-5 boundary difference between the fp16-operand GPU encoder and the fp32 oracle")
-    assert [s.id for s in res.segments] == [s.id for s in ores.segments]
-    for a, b in zip(res.segments, ores.segments):
+    nw = _assert_windows_match(res.segments, ores, records, st)     # oracle result tokens = concatenated segment tokens
+    assert res.seeks[:nw + 1] == ores.seeks[:nw + 1]
+    if nw == len(_window_tokens(ores.segments)):
+        assert res.seeks == ores.seeks and [s.id for s in res.segments] == [s.id for s in ores.segments]
+    eq_seeks = set(ores.seeks[:nw])
+    for a, b in zip([g for g in res.segments if g.seek in eq_seeks], [g for g in ores.segments if g.seek in eq_seeks]):
         assert a.tokens == b.tokens and a.seek == b.seek
         assert a.start == pytest.approx(b.start, abs=1e-5) and a.end == pytest.approx(b.end, abs=1e-5)
         assert a.temperature == pytest.approx(b.temperature)
@@ -610,7 +635,9 @@ def test_transcribe_chunked_vad_vs_oracle(micro):
         def make_step(enc):
             state = om.new_state(enc.astype(np.float16).astype(np.float32))     # the cross-K/V GEMM reads fp16 operands
             return lambda t, p: state.step(t, p)
-        return OD.transcribe_task_run(samples, oopts, st, False, langs, dims.n_vocab, encode_window, make_step)
+        chunk_records.append([])
+        return OD.transcribe_task_run(samples, oopts, st, False, langs, dims.n_vocab, encode_window, make_step, records=chunk_records[-1])
+    chunk_records = []
     ref = OD.transcribe_vad_chunked(audio, OD.DecodingOptions(**kw), one)
     assert len(got) == len(ref) >= 3
     assert [o for o, _ in got] == [int(round(t * 16000)) for t, _ in ref] == [o for o, _ in OD.vad_chunk_all(audio)]
@@ -624,10 +651,11 @@ def test_transcribe_chunked_vad_vs_oracle(micro):
         for a, b in zip(r.segments, alone.segments):
             assert a.tokens == b.tokens and a.seek == b.seek + int(seek_time * np.float32(16000))
             assert a.start == float(np.float32(b.start) + seek_time) and a.end == float(np.float32(b.end) + seek_time)
-    for (off, r), (t, o) in zip(got, ref):
-        seg_tokens = [t for g in r.segments for t in g.tokens]
-        if seg_tokens != o.tokens:
-            pytest.xfail(f"token difference vs the fp32 oracle in chunk at {off}: {seg_tokens} vs {o.tokens} (seeks {r.seeks} vs {o.seeks})")
+    for ci, ((off, r), (t, o)) in enumerate(zip(got, ref)):
+        # the oracle transcribes the chunk's own samples (seek 0-based); the batched result is shifted by the chunk offset
+        nw = _assert_windows_match(r.segments, o, chunk_records[ci], st, seek_shift=int(np.float32(off) / np.float32(16000) * np.float32(16000)))
+        if nw < len(_window_tokens(o.segments)):
+            continue            # proven near-tie inside this chunk: the rest of the chunk is not comparable
         assert len(r.segments) == len(o.segments)
         for a, b in zip(r.segments, o.segments):
             assert a.tokens == b.tokens and a.seek == b.seek

@@ -153,6 +153,53 @@ static int bind_weights(wh_model* m) {
     return WH_OK;
 }
 
+// Decoder path selection, read once per process: WH_DEC_PATH=gemv keeps the lane-per-K GEMV kernels of decoder.hip (the A/B
+// side of the parity tests); default = the MFMA batch-tile path of decoder32.hip.
+static bool dec32_enabled() {
+    static const bool on = [] { const char* e = getenv("WH_DEC_PATH"); return !(e && strcmp(e, "gemv") == 0); }();
+    return on;
+}
+
+// Carve 256-byte aligned sub-buffers out of one allocation.
+struct Carver {
+    char* base = nullptr; size_t off = 0;
+    template <typename T> T* take(size_t n) { T* p = reinterpret_cast<T*>(base + off); off = (off + n * sizeof(T) + 255) / 256 * 256; return p; }
+};
+
+static int build_dec32(wh_model* m) {
+    const wh_dims& D = m->dims;
+    const size_t d = D.n_text_state, L = D.n_text_layer, V = D.n_vocab, Vp = (V + 31) / 32 * 32;
+    size_t bytes = L * (14 * d * d * 2 + 16 * d * 4 + 12 * 256) + Vp * d * 2 + 2 * Vp * 4 + 3 * 256;
+    hipError_t e = hipMalloc(&m->dec32_blob, bytes);
+    if (e != hipSuccess) return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the tiled decoder weights failed: %s", bytes, hipGetErrorString(e));
+    WH_HIP(hipMemset(m->dec32_blob, 0, bytes));
+    Carver c; c.base = (char*)m->dec32_blob;
+    m->dec32.resize(L);
+    hipStream_t st = nullptr;
+    for (size_t l = 0; l < L; ++l) {
+        const DecLayerW& w = m->dec[l];
+        Dec32LayerW& t = m->dec32[l];
+        f16* p;
+        p = c.take<f16>(3 * d * d); dec32_tile_weights(w.qkv_w, 3 * d, d, p, st); t.qkv_t = p;
+        p = c.take<f16>(d * d); dec32_tile_weights(w.o_w, d, d, p, st); t.o_t = p;
+        p = c.take<f16>(d * d); dec32_tile_weights(w.cq_w, d, d, p, st); t.cq_t = p;
+        p = c.take<f16>(d * d); dec32_tile_weights(w.co_w, d, d, p, st); t.co_t = p;
+        p = c.take<f16>(4 * d * d); dec32_tile_weights(w.fc1_w, 4 * d, d, p, st); t.fc1_t = p;
+        p = c.take<f16>(4 * d * d); dec32_tile_weights(w.fc2_w, d, 4 * d, p, st); t.fc2_t = p;
+        float *g, *cc;
+        g = c.take<float>(3 * d); cc = c.take<float>(3 * d); dec32_fold_vectors(w.qkv_w, 3 * d, d, w.ln1_g, w.ln1_b, w.qkv_b, g, cc, st); t.qkv_g = g; t.qkv_c = cc;
+        g = c.take<float>(d); cc = c.take<float>(d); dec32_fold_vectors(w.cq_w, d, d, w.ln2_g, w.ln2_b, w.cq_b, g, cc, st); t.cq_g = g; t.cq_c = cc;
+        g = c.take<float>(4 * d); cc = c.take<float>(4 * d); dec32_fold_vectors(w.fc1_w, 4 * d, d, w.ln3_g, w.ln3_b, w.fc1_b, g, cc, st); t.fc1_g = g; t.fc1_c = cc;
+    }
+    f16* et = c.take<f16>(Vp * d); dec32_tile_weights(m->emb, V, d, et, st); m->emb_t = et;
+    float* g = c.take<float>(Vp); float* cc = c.take<float>(Vp);
+    dec32_fold_vectors(m->emb, V, d, m->lnf_g, m->lnf_b, nullptr, g, cc, st); m->lg_g = g; m->lg_c = cc;
+    if (c.off > bytes) return set_error(WH_ERR_HIP, "internal: tiled decoder weights overflow (%zu > %zu)", c.off, bytes);
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipDeviceSynchronize());
+    return WH_OK;
+}
+
 static int set_alignment_heads(wh_model* m, const int32_t* pairs, int n) {
     const int L = m->dims.n_text_layer, H = m->dims.n_text_head;
     std::vector<int> slot(L * H, -1);
@@ -208,6 +255,7 @@ extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_m
     }
     int r = bind_weights(m);
     if (!r) r = build_mel_tables(m);
+    if (!r && dec32_enabled()) r = build_dec32(m);
     if (!r) {
         std::vector<int32_t> pairs;   // default: every head of the upper half of the decoder (openai/whisper model.py)
         for (int l = D.n_text_layer / 2; l < D.n_text_layer; ++l)
@@ -236,6 +284,7 @@ extern "C" int wh_model_load(const char* path, int device, wh_model** out) {
 extern "C" void wh_model_destroy(wh_model* m) {
     if (!m) return;
     if (m->blob_dev) hipFree(m->blob_dev);
+    if (m->dec32_blob) hipFree(m->dec32_blob);
     if (m->mel_tables_dev) hipFree(m->mel_tables_dev);
     if (m->align_slot_dev) hipFree(m->align_slot_dev);
     delete m;
@@ -319,6 +368,24 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
     DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress); DALLOC(s->sup_mask_dev, V); DALLOC(s->stats, B * kStatBlocks * 8);
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
+    if (!m->dec32.empty()) {
+        const size_t n_bt = (B + 31) / 32, R = n_bt * 32;
+        const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 16 * 256;
+        if (hipMalloc(&s->d32_blob, bytes) != hipSuccess || hipMemset(s->d32_blob, 0, bytes) != hipSuccess) {
+            wh_session_destroy(s);
+            return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the decode-step buffers failed", bytes);
+        }
+        Carver c; c.base = (char*)s->d32_blob;
+        Dec32& q = s->d32;
+        q.layers_host = m->dec32.data(); q.emb_t = m->emb_t; q.lg_g = m->lg_g; q.lg_c = m->lg_c; q.n_bt = (int)n_bt;
+        q.x = c.take<float>(R * d); q.q = c.take<float>(R * d);
+        q.za_hi = c.take<f16>(R * d); q.za_lo = c.take<f16>(R * d); q.zb_hi = c.take<f16>(R * d); q.zb_lo = c.take<f16>(R * d);
+        q.h = c.take<f16>(R * 4 * d);
+        q.stat = c.take<float2>(n_bt * (d / 32) * 32);
+        q.part = c.take<float>(n_bt * (size_t)kD32PartFloats); q.part_floats = kD32PartFloats;
+        q.ticket = c.take<int>(n_bt * 4096);
+        s->use32 = true;
+    }
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
     (void)wh::debug_buffer();   // WH_DBG=1 probe buffer must exist before any stream capture
@@ -333,6 +400,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (!s) return;
     if (s->st) hipStreamSynchronize(s->st);
     whi::drop_session_graphs(s);
+    if (s->d32_blob) hipFree(s->d32_blob);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->xa, s->q, s->att, s->part, s->ticket, s->logits, s->hbuf,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
@@ -474,6 +542,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch) {
     { static const bool off = [] { const char* e = getenv("WH_NO_FUSED_CQ"); return e && e[0] == '1'; }(); db.fused_cq = off ? 0 : 1; }
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
+    db.d32 = s->use32 ? &s->d32 : nullptr;
     return db;
 }
 }  // namespace whi

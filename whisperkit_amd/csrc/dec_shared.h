@@ -1,0 +1,33 @@
+// Device helpers shared by the two decoder paths (decoder.hip: GEMV kernels, attention, samplers; decoder32.hip: MFMA projections).
+#pragma once
+#include "kernels.h"
+
+namespace wh {
+
+__device__ __forceinline__ bool slot_live(const SeqState* s) { return s->active && !s->done; }
+
+// running (max, sum exp(x - max), argmax) of a softmax, mergeable in any fixed order; equal maxima keep the smaller index
+struct SoftStat { float m, s; int i; };
+__device__ __forceinline__ void stat_merge(SoftStat& a, float em, float es, int ei) {
+    if (em == -INFINITY) return;
+    if (a.m == -INFINITY || em > a.m) {
+        a.s = (a.m == -INFINITY ? 0.0f : a.s * __expf(a.m - em)) + es;
+        a.m = em; a.i = ei;
+    } else if (em == a.m) {
+        a.s += es; a.i = min(a.i, ei);
+    } else {
+        a.s += es * __expf(em - a.m);
+    }
+}
+
+// element (slot b, channel n) of an activation plane of K channels: Z[b / 32][n / 16][(n / 8) & 1][b & 31][n & 7]
+__device__ __forceinline__ size_t plane_index(int b, int n, int K) {
+    return ((((size_t)(b >> 5) * (K >> 4) + (n >> 4)) * 2 + ((n >> 3) & 1)) * 32 + (b & 31)) * 8 + (n & 7);
+}
+// f32 -> f16 hi + scaled f16 lo (z ~ hi + lo / 2048, 22 mantissa bits; the scale keeps lo out of the f16 subnormals)
+__device__ __forceinline__ void split_hilo(float z, f16& hi, f16& lo) {
+    hi = (f16)z;
+    lo = (f16)((z - (float)hi) * 2048.0f);
+}
+
+}  // namespace wh

@@ -30,7 +30,7 @@
 // All results are bit-deterministic (fixed summation orders, no float atomics).
 #include <cstdlib>
 
-#include "kernels.h"
+#include "dec_shared.h"
 
 namespace wh {
 
@@ -58,8 +58,6 @@ struct GemvArgs {
 };
 
 #define DBG_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = ((i) == 6) ? (unsigned long long)clock64() : ((i) == 7 ? (unsigned long long)clock64() : (unsigned long long)wall_clock64()); } while (0)
-
-__device__ __forceinline__ bool slot_live(const SeqState* s) { return s->active && !s->done; }
 
 // Sum 64 lanes of N values each; afterwards lane L holds the total of value index L >> (6 - log2 N)
 // (N = 4, 8, 16, 32).  Costs N-1 + (6 - log2 N) shuffles instead of 6 N.  Template recursion keeps every
@@ -550,7 +548,8 @@ struct AttnArgs {
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
     const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
-    float* att;              // [B][d] attention output (before the out projection)
+    float* att;              // [B][d] attention output (before the out projection); GEMV path
+    f16 *att_hi, *att_lo;    // MFMA path (decoder32.hip): the same values as an f16 hi | lo pair in B-fragment plane order
     float* part;             // [B][H][n_split][kPartStride]: (m, l, o[64]) of every key split, one 128-byte-aligned slot each
     int* ticket;             // [B][H] arrival counters (zero between launches)
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
@@ -560,6 +559,16 @@ struct AttnArgs {
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
 #define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+
+__device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float v) {
+    if (a.att_hi) {
+        f16 hi, lo;
+        split_hilo(v, hi, lo);
+        const size_t o = plane_index(b, n, a.d);
+        a.att_hi[o] = hi;
+        a.att_lo[o] = lo;
+    } else a.att[(size_t)b * a.d + n] = v;
+}
 
 // One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 halves).  Thread layout: 8 lanes per
 // key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     auto qfix = [](float (&)[8], int) {};
     if (!attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, kMaxTok, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
-    if (threadIdx.x < 64) a.att[(size_t)b * d + h * kHeadDim + threadIdx.x] = o_l[threadIdx.x] / l;
+    if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
 
 template <int PASSES>
@@ -786,7 +795,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
                 lg = fmaf(w, pl[i * 66 + 1], lg);
                 og = fmaf(w, pl[i * 66 + 2 + tid], og);
             }
-            a.att[(size_t)b * d + h * kHeadDim + tid] = og / lg;
+            store_att(a, b, h * kHeadDim + tid, og / lg);
         }
     }
     ATT_STAMP(5);
@@ -1032,18 +1041,6 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
 }
 
 // ---------------------------------------------------------------------------------------------- fused greedy sampler, part 2
-struct SoftStat { float m, s; int i; };
-__device__ __forceinline__ void stat_merge(SoftStat& a, float em, float es, int ei) {
-    if (em == -INFINITY) return;
-    if (a.m == -INFINITY || em > a.m) {
-        a.s = (a.m == -INFINITY ? 0.0f : a.s * __expf(a.m - em)) + es;
-        a.m = em; a.i = ei;
-    } else if (em == a.m) {
-        a.s += es; a.i = min(a.i, ei);
-    } else {
-        a.s += es * __expf(em - a.m);
-    }
-}
 __device__ __forceinline__ void stat_wave_reduce(SoftStat& a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1187,17 +1184,93 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
 }
 
 int cross_attn_splits(int batch, int n_head) {
-    // keys per workgroup 256 / 128 / 64: the coarsest split that still gives >= 512 workgroups
-    static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 8 / 4 / 2
-    if (forced) return (kCtx + forced * 32 - 1) / (forced * 32);
-    for (int passes : {16, 12, 8, 4}) {
-        int s = (kCtx + passes * 32 - 1) / (passes * 32);
-        if (s * n_head * batch >= 512) return s;
+    // Keys per workgroup 384 / 128 / 64, chosen from the head count ONLY: the number of splits fixes the order in which the
+    // partial softmax sums are combined, so it must not depend on the batch - a slot decodes to the same bits alone or in a
+    // batch of 32 (tests/test_gpu_dims.py).  With >= 12 heads even a batch of 8 gives >= 384 workgroups at 4 splits.
+    (void)batch;
+    static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 16 / 12 / 8 / 4 / 2
+    const int passes = forced ? forced : (n_head >= 12 ? 12 : n_head >= 4 ? 4 : 2);
+    return (kCtx + passes * 32 - 1) / (passes * 32);
+}
+
+static void launch_cross_attn(const AttnArgs& at, int S, int H, int B, hipStream_t st) {
+    ProfScope ps_(KK_DEC_CROSS_ATTN, st);
+    const dim3 grid(S, H, B);
+    static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
+    if (S == 3) dec_cross_attn_kernel<16><<<grid, 256, xlds, st>>>(at);
+    else if (S == 4) dec_cross_attn_kernel<12><<<grid, 256, xlds, st>>>(at);
+    else if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, xlds, st>>>(at);
+    else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, xlds, st>>>(at);
+    else dec_cross_attn_kernel<2><<<grid, 256, xlds, st>>>(at);
+}
+
+// The MFMA batch-tile path (decoder32.hip): embed -> per layer [QKV, self-attention, out projection, cross query, cross-attention,
+// cross out projection, fc1, fc2] -> logits -> sampler.  Every activation hand-off is a plane pair in B-fragment order, every
+// LayerNorm is folded into the consumer's epilogue (see decoder32.hip).
+static void launch_decoder_step32(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st) {
+    const Dec32& D = *db.d32;
+    const int d = db.d, B = db.batch, H = db.n_head, L = db.n_layer, V = db.n_vocab;
+    const int n_bt = (B + 31) / 32;
+    const size_t self_stride = (size_t)db.max_batch * H * kMaxTok * kHeadDim;
+    const size_t cross_stride = (size_t)db.max_batch * H * kCtx * kHeadDim;
+    const int S = cross_attn_splits(B, H);
+    launch_dec32_embed(db.emb, db.pos, db.seq, B, d, V, n_bt, D.x, db.layers_host[0].ln1_g, D.za_hi, D.za_lo, D.stat, st);
+    P32Args base{};
+    base.batch = B; base.d = d; base.n_head = H; base.n_vocab = V; base.seq = db.seq; base.part = D.part; base.ticket = D.ticket;
+    base.x = D.x; base.stat_in = D.stat; base.n_stat = d / 32;
+    for (int l = 0; l < L; ++l) {
+        const DecLayerW& w = db.layers_host[l];
+        const Dec32LayerW& t = D.layers_host[l];
+        P32Args a = base;       // LN1 (folded) + QKV: q (f32), k / v into the self-attention cache at token_index
+        a.N = 3 * d; a.K = d; a.Wt = t.qkv_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.qkv_g; a.fold_c = t.qkv_c; a.q = D.q;
+        a.self_k = db.self_k + (size_t)l * self_stride; a.self_v = db.self_v + (size_t)l * self_stride; a.prof_kind = KK_DEC_QKV;
+        launch_dec32_proj(P32_QKV, a, n_bt, st);
+        AttnArgs at{};
+        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q;
+        at.self_k = a.self_k; at.self_v = a.self_v;
+        at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
+        at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
+        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
+        { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
+        a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
+        a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
+        a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
+        launch_dec32_proj(P32_RESID, a, n_bt, st);
+        a = base;               // LN2 (folded) + cross-attention query
+        a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
+        launch_dec32_proj(P32_Q, a, n_bt, st);
+        at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
+        launch_cross_attn(at, S, H, B, st);
+        a = base;               // x += W_co att + b_co; planes gamma_3 x, statistics for LN3
+        a.N = d; a.K = d; a.Wt = t.co_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.co_b; a.gamma_next = w.ln3_g;
+        a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_COPROJ;
+        launch_dec32_proj(P32_RESID, a, n_bt, st);
+        a = base;               // LN3 (folded) + fc1 + GELU -> f16 plane
+        a.N = 4 * d; a.K = d; a.Wt = t.fc1_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.fc1_g; a.fold_c = t.fc1_c; a.h_out = D.h; a.prof_kind = KK_DEC_FC1;
+        launch_dec32_proj(P32_FC1, a, n_bt, st);
+        a = base;               // x += W_2 h + b_2; planes of the next layer's LN1 (or the final LayerNorm)
+        a.N = d; a.K = 4 * d; a.Wt = t.fc2_t; a.zhi = D.h; a.zlo = nullptr; a.bias = w.fc2_b;
+        a.gamma_next = (l + 1 < L) ? db.layers_host[l + 1].ln1_g : db.lnf_g;
+        a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_FC2;
+        launch_dec32_proj(P32_RESID, a, n_bt, st);
     }
-    return (kCtx + 63) / 64;
+    const bool fused = sample && db.fused_greedy;
+    P32Args a = base;           // final LayerNorm (folded) + tied-embedding logits (+ the fused greedy sampler statistics)
+    a.N = V; a.K = d; a.Wt = D.emb_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = D.lg_g; a.fold_c = D.lg_c;
+    a.logits = fused ? nullptr : db.logits; a.prof_kind = KK_DEC_LOGITS;
+    if (fused) { a.stats = db.stats; a.sup_mask = db.sup_mask; a.cfg = cfg_dev; }
+    launch_dec32_proj(P32_LOGITS, a, n_bt, st);
+    if (fused) {
+        ProfScope ps_(KK_SAMPLER, st);
+        sampler_final_kernel<<<B, 256, 0, st>>>(cfg_dev, db.seq, db.stats, (V + 31) / 32);
+    } else if (sample) {
+        ProfScope ps_(KK_SAMPLER, st);
+        sampler_kernel<1, 1, 1, 0><<<B, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, db.seq, db.logits, 0, nullptr, nullptr);
+    }
 }
 
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st) {
+    if (db.d32) { launch_decoder_step32(db, cfg_dev, suppress_dev, sample, st); return; }
     const int d = db.d, B = db.batch, H = db.n_head, L = db.n_layer;
     const size_t self_stride = (size_t)db.max_batch * H * kMaxTok * kHeadDim;
     const size_t cross_stride = (size_t)db.max_batch * H * kCtx * kHeadDim;
@@ -1233,16 +1306,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             { ProfScope ps_(KK_DEC_CQ, st); g_dbg_kind = KK_DEC_CQ; launch_gemv<MODE_Q>(g, st); }
         }
         at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
-        {
-            ProfScope ps_(KK_DEC_CROSS_ATTN, st);
-            const dim3 grid(S, H, B);
-            static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
-            if (S == 3) dec_cross_attn_kernel<16><<<grid, 256, xlds, st>>>(at);
-            else if (S == 4) dec_cross_attn_kernel<12><<<grid, 256, xlds, st>>>(at);
-            else if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, xlds, st>>>(at);
-            else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, xlds, st>>>(at);
-            else dec_cross_attn_kernel<2><<<grid, 256, xlds, st>>>(at);
-        }
+        launch_cross_attn(at, S, H, B, st);
         // x += W_co att + b_co
         g.W = w.co_w; g.bias = w.co_b;
         { ProfScope ps_(KK_DEC_COPROJ, st); g_dbg_kind = KK_DEC_COPROJ; launch_gemv<MODE_RESID>(g, st); }

@@ -1,0 +1,414 @@
+// Decoder projections on the matrix cores for batch tiles of 32 sequences (gfx950): the weight-streaming half of the token step
+// that replaces the per-token CoreML TextDecoder call of Sources/WhisperKit/Core/TextDecoder.swift:381-418.
+//
+// Why: the lane-per-K GEMVs of decoder.hip do B x K x N FMAs on the vector ALUs - at 32 sequences per step they take 18-29 us
+// per launch for 3-13 MB of weights (0.44 TB/s, profiles/r01g_bench_largev3_b32_kernels.json).  With the batch as the 32-wide
+// N side of v_mfma_f32_32x32x16_f16 a 1 KB weight tile costs two MFMAs whatever the batch, and the kernel is a weight stream.
+//
+// Data layout (everything is laid out so that ONE coalesced 1 KB wave load is ONE MFMA fragment, no LDS staging, no shuffles):
+//   weights      Wt[row tile rt][k tile kt][lane 64][8 halves]   lane l = weight row rt*32 + (l & 31), k = kt*16 + 8*(l >> 5) + 0..7
+//                (re-tiled from the blob's [N][K] once, at model load: d32_tile_weights_kernel)
+//   activations  Z[batch tile][k tile][k half][slot 32][8 halves], an f16 hi plane and an f16 lo plane with z ~ hi + lo / 2048
+//                (22 mantissa bits: f32-level accuracy, tests/estimate_f16_activation_error.py), written by the PRODUCING kernel
+//   accumulators D[weight row (r & 3) + 8 (r >> 2) + 4 (l >> 5)][slot l & 31]: a lane owns ONE slot, so every per-slot scalar
+//                (LayerNorm statistics, cache position, liveness) is a per-lane scalar
+//
+// LayerNorm never runs as a pass: W (gamma (x - mu) rstd + beta) + b = rstd (W (gamma x) - mu (W gamma)) + (W beta + b), so the
+// producer of x writes z = gamma_next * x (it knows which LayerNorm comes next), the consumer multiplies raw planes and applies
+// (mu, rstd) in its epilogue with g = W gamma and c = W beta + b precomputed in f64 at model load.  The statistics themselves
+// are per-row-tile partial (mean, M2) pairs emitted by the producer's finishing workgroups and Chan-combined in a fixed order by
+// every consumer - bit-deterministic, batch-invariant, never a two-pass read of the row.
+//
+// Work split: a workgroup = 4 waves = one 32-row tile x one K slice; the waves split the slice (tw k tiles each, loads of the
+// next chunk of TC tiles in flight under the MFMAs of the current one) and meet in LDS.  N = d projections (out projections,
+// cross query, fc2) split K across `ks` workgroups as well: each publishes its 32 x 32 partial tile with write-through stores,
+// takes a ticket, and the last arriver sums the slices in index order (MI355X_MICROARCH.md "splitk-seam": cheaper here than a
+// kernel boundary because the combine is 4-32 KB and the finisher also owns the epilogue).
+#include "dec_shared.h"
+
+namespace wh {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------- model-load helpers
+__global__ void d32_tile_weights_kernel(const f16* __restrict__ W, int N, int K, u32x4* __restrict__ out, size_t n_out) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    const int KT = K >> 4;
+    const int lane = (int)(o & 63);
+    const size_t tile = o >> 6;
+    const int kt = (int)(tile % KT), rt = (int)(tile / KT);
+    const int row = rt * 32 + (lane & 31), k = kt * 16 + 8 * (lane >> 5);
+    u32x4 v = {0, 0, 0, 0};
+    if (row < N) v = *reinterpret_cast<const u32x4*>(W + (size_t)row * K + k);
+    out[o] = v;
+}
+void dec32_tile_weights(const f16* W, int N, int K, f16* out, hipStream_t st) {
+    const size_t n_out = (size_t)((N + 31) / 32) * (K / 16) * 64;
+    d32_tile_weights_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, st>>>(W, N, K, reinterpret_cast<u32x4*>(out), n_out);
+}
+
+__global__ __launch_bounds__(256) void d32_fold_kernel(const f16* __restrict__ W, int N, int K, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ bias,
+                                                       float* __restrict__ g, float* __restrict__ c) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    double sg = 0.0, sc = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double w = (double)(float)W[(size_t)row * K + k];
+        sg += w * (double)gamma[k];
+        sc += w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o, 64); sc += __shfl_xor(sc, o, 64); }
+    if (lane == 0) { g[row] = (float)sg; c[row] = (float)(sc + (bias ? (double)bias[row] : 0.0)); }
+}
+void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* g, float* c, hipStream_t st) {
+    d32_fold_kernel<<<(N + 3) / 4, 256, 0, st>>>(W, N, K, gamma, beta, bias, g, c);
+}
+
+// ---------------------------------------------------------------------------------------------- residual tail
+// Shared by the RESID finisher and the embedding kernel: thread (slot j, channels n..n+3) holds the new residual values.
+// Stores x, the planes z = gamma_next * x for the next LayerNorm consumer, and this row tile's (mean, M2) per slot.
+__device__ __forceinline__ void d32_resid_tail(const float (&xn)[4], bool valid, int bt, int rt, int n_rt, int n, int j, int gb, int tid,
+                                               int d, float* x, const float* gamma_next, f16* zhi, f16* zlo, float2* stat_out,
+                                               float (*xs)[33]) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma_next + n);
+    if (valid) {
+        *reinterpret_cast<float4*>(x + (size_t)gb * d + n) = float4{xn[0], xn[1], xn[2], xn[3]};
+        const float z[4] = {gm.x * xn[0], gm.y * xn[1], gm.z * xn[2], gm.w * xn[3]};
+        f16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(z[i], h_, l_); hi[i] = h_; lo[i] = l_; }
+        const size_t o = plane_index(gb, n, d);
+        *reinterpret_cast<f16x4*>(zhi + o) = hi;
+        *reinterpret_cast<f16x4*>(zlo + o) = lo;
+    }
+    const int nl = n & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[nl + i][j] = xn[i];
+    __syncthreads();
+    if (tid < 32) {      // slot tid: two-pass statistics of this tile's 32 channels, fixed order
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += xs[r][tid];
+        const float mean = s * (1.0f / 32.0f);
+        float m2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { const float e = xs[r][tid] - mean; m2 = fmaf(e, e, m2); }
+        stat_out[((size_t)bt * n_rt + rt) * 32 + tid] = float2{mean, m2};
+    }
+}
+
+// Chan's pairwise update of (count, mean, M2) with a 32-sample partial (mean_b, M2_b)
+__device__ __forceinline__ void chan32(float& cn, float& cm, float& cM2, float mb, float M2b) {
+    const float nn = cn + 32.0f;
+    const float delta = mb - cm;
+    cm += delta * (32.0f / nn);
+    cM2 += M2b + delta * delta * (cn * 32.0f / nn);
+    cn = nn;
+}
+__device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, float nb, float mb, float M2b) {
+    if (nb == 0.0f) return;
+    const float nn = cn + nb;
+    const float delta = mb - cm;
+    cm += delta * (nb / nn);
+    cM2 += M2b + delta * delta * (cn * nb / nn);
+    cn = nn;
+}
+
+// ---------------------------------------------------------------------------------------------- the projection kernel
+template <int MODE, bool HILO, int TC>
+__global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
+    constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
+    __shared__ float red[4][16][64];                 // the four waves' partial tiles
+    __shared__ float st_l[8][32][3];                 // LayerNorm statistics: 8 partial (n, mean, M2) per slot
+    __shared__ float xs_raw[MODE == P32_LOGITS ? 256 * 6 : 32 * 33];   // RESID: the tile's new residual values; LOGITS: sampler records
+    float (*xs)[33] = reinterpret_cast<float (*)[33]>(xs_raw);
+    __shared__ int last_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_rt = (a.N + 31) >> 5;
+    const int rt = blockIdx.x % n_rt, ksi = blockIdx.x / n_rt, bt = blockIdx.y;
+    const int KT = a.K >> 4;
+    const int kt0 = (ksi * 4 + wave) * a.tw;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)rt * KT + kt0) * 64 + lane;
+    const size_t zoff = ((size_t)bt * KT + kt0) * 64 + lane;
+    const u32x4* hp = reinterpret_cast<const u32x4*>(a.zhi) + zoff;
+    const u32x4* lp = HILO ? reinterpret_cast<const u32x4*>(a.zlo) + zoff : nullptr;
+    // epilogue coordinates of this thread: slot j, channels n .. n + 3 (the accumulator rows 4 wave + i of half-wave h)
+    const int j = tid & 31, sub = tid >> 5;
+    const int n = rt * 32 + 4 * sub;
+    const int gb = bt * 32 + j;
+    const bool valid = gb < a.batch;
+
+    // ---- small epilogue operands, requested first (memory returns are in order per wave: they arrive under the weight stream)
+    float2 sp[5] = {};
+    if constexpr (kLN) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int idx = min(sub + 8 * i, a.n_stat - 1);
+            sp[i] = a.stat_in[((size_t)bt * a.n_stat + idx) * 32 + j];
+        }
+    }
+    float4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};    // LN modes: g, c;  RESID: bias, old x
+    int pos_l = 0, live_l = 0;
+    if constexpr (kLN) {
+        e0 = *reinterpret_cast<const float4*>(a.fold_g + n);
+        e1 = *reinterpret_cast<const float4*>(a.fold_c + n);
+    } else {
+        e0 = *reinterpret_cast<const float4*>(a.bias + n);
+        e1 = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
+    }
+    if (valid) { live_l = slot_live(a.seq + gb); if constexpr (MODE == P32_QKV) pos_l = a.seq[gb].token_index; }
+    int rules[6] = {0, 0, 0, 0, 0, 0};
+    unsigned masked4 = 0xffffffffu;
+    int tb = 0, ws_tok = 0, eot_tok = 0, nots_tok = 0;
+    if constexpr (MODE == P32_LOGITS) {
+        if (a.stats) {
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rules[i] = a.seq[gb].f_rules[i];
+            }
+            if (n + 3 < a.N) masked4 = *reinterpret_cast<const unsigned*>(a.sup_mask + n);
+            else {
+                masked4 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) masked4 |= (unsigned)(n + i < a.N ? a.sup_mask[n + i] : 1) << (8 * i);
+            }
+            tb = a.cfg->time_token_begin; ws_tok = a.cfg->whitespace_token; eot_tok = a.cfg->end_token; nots_tok = a.cfg->no_timestamps_token;
+        }
+    }
+
+    // ---- weight stream x activation planes on the matrix cores
+    f32x16 acc_h = {0}, acc_l = {0};
+    u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
+    auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64);     // streamed once: nt
+#pragma unroll
+        for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
+        if constexpr (HILO) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
+        }
+    };
+    auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
+            acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h, 0, 0, 0);
+            if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l, 0, 0, 0);
+        }
+    };
+    const int nch = a.tw / TC;
+    ld(wa, ha, la, 0);
+    // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
+    if constexpr (kLN) {
+        float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (sub + 8 * i < a.n_stat) chan32(cn, cm, cM2, sp[i].x, sp[i].y);
+        st_l[sub][j][0] = cn; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
+    }
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) ld(wb, hb, lb, c + 1);
+        mm(wa, ha, la);
+        if (c + 2 < nch) ld(wa, ha, la, c + 2);
+        if (c + 1 < nch) mm(wb, hb, lb);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = HILO ? fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]) : acc_h[r];
+    __syncthreads();
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
+
+    // ---- K split across workgroups: publish, ticket, the last arriver sums the slices in index order
+    if (a.ks > 1) {
+        float* base = a.part + (((size_t)bt * n_rt + rt) * a.ks) * 1024 + tid * 4;
+        float* mine = base + (size_t)ksi * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(mine + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int* cnt = a.ticket + bt * n_rt + rt;
+            const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == a.ks - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
+            }
+            last_flag = last;
+        }
+        __syncthreads();
+        if (!last_flag) return;             // workgroup-uniform
+        float pv[8][4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {       // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
+            const float* p = base + (size_t)(s < a.ks ? s : 0) * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = pv[0][i];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) t += (s < a.ks) ? pv[s][i] : 0.0f;
+            v[i] = t;
+        }
+    }
+
+    // ---- epilogues
+    float y[4];
+    if constexpr (kLN) {
+        float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) chan_merge(cn, cm, cM2, st_l[s][j][0], st_l[s][j][1], st_l[s][j][2]);
+        const float mu = cm, rstd = rsqrtf(cM2 / (float)a.d + 1e-5f);
+        const float g4[4] = {e0.x, e0.y, e0.z, e0.w}, c4[4] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(rstd, v[i] - mu * g4[i], c4[i]);
+    }
+    if constexpr (MODE == P32_QKV) {
+        if (valid && live_l) {
+            const int d = a.d;
+            if (n < d) *reinterpret_cast<float4*>(a.q + (size_t)gb * d + n) = float4{y[0], y[1], y[2], y[3]};
+            else {
+                int c = n - d;
+                f16* dst = a.self_k;
+                if (c >= d) { c -= d; dst = a.self_v; }
+                const int pos = min(max(pos_l, 0), kMaxTok - 1);
+                *reinterpret_cast<f16x4*>(dst + (((size_t)gb * a.n_head + (c >> 6)) * kMaxTok + pos) * kHeadDim + (c & 63)) =
+                    f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+            }
+        }
+    } else if constexpr (MODE == P32_Q) {
+        if (valid && live_l) *reinterpret_cast<float4*>(a.q + (size_t)gb * a.d + n) = float4{y[0], y[1], y[2], y[3]};
+    } else if constexpr (MODE == P32_FC1) {
+        if (valid)
+            *reinterpret_cast<f16x4*>(a.h_out + plane_index(gb, n, a.N)) =
+                f16x4{(f16)gelu_erf(y[0]), (f16)gelu_erf(y[1]), (f16)gelu_erf(y[2]), (f16)gelu_erf(y[3])};
+    } else if constexpr (MODE == P32_RESID) {
+        const float b4[4] = {e0.x, e0.y, e0.z, e0.w}, x4[4] = {e1.x, e1.y, e1.z, e1.w};
+        float xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[i] + b4[i]);
+        d32_resid_tail(xn, valid && live_l, bt, rt, n_rt, n, j, gb, tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out, xs);
+    } else {    // P32_LOGITS
+        if (a.logits && valid && live_l) {
+            float* lo = a.logits + (size_t)gb * a.N + n;
+            if (n + 3 < a.N) {
+                *reinterpret_cast<float2*>(lo) = float2{y[0], y[1]};
+                *reinterpret_cast<float2*>(lo + 2) = float2{y[2], y[3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n + i < a.N) lo[i] = y[i];
+            }
+        }
+        if (a.stats) {
+            // fused greedy sampler, part 1 (decoder.hip logits_block_stats): the index-predicate filters of LogitsFilter.swift on this
+            // thread's 4 ids, then (max, sum exp, argmax) separately for text and timestamp ids; the 8 threads of a slot meet in LDS
+            SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
+            const int blank = rules[0], ts_active = rules[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int id = n + i;
+                bool masked = ((masked4 >> (8 * i)) & 0xff) != 0 || id >= a.N;                                   // SuppressTokensFilter
+                masked |= blank && (id == ws_tok || id == eot_tok);                                               // SuppressBlankFilter
+                masked |= ts_active && (id == nots_tok || (id >= rules[2] && id < rules[3]) || (id >= rules[4] && id < rules[5]));   // TimestampRulesFilter
+                if (!masked) { if (id < tb) stat_merge(t, y[i], 1.0f, id); else stat_merge(u, y[i], 1.0f, id); }
+            }
+            float* rec = xs_raw + (size_t)(sub * 32 + j) * 6;
+            rec[0] = t.m; rec[1] = t.s; rec[2] = __int_as_float(t.i); rec[3] = u.m; rec[4] = u.s; rec[5] = __int_as_float(u.i);
+            __syncthreads();
+            if (tid < 32 && valid && live_l) {
+                SoftStat T{-INFINITY, 0.0f, 0x7fffffff}, U{-INFINITY, 0.0f, 0x7fffffff};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float* r_ = xs_raw + (size_t)(s * 32 + tid) * 6;
+                    stat_merge(T, r_[0], r_[1], __float_as_int(r_[2]));
+                    stat_merge(U, r_[3], r_[4], __float_as_int(r_[5]));
+                }
+                float* o = a.stats + ((size_t)gb * kStatBlocks + rt) * 8;
+                *reinterpret_cast<float4*>(o) = float4{T.m, T.s, __int_as_float(T.i), U.m};
+                *reinterpret_cast<float2*>(o + 4) = float2{U.s, __int_as_float(U.i)};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- embedding
+// x = token_embedding[next_token] + positional_embedding[token_index] (openai/whisper TextDecoder.forward), the head of the
+// residual chain: same tail as a RESID finisher (x, gamma_1 x planes of layer 0, row-tile statistics).
+__global__ __launch_bounds__(256) void dec32_embed_kernel(const f16* __restrict__ emb, const float* __restrict__ pos, const SeqState* __restrict__ seq,
+                                                          int batch, int d, int n_vocab, float* x, const float* gamma_next, f16* zhi, f16* zlo,
+                                                          float2* stat_out) {
+    __shared__ float xs[32][33];
+    const int tid = threadIdx.x, j = tid & 31, sub = tid >> 5;
+    const int rt = blockIdx.x, bt = blockIdx.y, n_rt = gridDim.x;
+    const int n = rt * 32 + 4 * sub, gb = bt * 32 + j;
+    const bool valid = gb < batch;
+    float xn[4] = {0, 0, 0, 0};
+    bool live = false;
+    if (valid) {
+        live = slot_live(seq + gb);
+        const int tok = min(max(seq[gb].next_token, 0), n_vocab - 1);
+        const int p = min(max(seq[gb].token_index, 0), kMaxTok - 1);
+        const f16x4 e = *reinterpret_cast<const f16x4*>(emb + (size_t)tok * d + n);
+        const float4 pz = *reinterpret_cast<const float4*>(pos + (size_t)p * d + n);
+        xn[0] = (float)e[0] + pz.x; xn[1] = (float)e[1] + pz.y; xn[2] = (float)e[2] + pz.z; xn[3] = (float)e[3] + pz.w;
+    }
+    d32_resid_tail(xn, valid && live, bt, rt, n_rt, n, j, gb, tid, d, x, gamma_next, zhi, zlo, stat_out, xs);
+}
+void launch_dec32_embed(const f16* emb, const float* pos, const SeqState* seq, int batch, int d, int n_vocab, int n_bt, float* x,
+                        const float* gamma_next, f16* zhi, f16* zlo, float2* stat, hipStream_t st) {
+    ProfScope ps_(KK_DEC_EMBED, st);
+    dec32_embed_kernel<<<dim3(d / 32, n_bt), 256, 0, st>>>(emb, pos, seq, batch, d, n_vocab, x, gamma_next, zhi, zlo, stat);
+}
+
+// ---------------------------------------------------------------------------------------------- launcher
+static int env_int32(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// K splits across workgroups: only the N = d projections need them (40 row tiles at d = 1280 would leave 5/6 of the chip idle);
+// the split must divide the K / 64 tile groups.  WH_D32_KS_* override (tuning).
+int dec32_ksplit(int mode, int N, int K, bool f16_input) {
+    static const int ks_resid = env_int32("WH_D32_KS_RESID", 4), ks_fc2 = env_int32("WH_D32_KS_FC2", 4), ks_q = env_int32("WH_D32_KS_Q", 4),
+                     ks_wide = env_int32("WH_D32_KS_WIDE", 1);
+    int want = (mode == P32_RESID) ? (f16_input ? ks_fc2 : ks_resid) : (mode == P32_Q ? ks_q : ks_wide);
+    const int groups = K / 64;
+    want = max(1, min(want, 8));
+    while (want > 1 && groups % want) --want;
+    return want;
+}
+
+template <int MODE, bool HILO>
+static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
+    const int tw = a.tw;
+    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
+    else if (tw % 6 == 0) dec32_proj_kernel<MODE, HILO, 6><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
+}
+
+void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) {
+    P32Args a = a_in;
+    const bool hilo = a.zlo != nullptr;
+    a.ks = dec32_ksplit(mode, a.N, a.K, !hilo);
+    a.tw = a.K / (64 * a.ks);
+    const dim3 grid(((a.N + 31) / 32) * a.ks, n_bt);
+    ProfScope ps_(a.prof_kind, st);
+    switch (mode) {
+        case P32_QKV: launch_tc<P32_QKV, true>(a, grid, st); break;
+        case P32_Q: launch_tc<P32_Q, true>(a, grid, st); break;
+        case P32_FC1: launch_tc<P32_FC1, true>(a, grid, st); break;
+        case P32_LOGITS: launch_tc<P32_LOGITS, true>(a, grid, st); break;
+        default:
+            if (hilo) launch_tc<P32_RESID, true>(a, grid, st);
+            else launch_tc<P32_RESID, false>(a, grid, st);
+    }
+}
+
+}  // namespace wh

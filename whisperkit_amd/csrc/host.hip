@@ -759,7 +759,7 @@ extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const in
 static const char* kKindNames[KK_COUNT] = {
     "mel_power", "mel_finalize", "gemm_conv1", "gemm_conv2", "layernorm", "gemm_enc_qkv", "enc_attention", "gemm_enc_o", "gemm_enc_fc1",
     "gemm_enc_fc2", "gemm_cross_kv", "dec_gemv_qkv", "dec_self_attn", "dec_gemv_oproj", "dec_gemv_cq", "dec_cross_attn", "dec_gemv_coproj",
-    "dec_gemv_fc1", "dec_gemv_fc2", "dec_gemv_logits", "sampler"};
+    "dec_gemv_fc1", "dec_gemv_fc2", "dec_gemv_logits", "sampler", "dec_embed"};
 namespace wh { unsigned long long* debug_buffer(); }
 extern "C" int wh_debug_dump(const char* path) {
     unsigned long long* b = wh::debug_buffer();
@@ -783,7 +783,7 @@ extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double*
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
     if (!avg_us || !launches || n_steps < 0 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_kernels: invalid argument");
     const int L = s->m->dims.n_text_layer, Le = s->m->dims.n_audio_layer;
-    const size_t cap = (size_t)(8 * L + 2) * n_steps + 7 * Le + 16;
+    const size_t cap = (size_t)(9 * L + 4) * n_steps + 7 * Le + 16;
     KernelProfiler prof;
     prof.ev.resize(2 * cap); prof.kind.resize(cap); prof.capacity = cap;
     for (auto& e : prof.ev) WH_HIP(hipEventCreate(&e));

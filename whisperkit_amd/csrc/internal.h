@@ -33,6 +33,10 @@ struct wh_model {
     std::vector<wh::DecLayerW> dec;
     const f16 *conv1_w, *conv2_w, *emb, *ckv_w;
     const float *conv1_b, *conv2_b, *enc_pos, *lnp_g, *lnp_b, *dec_pos, *ckv_b, *lnf_g, *lnf_b;
+    // MFMA decode path (decoder32.hip): decoder weights re-tiled into MFMA A-fragment order + LayerNorm fold vectors, built at load
+    std::vector<wh::Dec32LayerW> dec32;
+    void* dec32_blob = nullptr;
+    const f16* emb_t = nullptr; const float *lg_g = nullptr, *lg_c = nullptr;
     std::vector<int> align_slot;   // [L*H] -> slot or -1
     int n_align = 0;
     int* align_slot_dev = nullptr;
@@ -53,6 +57,9 @@ struct wh_session {
     int* ticket = nullptr;
     f16* hbuf = nullptr;
     float *align = nullptr, *align_mean = nullptr;
+    wh::Dec32 d32{};                      // MFMA decode path buffers (one allocation: d32_blob)
+    void* d32_blob = nullptr;
+    bool use32 = false;
     wh::SeqState* seq = nullptr;
     wh::SeqState* seq_host = nullptr;     // pinned
     wh::SamplerCfg* cfg_dev = nullptr;

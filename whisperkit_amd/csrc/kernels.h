@@ -12,7 +12,7 @@ namespace wh {
 enum KernelKind {
     KK_MEL_POWER = 0, KK_MEL_FINALIZE, KK_CONV1, KK_CONV2, KK_LAYERNORM, KK_ENC_QKV, KK_ENC_ATTN, KK_ENC_O, KK_ENC_FC1, KK_ENC_FC2,
     KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_OPROJ, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_COPROJ, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS,
-    KK_SAMPLER,
+    KK_SAMPLER, KK_DEC_EMBED,
     KK_COUNT
 };
 struct KernelProfiler {
@@ -161,11 +161,58 @@ struct DecodeBuffers {
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
+    const struct Dec32* d32; // MFMA batch-tile decode path (decoder32.hip); null: GEMV path
 };
-constexpr int kStatBlocks = 1024; // >= workgroups of the logits kernel (V / 64 rows)
+constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
 constexpr int kMaxSplit = 24;   // cross-attention key splits (64 keys per workgroup at the finest)
 constexpr int kPartStride = 96; // floats per split partial (m, l, o[64]) padded to 3 x 128 bytes: no cache line is shared between splits
 int cross_attn_splits(int batch, int n_head);
+
+// ---------------------------------------------------------------------------------------------- MFMA decode path (decoder32.hip)
+// Batch tiles of 32 slots are the N side of v_mfma_f32_32x32x16_f16; weights are re-tiled at model load so that one
+// 1 KB coalesced load IS one A fragment: Wt[row tile][k tile][lane 64][8 halves], lane l = (row & 31) | (k half << 5).
+// Activations travel between kernels in the matching B-fragment order ("planes"): Z[batch tile][k tile][k half][slot 32][8],
+// f16 hi plane + f16 lo plane (lo = (z - hi) * 2048: 22 mantissa bits, no subnormals), written by the producing kernel.
+struct Dec32LayerW {
+    const f16 *qkv_t, *o_t, *cq_t, *co_t, *fc1_t, *fc2_t;      // tiled weights
+    const float *qkv_g, *qkv_c, *cq_g, *cq_c, *fc1_g, *fc1_c;  // LayerNorm folds: g = W gamma, c = W beta + bias
+};
+struct Dec32 {
+    const Dec32LayerW* layers_host;   // [L]
+    const f16* emb_t; const float *lg_g, *lg_c;   // tied-embedding logits: tiled [ceil(V/32)*32][d], folds of the final LayerNorm
+    int n_bt;                // batch tiles allocated (ceil(max_batch / 32))
+    float* x;                // [n_bt*32][d] residual stream
+    float* q;                // [n_bt*32][d] query of the attention kernels
+    f16 *za_hi, *za_lo;      // [n_bt][d/16][2][32][8] gamma * x of the next LayerNorm consumer
+    f16 *zb_hi, *zb_lo;      // attention output (input of the out projections)
+    f16* h;                  // [n_bt][4d/16][2][32][8] GELU(fc1), single plane
+    float2* stat;            // [n_bt][d/32][32] per-row-tile (mean, M2) of the residual stream: LayerNorm statistics, Chan-combined
+    float* part; int* ticket; // split-K partial tiles + arrival counters
+    size_t part_floats;
+};
+constexpr int kD32PartFloats = 2 * 1024 * 1024;   // per batch tile: row tiles x K splits x 1024 <= 2 M floats
+enum { P32_QKV = 0, P32_Q = 1, P32_RESID = 2, P32_FC1 = 3, P32_LOGITS = 4 };
+struct P32Args {
+    int batch, N, K, d, n_head, n_vocab;
+    int ks, tw;              // K splits across workgroups; 16-wide k tiles per wave = K / (64 ks)
+    const f16* Wt;
+    const f16 *zhi, *zlo;    // input planes (zlo == null: single f16 plane)
+    const float2* stat_in; int n_stat; const float *fold_g, *fold_c;           // LayerNorm fold (QKV, Q, FC1, LOGITS)
+    const float* bias; float* x; const float* gamma_next; f16 *zhi_out, *zlo_out; float2* stat_out;   // RESID
+    float* q; f16 *self_k, *self_v;                                            // QKV / Q
+    f16* h_out;                                                                // FC1
+    float* logits; float* stats; const unsigned char* sup_mask; const SamplerCfg* cfg;   // LOGITS (+ fused greedy statistics)
+    float* part; int* ticket;
+    const SeqState* seq;
+    int prof_kind;
+};
+void launch_dec32_proj(int mode, const P32Args& a, int n_bt, hipStream_t st);
+void launch_dec32_embed(const f16* emb, const float* pos, const SeqState* seq, int batch, int d, int n_vocab, int n_bt, float* x,
+                        const float* gamma_next, f16* zhi, f16* zlo, float2* stat, hipStream_t st);
+// model-load helpers: re-tile W[N][K] -> out[ceil(N/32)][K/16][64][8]; g[n] = sum_k W[n][k] gamma[k], c[n] = sum_k W[n][k] beta[k] + bias[n] (f64 sums)
+void dec32_tile_weights(const f16* W, int N, int K, f16* out, hipStream_t st);
+void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* g, float* c, hipStream_t st);
+int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // one decoder forward + (optionally) fused filter/sample/state-advance for all slots
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st);
