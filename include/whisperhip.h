@@ -51,7 +51,8 @@ typedef enum wh_status {
     WH_ERR_TRANSCRIPTION_FAILED = 9,
     WH_ERR_DECODING_FAILED = 10,
     WH_ERR_INVALID_ARGUMENT = 100,
-    WH_ERR_HIP = 101
+    WH_ERR_HIP = 101,
+    WH_ERR_CANCELLED = 102      /* Swift CancellationError thrown by Task.checkCancellation (Core/TranscribeTask.swift:135,144,165) */
 } wh_status;
 
 #define WH_WINDOW_SAMPLES 480000 /* Constants.defaultWindowSamples, Core/Models.swift:1457 */
@@ -167,7 +168,9 @@ int wh_model_create(const void* blob, size_t nbytes, int device, wh_model** out)
 int wh_model_load(const char* path, int device, wh_model** out);
 void wh_model_destroy(wh_model* m);
 int wh_model_dims(const wh_model* m, wh_dims* out);
-/* alignment heads for word timestamps: (layer, head) pairs; default = upper half of the decoder layers */
+/* alignment heads for word timestamps: (layer, head) pairs; default = the blob's "dec.alignment_heads" tensor when present
+ * (checkpoint conversion stores generation_config.alignment_heads there), else the upper half of the decoder layers.  May be
+ * called while sessions exist but not while one of them is decoding: sessions re-size their score buffers on their next use. */
 int wh_model_set_alignment_heads(wh_model* m, const int32_t* layer_head_pairs, int n_pairs);
 
 /* dimension getters the reference introspects from the CoreML models */
@@ -215,6 +218,18 @@ int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens, const int
                       float* logits_out_host /* [batch][n_vocab] or NULL */);
 int wh_get_alignment_weights(wh_session* s, int b, float* out_host /* [224][1500] */);
 
+/* Device-resident hand-off (MLMultiArray outputs of the CoreML stages stay on the accelerator in the reference too): pointers
+ * into the session's HBM buffers of slot b, valid until the session rewrites them; consume them on wh_session_stream(s) or after
+ * wh_session_synchronize.  mel [n_mels][3000] f32; encoder output [1500][d] as f32 and as the f16 copy the decoder reads
+ * (either pointer argument may be NULL); logits [max_batch][n_vocab] f32 as left by the last wh_predict_logits / T > 0 step. */
+int wh_get_mel_device(wh_session* s, int b, const float** mel_dev);
+int wh_get_encoder_output_device(wh_session* s, int b, const float** enc_f32_dev, const void** enc_f16_dev);
+int wh_get_logits_device(wh_session* s, const float** logits_dev);
+/* Task.checkCancellation (Core/TranscribeTask.swift:135,144,165; TextDecoder early stop): `flag` is polled between pipeline
+ * stages, between windows and every 8 decoder steps; a non-zero value makes the running call return WH_ERR_CANCELLED.  NULL
+ * removes it.  The flag must outlive the calls it guards. */
+int wh_session_set_cancel_flag(wh_session* s, const volatile int32_t* flag);
+
 /* LogitsFiltering.filterLogits for the built-in chain of createLogitsFilters (Core/TextDecoder.swift:857-899,
  * Core/Text/LogitsFilter.swift) applied on device to caller-supplied logits; `tokens` = currentTokens,
  * `prefilled_index`/`initial_prompt_index` as in decodeText.  language_filter != 0 applies LanguageLogitsFilter instead. */
@@ -244,6 +259,12 @@ int wh_session_set_progress_callback(wh_session* s, wh_progress_fn fn, void* use
 int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,
                    const int32_t* prompt, int n_prompt, const float* temperatures, const int32_t* active,
                    uint64_t seed, wh_decoding_result* out /* [batch] */);
+/* The same with one language token per slot (language_tokens[b] >= 0 replaces the token after <|startoftranscript|> of the
+ * shared prompt for slot b): batched windows of audios in different languages, each prompted like its own TranscribeTask
+ * would prompt it (Core/TextDecoder.swift:183-188).  language_tokens == NULL: identical to wh_decode_text. */
+int wh_decode_text_languages(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,
+                             const int32_t* prompt, int n_prompt, const int32_t* language_tokens, const float* temperatures,
+                             const int32_t* active, uint64_t seed, wh_decoding_result* out /* [batch] */);
 /* TextDecoding.detectLanguage (Core/TextDecoder.swift:420-539) */
 int wh_detect_language(wh_session* s, int batch, const wh_special_tokens* st, int32_t* language_tokens_out,
                        float* logprobs_out);

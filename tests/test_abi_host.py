@@ -271,13 +271,13 @@ def test_bench_work_formulas_reproduce_the_survey_figures():
     dims = weights.MODEL_DIMS["large-v3"]
     d, L_, V = dims.n_text_state, dims.n_text_layer, dims.n_vocab
     assert L_ * (w("dec_cross_attn", dims) - 2 * d * 4) == pytest.approx(245.8e6, rel=0.001)          # K and V of 1500 positions, fp16
-    # decoder weights read per step, shared by the batch: SURVEY counts 1.81 GB; the folded cross-query matrices replace W_cq by 4 d^2
-    per_layer_w = (3 * d * d + d * d + 4 * d * d + d * d + 4 * d * d + 4 * d * d) * 2
-    got = L_ * sum(w(k, dims, 1, 0.0) for k in ("dec_gemv_qkv", "dec_gemv_oproj", "dec_gemv_coproj", "dec_gemv_fc1", "dec_gemv_fc2")) + \
-        w("dec_gemv_logits", dims, 1, 0.0)
+    # decoder weights read per step, shared by the batch (MFMA path: every matrix exactly once, no folded product matrices)
+    per_layer_w = (3 * d * d + d * d + d * d + d * d + 4 * d * d + 4 * d * d) * 2
+    got = L_ * sum(w(k, dims, 1, 0.0) for k in ("dec_proj_qkv", "dec_proj_oproj", "dec_proj_cq", "dec_proj_coproj", "dec_proj_fc1", "dec_proj_fc2")) + \
+        w("dec_proj_logits", dims, 1, 0.0)
     assert got == pytest.approx(L_ * per_layer_w + V * d * 2, rel=0.01)
     all_decoder = L_ * (4 + 4 + 8) * d * d * 2 + V * d * 2               # SURVEY's 1.81 GB: every decoder matrix incl. the cross K/V projections
     assert all_decoder == pytest.approx(1.81e9, rel=0.02)
-    per_step_classic = all_decoder - L_ * 2 * d * d * 2                     # ... which run once per window (gemm_cross_kv), not per token
-    assert got - per_step_classic == pytest.approx(L_ * 3 * d * d * 2, rel=0.03)   # the fold trades W_cq (d^2) for 4 d^2 per layer
+    per_step = all_decoder - L_ * 2 * d * d * 2                             # ... which run once per window (gemm_cross_kv), not per token
+    assert got == pytest.approx(per_step, rel=0.01)
     assert w("mel_power", weights.MODEL_DIMS["large-v3"]) + 0 >= 480000 * 4                              # PCM read is in the bill

@@ -46,9 +46,10 @@ def test_hf_folder_and_openai_pt_round_trip(tmp_path):
     out = tmp_path / "m.whipw"
     assert checkpoint.main([str(folder), str(out)]) == 0
     blob = np.fromfile(str(out), dtype=np.uint8)
-    assert np.array_equal(blob, weights.pack_blob(dims, sd))
+    assert np.array_equal(blob, weights.pack_blob(dims, sd, alignment_heads=[(1, 0), (1, 1)]))
     d4, tensors = weights.unpack_blob(blob)
     assert d4 == dims and json.load(open(str(out) + ".alignment_heads.json")) == [[1, 0], [1, 1]]
+    assert tensors["dec.alignment_heads"].tolist() == [[1, 0], [1, 1]]     # wh_model_load picks the heads up from the blob itself
     # a bf16 safetensors file loads as well (values rounded to bf16, returned as fp32)
     from safetensors.torch import save_file
     hf = weights.to_hf_state_dict(sd)

@@ -1,0 +1,203 @@
+"""GPU tests for the round-2 boundary and host-logic changes: alignment survives another slot's temperature fallback, every
+slot of a batch is prompted with its own detected language, polled cancellation (Task.checkCancellation), alignment heads
+changed while sessions exist, weight-blob validation, device-resident outputs, session-owned step graphs."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import decode as OD
+from oracle.model import OracleWhisper
+from whisperkit_amd import api, weights
+from whisperkit_amd.synth import synthetic_chunk
+
+pytestmark = pytest.mark.gpu
+
+NOFALLBACK = dict(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, temperatureFallbackCount=0)
+
+
+@pytest.fixture(scope="module")
+def micro():
+    dims = weights.MODEL_DIMS["test-micro"]
+    sd = weights.synthetic_state_dict(dims, seed=0)
+    return dims, sd, api.Model(dims, sd)
+
+
+@pytest.fixture(scope="module")
+def micro_ml():
+    dims = weights.MODEL_DIMS["test-micro-ml"]
+    sd = weights.synthetic_state_dict(dims, seed=1)
+    return dims, sd, api.Model(dims, sd)
+
+
+def _words(r):
+    return [(w.tokens, round(w.start, 4), round(w.end, 4)) for w in r.allWords()]
+
+
+def test_fallback_of_one_slot_keeps_the_other_slots_alignment(micro):
+    """a slot accepted at T = 0 must keep its alignment rows while another slot of the batch re-decodes at the
+    next temperature (TranscribeTask.decodeWithFallback resets only the task's own DecodingInputs, TranscribeTask.swift:374-398)."""
+    dims, _, model = micro
+    audios = [synthetic_chunk(901), synthetic_chunk(902)]
+    # withoutTimestamps: no timestamp tokens -> the seek advances by the whole window -> exactly one window per audio
+    base = dict(sampleLength=14, firstTokenLogProbThreshold=None, compressionRatioThreshold=None, wordTimestamps=True, seed=3, withoutTimestamps=True)
+    s2 = api.Session(model, 2)
+    probe = s2.transcribe(audios, api.DecodingOptions(**base, logProbThreshold=None, temperatureFallbackCount=0))
+    lps = [r.segments[0].avgLogprob for r in probe]
+    assert abs(lps[0] - lps[1]) > 1e-3
+    thr = 0.5 * (lps[0] + lps[1])                     # exactly one slot is below the threshold and falls back once
+    opts = api.DecodingOptions(**base, logProbThreshold=thr, temperatureFallbackCount=1)
+    got = s2.transcribe(audios, opts)
+    keeper = int(np.argmax(lps))
+    assert got[keeper].timings["total_decoding_fallbacks"] == 0 and got[1 - keeper].timings["total_decoding_fallbacks"] == 1
+    s1 = api.Session(model, 1)
+    alone = s1.transcribe([audios[keeper]], opts)[0]        # the keeper decoded at T = 0 only: deterministic, comparable
+    assert got[keeper].tokens == alone.tokens
+    assert _words(got[keeper]) == _words(alone)
+    for i in (0, 1):
+        assert len(got[i].allWords()) > 0 and any(w.end > w.start for w in got[i].allWords()), i
+
+
+def test_batched_language_detection_prompts_every_slot_with_its_own_language(micro_ml):
+    """detectLanguage runs per audio (one TranscribeTask each, WhisperKit.swift:735-792): in a device batch
+    every slot's prompt carries ITS language token."""
+    dims, _, model = micro_ml
+    s2, s1 = api.Session(model, 2), api.Session(model, 1)
+    pair = None
+    for seed in range(300, 340):                      # two windows whose detected languages differ
+        xs = [synthetic_chunk(seed), synthetic_chunk(seed + 100)]
+        for b, x in enumerate(xs):
+            s2.padOrTrim(x, b)
+        s2.logMelSpectrogram(2); s2.encodeFeatures(2); s2.prepareDecoderInputs(2)
+        lt, _ = s2.detectLanguage(2)
+        if lt[0] != lt[1]:
+            pair = (xs, lt)
+            break
+    assert pair is not None, "no pair of synthetic chunks with different detected languages"
+    xs, lt = pair
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12, detectLanguage=True)
+    got = s2.transcribe(xs, opts)
+    for i in (0, 1):
+        alone = s1.transcribe([xs[i]], opts)[0]
+        assert got[i].tokens == alone.tokens, i
+        assert got[i].tokens[1] == lt[i]              # <|startoftranscript|> <|lang|> ...
+    # the step API form
+    prompt = s2.prefillPrompt(api.DecodingOptions(**NOFALLBACK, sampleLength=12))
+    for b, x in enumerate(xs):
+        s2.padOrTrim(x, b)
+    s2.logMelSpectrogram(2); s2.encodeFeatures(2); s2.prepareDecoderInputs(2)
+    r = s2.decodeText(prompt, api.DecodingOptions(**NOFALLBACK, sampleLength=12), batch=2, languageTokens=lt)
+    assert [x.tokens[1] for x in r] == list(lt)
+
+
+def test_cancel_flag_is_polled(micro):
+    dims, _, model = micro
+    sess = api.Session(model, 1)
+    flag = C.c_int32(1)
+    sess.setCancelFlag(flag)
+    with pytest.raises(api.WhisperError) as e:
+        sess.transcribe([synthetic_chunk(5)], api.DecodingOptions(**NOFALLBACK, sampleLength=20))
+    assert e.value.code == 102                        # WH_ERR_CANCELLED
+    flag.value = 0
+    assert len(sess.transcribe([synthetic_chunk(5)], api.DecodingOptions(**NOFALLBACK, sampleLength=20))[0].tokens) > 0
+    sess.setCancelFlag(None)
+
+
+def test_alignment_heads_changed_while_a_session_exists():
+    """more heads than the session's score buffer was sized for must re-size it (and drop graphs that bake
+    the old row stride), not write past it."""
+    dims = weights.MODEL_DIMS["test-micro"]
+    sd = weights.synthetic_state_dict(dims, seed=0)
+    model = api.Model(dims, sd)
+    sess = api.Session(model, 2)
+    xs = [synthetic_chunk(611), synthetic_chunk(612)]
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=20, wordTimestamps=True)
+
+    def run():
+        for b, x in enumerate(xs):
+            sess.padOrTrim(x, b)
+        sess.logMelSpectrogram(2); sess.encodeFeatures(2); sess.prepareDecoderInputs(2)
+        res = sess.decodeText(sess.prefillPrompt(opts), opts, batch=2)
+        return res, [sess.getAlignmentWeights(b) for b in range(2)]
+    _, a_default = run()
+    heads = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    model.setAlignmentHeads(heads)
+    res, a_all = run()
+    assert np.abs(a_all[0] - a_default[0]).max() > 1e-5          # the head set really changed
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+    om = OracleWhisper(dims, sd, alignment_heads=heads)
+    for b in range(2):
+        state = om.new_state(sess.getEncoderOutput(b).astype(np.float16).astype(np.float32))
+        oopts = OD.DecodingOptions(**NOFALLBACK, sampleLength=20, wordTimestamps=True)
+        OD.decode_text(lambda t, p: state.step(t, p), sess.prefillPrompt(opts), OD.GreedyTokenSampler(0.0, st.endToken, oopts), oopts, st, False, langs)
+        n = res[b].steps
+        assert np.abs(a_all[b][1:n + 1] - state.alignment[1:n + 1]).max() <= 1e-4
+    model.setAlignmentHeads([(1, 1)])                                 # fewer heads: same path
+    _, a_one = run()
+    np.testing.assert_allclose(a_one[0][1:10].sum(1), 1.0, atol=1e-3)
+
+
+def test_weight_blob_validation_rejects_instead_of_crashing(micro):
+    dims, sd, _ = micro
+    blob = bytearray(bytes(weights.pack_blob(dims, sd)))
+
+    def create(b):
+        return api.Model(dims, blob=bytes(b))
+    bad = bytearray(blob); struct.pack_into("<i", bad, 8 + 4 * 9, -1)             # n_text_layer = -1
+    with pytest.raises(api.WhisperError):
+        create(bad)
+    bad = bytearray(blob); struct.pack_into("<i", bad, 8 + 4 * 5, 10)             # n_vocab = 10
+    with pytest.raises(api.WhisperError):
+        create(bad)
+    entry = struct.Struct("<64sii4qqq")
+    name, dt, nd, s0, s1, s2, s3, off, nb = entry.unpack_from(blob, 56)
+    bad = bytearray(blob); entry.pack_into(bad, 56, name, dt, nd, s0, s1, s2, s3, off, -nb)      # negative nbytes
+    with pytest.raises(api.WhisperError):
+        create(bad)
+    bad = bytearray(blob); entry.pack_into(bad, 56, name, dt, nd, s0, s1, s2, s3, off, nb // 2)  # tensor smaller than the dims need
+    with pytest.raises(api.WhisperError):
+        create(bad)
+    bad = bytearray(blob); entry.pack_into(bad, 56, name, dt, nd, s0, s1, s2, s3, (1 << 62), nb)  # offset + nbytes overflow
+    with pytest.raises(api.WhisperError):
+        create(bad)
+    create(blob).close()
+
+
+def test_device_resident_outputs(micro):
+    dims, _, model = micro
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    sess = api.Session(model, 2)
+    for b in range(2):
+        sess.padOrTrim(synthetic_chunk(40 + b), b)
+    sess.logMelSpectrogram(2); sess.encodeFeatures(2); sess.synchronize()
+    for b in range(2):
+        mel = np.empty((dims.n_mels, 3000), np.float32)
+        assert hip.hipMemcpy(mel.ctypes.data, sess.getMelDevice(b), mel.nbytes, 2) == 0
+        np.testing.assert_array_equal(mel, sess.getMel(b))
+        p32, p16 = sess.getEncoderOutputDevice(b)
+        e32 = np.empty((1500, dims.n_audio_state), np.float32); e16 = np.empty((1500, dims.n_audio_state), np.float16)
+        assert hip.hipMemcpy(e32.ctypes.data, p32, e32.nbytes, 2) == 0 and hip.hipMemcpy(e16.ctypes.data, p16, e16.nbytes, 2) == 0
+        np.testing.assert_array_equal(e32, sess.getEncoderOutput(b))
+        np.testing.assert_array_equal(e16, e32.astype(np.float16))
+    sess.prepareDecoderInputs(2)
+    got = sess.predictLogits([50257, 50257], [0, 0])
+    lg = np.empty((2, dims.n_vocab), np.float32)
+    assert hip.hipMemcpy(lg.ctypes.data, sess.getLogitsDevice(), lg.nbytes, 2) == 0
+    np.testing.assert_array_equal(lg, got)
+
+
+def test_sessions_own_their_step_graphs(micro):
+    """No process-wide graph cache: sessions created and destroyed in any order keep decoding correctly."""
+    dims, _, model = micro
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=20)
+    ref = None
+    for rep in range(3):
+        ss = [api.Session(model, 1) for _ in range(3)]
+        for s in ss:
+            s.padOrTrim(synthetic_chunk(77)); s.logMelSpectrogram(1); s.encodeFeatures(1); s.prepareDecoderInputs(1)
+        rs = [s.decodeText(s.prefillPrompt(opts), opts)[0].tokens for s in ss]
+        ref = ref or rs[0]
+        assert all(r == ref for r in rs)
+        ss[1].close(); ss[0].close(); ss[2].close()

@@ -119,7 +119,12 @@ SYMBOLS = {
     "wh_filter_logits": (I, [VP, POPT, PST, PI32, I, I, I, I, VP, I]),
     "wh_sample_token": (I, [VP, VP, I, F, I, U64, I, PI32, PF]),
     "wh_decode_text": (I, [VP, I, POPT, PST, PI32, I, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
+    "wh_decode_text_languages": (I, [VP, I, POPT, PST, PI32, I, PI32, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
     "wh_detect_language": (I, [VP, I, PST, PI32, PF]),
+    "wh_get_mel_device": (I, [VP, I, PVP]),
+    "wh_get_encoder_output_device": (I, [VP, I, PVP, PVP]),
+    "wh_get_logits_device": (I, [VP, PVP]),
+    "wh_session_set_cancel_flag": (I, [VP, VP]),
     "wh_prefill_prompt": (I, [VP, POPT, PST, C.c_int32, PI32, I]),
     "wh_transcribe": (I, [VP, VP, I, POPT, PST, PVP]),
     "wh_transcribe_batch": (I, [VP, PVP, PI32, I, POPT, PST, PVP]),

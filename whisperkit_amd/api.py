@@ -319,11 +319,11 @@ class Tokenizer:
 class Model:
     """The three loaded model stages (weights on one GPU)."""
 
-    def __init__(self, dims: WhisperDims, state_dict=None, device: int = 0, blob: Optional[bytes] = None):
+    def __init__(self, dims: WhisperDims, state_dict=None, device: int = 0, blob: Optional[bytes] = None, alignment_heads=None):
         self.lib = L.load()
         self.dims = dims
         if blob is None:
-            blob = pack_blob(dims, state_dict)
+            blob = pack_blob(dims, state_dict, alignment_heads=alignment_heads)
         self.handle = C.c_void_p()
         arr = np.frombuffer(blob, dtype=np.uint8)      # zero-copy view of bytes / bytearray / uint8 ndarray
         _check(self.lib.wh_model_create(C.c_void_p(arr.ctypes.data), arr.nbytes, device, C.byref(self.handle)))
@@ -337,10 +337,7 @@ class Model:
         WhisperKit.loadModels on the CoreML bundles (Core/WhisperKit.swift:358-442)."""
         from .checkpoint import load_checkpoint
         dims, sd, heads = load_checkpoint(src)
-        m = cls(dims, sd, device=device)
-        if heads:
-            m.setAlignmentHeads(heads)
-        return m
+        return cls(dims, sd, device=device, alignment_heads=heads)      # the heads travel inside the blob (dec.alignment_heads)
 
     @classmethod
     def synthetic(cls, name: str, seed: int = 0, device: int = 0, **kw):
@@ -498,16 +495,49 @@ class Session:
         return list(buf[:n])
 
     def decodeText(self, prompt: Sequence[int], options: DecodingOptions, batch: int = 1, temperatures: Optional[Sequence[float]] = None,
-                   active: Optional[Sequence[int]] = None, seed: int = 0, specialTokens=None) -> List[DecodingResult]:
+                   active: Optional[Sequence[int]] = None, seed: int = 0, specialTokens=None,
+                   languageTokens: Optional[Sequence[int]] = None) -> List[DecodingResult]:
+        """TextDecoding.decodeText for slots [0, batch).  `languageTokens[b]` (>= 0) replaces the language token of the shared
+        prompt for slot b (wh_decode_text_languages): batched windows of audios in different languages."""
         st = specialTokens if specialTokens is not None else self.model.specialTokens
         o = options.to_c()
         p = np.ascontiguousarray(list(prompt), dtype=np.int32)
         temps = np.ascontiguousarray(temperatures if temperatures is not None else [options.temperature] * batch, dtype=np.float32)
         act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
         res = (L.WhDecodingResult * batch)()
-        _check(self.lib.wh_decode_text(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
-                                       temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+        if languageTokens is None:
+            _check(self.lib.wh_decode_text(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                                           temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+        else:
+            lt = np.ascontiguousarray(languageTokens, dtype=np.int32)
+            assert len(lt) == batch
+            _check(self.lib.wh_decode_text_languages(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                                                     lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF),
+                                                     None if act is None else act.ctypes.data_as(L.PI32), seed, res))
         return [DecodingResult.from_c(r) for r in res]
+
+    def setCancelFlag(self, flag: Optional["C.c_int32"]):
+        """Task.checkCancellation: a ctypes.c_int32 polled by the running call (non-zero -> WhisperError code 102); None removes it.
+        The object is kept alive by the session."""
+        self._cancel = flag
+        _check(self.lib.wh_session_set_cancel_flag(self.handle, None if flag is None else C.addressof(flag)))
+
+    def getMelDevice(self, slot: int = 0) -> int:
+        """device pointer of slot's log-mel [n_mels][3000] f32 (stays in HBM; valid until the next logMelSpectrogram)"""
+        p = C.c_void_p()
+        _check(self.lib.wh_get_mel_device(self.handle, slot, C.byref(p)))
+        return p.value
+
+    def getEncoderOutputDevice(self, slot: int = 0) -> Tuple[int, int]:
+        """device pointers (f32, f16) of slot's encoder output [1500][d]"""
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(self.lib.wh_get_encoder_output_device(self.handle, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def getLogitsDevice(self) -> int:
+        p = C.c_void_p()
+        _check(self.lib.wh_get_logits_device(self.handle, C.byref(p)))
+        return p.value
 
     def detectLanguage(self, batch: int = 1, specialTokens=None):
         st = specialTokens if specialTokens is not None else self.model.specialTokens

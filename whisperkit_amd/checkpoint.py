@@ -118,9 +118,10 @@ def load_checkpoint(src: str):
 
 
 def convert(src: str, out_path: str) -> Tuple[WhisperDims, Optional[List[Tuple[int, int]]]]:
-    """Write the WHIPW001 blob of checkpoint `src` to `out_path` (+ `<out>.alignment_heads.json` when the checkpoint names any)."""
+    """Write the WHIPW001 blob of checkpoint `src` to `out_path`; the checkpoint's alignment heads are stored inside the blob
+    (`dec.alignment_heads`, read by wh_model_load) and, for inspection, in `<out>.alignment_heads.json`."""
     dims, sd, heads = load_checkpoint(src)
-    blob = pack_blob(dims, sd)
+    blob = pack_blob(dims, sd, alignment_heads=heads)
     np.asarray(blob, dtype=np.uint8).tofile(out_path)
     if heads:
         with open(out_path + ".alignment_heads.json", "w", encoding="utf-8") as f:

@@ -112,43 +112,48 @@ struct BlobEntry {
 };
 #pragma pack(pop)
 
+// `count` = elements the kernels will read from this tensor (dims-derived): a blob whose table disagrees is rejected here
+// instead of driving out-of-bounds device reads later.
 template <typename T>
-static int get_tensor(wh_model* m, const std::string& name, const T** out, int dtype) {
+static int get_tensor(wh_model* m, const std::string& name, const T** out, int dtype, size_t count) {
     auto it = m->t.find(name);
     if (it == m->t.end()) return set_error(WH_ERR_MODELS_UNAVAILABLE, "weight blob has no tensor '%s'", name.c_str());
     if (it->second.dtype != dtype) return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor '%s' has dtype %d, expected %d", name.c_str(), it->second.dtype, dtype);
+    if (it->second.nbytes != count * sizeof(T))
+        return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor '%s' has %zu bytes, the model dimensions need %zu", name.c_str(), it->second.nbytes, count * sizeof(T));
     *out = (const T*)it->second.dev;
     return WH_OK;
 }
-#define GET16(name, field) do { int _r = get_tensor<f16>(m, name, &(field), 0); if (_r) return _r; } while (0)
-#define GET32(name, field) do { int _r = get_tensor<float>(m, name, &(field), 1); if (_r) return _r; } while (0)
+#define GET16(name, field, count) do { int _r = get_tensor<f16>(m, name, &(field), 0, (size_t)(count)); if (_r) return _r; } while (0)
+#define GET32(name, field, count) do { int _r = get_tensor<float>(m, name, &(field), 1, (size_t)(count)); if (_r) return _r; } while (0)
 
 static int bind_weights(wh_model* m) {
     const wh_dims& D = m->dims;
-    GET16("enc.conv1.w", m->conv1_w); GET32("enc.conv1.b", m->conv1_b);
-    GET16("enc.conv2.w", m->conv2_w); GET32("enc.conv2.b", m->conv2_b);
-    GET32("enc.pos", m->enc_pos); GET32("enc.lnp.g", m->lnp_g); GET32("enc.lnp.b", m->lnp_b);
+    const size_t d = D.n_audio_state, nm = D.n_mels, V = D.n_vocab, L = D.n_text_layer;
+    GET16("enc.conv1.w", m->conv1_w, d * 3 * nm); GET32("enc.conv1.b", m->conv1_b, d);
+    GET16("enc.conv2.w", m->conv2_w, d * 3 * d); GET32("enc.conv2.b", m->conv2_b, d);
+    GET32("enc.pos", m->enc_pos, (size_t)kCtx * d); GET32("enc.lnp.g", m->lnp_g, d); GET32("enc.lnp.b", m->lnp_b, d);
     m->enc.resize(D.n_audio_layer);
     for (int i = 0; i < D.n_audio_layer; ++i) {
         std::string p = "enc." + std::to_string(i);
         EncLayerW& w = m->enc[i];
-        GET32(p + ".ln1.g", w.ln1_g); GET32(p + ".ln1.b", w.ln1_b); GET16(p + ".qkv.w", w.qkv_w); GET32(p + ".qkv.b", w.qkv_b);
-        GET16(p + ".o.w", w.o_w); GET32(p + ".o.b", w.o_b); GET32(p + ".ln2.g", w.ln2_g); GET32(p + ".ln2.b", w.ln2_b);
-        GET16(p + ".fc1.w", w.fc1_w); GET32(p + ".fc1.b", w.fc1_b); GET16(p + ".fc2.w", w.fc2_w); GET32(p + ".fc2.b", w.fc2_b);
+        GET32(p + ".ln1.g", w.ln1_g, d); GET32(p + ".ln1.b", w.ln1_b, d); GET16(p + ".qkv.w", w.qkv_w, 3 * d * d); GET32(p + ".qkv.b", w.qkv_b, 3 * d);
+        GET16(p + ".o.w", w.o_w, d * d); GET32(p + ".o.b", w.o_b, d); GET32(p + ".ln2.g", w.ln2_g, d); GET32(p + ".ln2.b", w.ln2_b, d);
+        GET16(p + ".fc1.w", w.fc1_w, 4 * d * d); GET32(p + ".fc1.b", w.fc1_b, 4 * d); GET16(p + ".fc2.w", w.fc2_w, 4 * d * d); GET32(p + ".fc2.b", w.fc2_b, d);
     }
-    GET16("dec.emb", m->emb); GET32("dec.pos", m->dec_pos); GET16("dec.ckv.w", m->ckv_w); GET32("dec.ckv.b", m->ckv_b);
-    GET32("dec.ln.g", m->lnf_g); GET32("dec.ln.b", m->lnf_b);
+    GET16("dec.emb", m->emb, V * d); GET32("dec.pos", m->dec_pos, (size_t)D.n_text_ctx * d); GET16("dec.ckv.w", m->ckv_w, L * 2 * d * d); GET32("dec.ckv.b", m->ckv_b, L * 2 * d);
+    GET32("dec.ln.g", m->lnf_g, d); GET32("dec.ln.b", m->lnf_b, d);
     m->dec.resize(D.n_text_layer);
     for (int i = 0; i < D.n_text_layer; ++i) {
         std::string p = "dec." + std::to_string(i);
         DecLayerW& w = m->dec[i];
-        GET32(p + ".ln1.g", w.ln1_g); GET32(p + ".ln1.b", w.ln1_b); GET16(p + ".qkv.w", w.qkv_w); GET32(p + ".qkv.b", w.qkv_b);
-        GET16(p + ".o.w", w.o_w); GET32(p + ".o.b", w.o_b);
-        GET32(p + ".ln2.g", w.ln2_g); GET32(p + ".ln2.b", w.ln2_b); GET16(p + ".cq.w", w.cq_w); GET32(p + ".cq.b", w.cq_b);
-        GET16(p + ".co.w", w.co_w); GET32(p + ".co.b", w.co_b);
-        GET16(p + ".cqf.w", w.cqf_w); GET32(p + ".cqf.c0", w.cqf_c0); GET32(p + ".cqf.r", w.cqf_r); GET32(p + ".cqf.c", w.cqf_c);
-        GET32(p + ".ln3.g", w.ln3_g); GET32(p + ".ln3.b", w.ln3_b);
-        GET16(p + ".fc1.w", w.fc1_w); GET32(p + ".fc1.b", w.fc1_b); GET16(p + ".fc2.w", w.fc2_w); GET32(p + ".fc2.b", w.fc2_b);
+        GET32(p + ".ln1.g", w.ln1_g, d); GET32(p + ".ln1.b", w.ln1_b, d); GET16(p + ".qkv.w", w.qkv_w, 3 * d * d); GET32(p + ".qkv.b", w.qkv_b, 3 * d);
+        GET16(p + ".o.w", w.o_w, d * d); GET32(p + ".o.b", w.o_b, d);
+        GET32(p + ".ln2.g", w.ln2_g, d); GET32(p + ".ln2.b", w.ln2_b, d); GET16(p + ".cq.w", w.cq_w, d * d); GET32(p + ".cq.b", w.cq_b, d);
+        GET16(p + ".co.w", w.co_w, d * d); GET32(p + ".co.b", w.co_b, d);
+        GET16(p + ".cqf.w", w.cqf_w, 4 * d * d); GET32(p + ".cqf.c0", w.cqf_c0, d); GET32(p + ".cqf.r", w.cqf_r, d); GET32(p + ".cqf.c", w.cqf_c, d);
+        GET32(p + ".ln3.g", w.ln3_g, d); GET32(p + ".ln3.b", w.ln3_b, d);
+        GET16(p + ".fc1.w", w.fc1_w, 4 * d * d); GET32(p + ".fc1.b", w.fc1_b, 4 * d); GET16(p + ".fc2.w", w.fc2_w, 4 * d * d); GET32(p + ".fc2.b", w.fc2_b, d);
     }
     return WH_OK;
 }
@@ -216,7 +221,14 @@ static int set_alignment_heads(wh_model* m, const int32_t* pairs, int n) {
     return WH_OK;
 }
 
+static int model_create_impl(const void* blob, size_t nbytes, int device, wh_model** out);
+// C entry points never let a C++ exception (bad_alloc from a hostile header, ...) cross the ABI
 extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_model** out) {
+    try { return model_create_impl(blob, nbytes, device, out); }
+    catch (const std::exception& e) { return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_model_create: %s", e.what()); }
+    catch (...) { return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_model_create: unknown exception"); }
+}
+static int model_create_impl(const void* blob, size_t nbytes, int device, wh_model** out) {
     if (!blob || !out || nbytes < 56) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_model_create: null or truncated blob");
     const unsigned char* p = (const unsigned char*)blob;
     if (memcmp(p, "WHIPW001", 8) != 0) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_model_create: bad magic (expected WHIPW001)");
@@ -231,8 +243,11 @@ extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_m
     int32_t n_tensors;
     memcpy(&n_tensors, p + 48, 4);
     const wh_dims& D = m->dims;
-    if (D.n_audio_ctx != kCtx || D.n_audio_state % 64 || D.n_audio_state / D.n_audio_head != 64 || D.n_text_state / D.n_text_head != 64 ||
-        D.n_audio_state != D.n_text_state || D.n_audio_state > 1280 || (D.n_mels != 80 && D.n_mels != 128) || n_tensors <= 0 ||
+    if (D.n_audio_ctx != kCtx || D.n_audio_state < 64 || D.n_audio_state % 64 || D.n_audio_head < 1 || D.n_text_head < 1 ||
+        D.n_audio_state / D.n_audio_head != 64 || D.n_audio_state % D.n_audio_head || D.n_text_state / D.n_text_head != 64 || D.n_text_state % D.n_text_head ||
+        D.n_audio_state != D.n_text_state || D.n_audio_state > 1280 || (D.n_mels != 80 && D.n_mels != 128) ||
+        D.n_audio_layer < 1 || D.n_audio_layer > 64 || D.n_text_layer < 1 || D.n_text_layer > 64 || D.n_vocab < 51864 || D.n_vocab > 65536 ||
+        D.n_text_ctx < kMaxTok || D.n_text_ctx > 4096 || n_tensors <= 0 || n_tensors > 65536 ||
         56 + (size_t)n_tensors * sizeof(BlobEntry) > nbytes) {
         delete m;
         return set_error(WH_ERR_MODELS_UNAVAILABLE, "unsupported model dimensions in blob header");
@@ -245,7 +260,10 @@ extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_m
     for (int i = 0; i < n_tensors; ++i) {
         BlobEntry en;
         memcpy(&en, p + 56 + (size_t)i * sizeof(BlobEntry), sizeof(BlobEntry));
-        if (en.offset < 0 || (size_t)(en.offset + en.nbytes) > nbytes) { wh_model_destroy(m); return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor %d out of blob bounds", i); }
+        if (en.offset < 0 || en.nbytes < 0 || (size_t)en.offset > nbytes || (size_t)en.nbytes > nbytes - (size_t)en.offset) {
+            wh_model_destroy(m);
+            return set_error(WH_ERR_MODELS_UNAVAILABLE, "tensor %d out of blob bounds", i);
+        }
         WhTensor t;
         t.dev = (char*)m->blob_dev + en.offset;
         t.dtype = en.dtype; t.ndim = en.ndim; t.nbytes = (size_t)en.nbytes;
@@ -257,9 +275,15 @@ extern "C" int wh_model_create(const void* blob, size_t nbytes, int device, wh_m
     if (!r) r = build_mel_tables(m);
     if (!r && dec32_enabled()) r = build_dec32(m);
     if (!r) {
-        std::vector<int32_t> pairs;   // default: every head of the upper half of the decoder (openai/whisper model.py)
-        for (int l = D.n_text_layer / 2; l < D.n_text_layer; ++l)
-            for (int h = 0; h < D.n_text_head; ++h) { pairs.push_back(l); pairs.push_back(h); }
+        std::vector<int32_t> pairs;
+        auto ah = m->t.find("dec.alignment_heads");      // optional int32 [n][2] written by checkpoint conversion (generation_config.alignment_heads)
+        if (ah != m->t.end() && ah->second.dtype == 2 && ah->second.nbytes % 8 == 0 && ah->second.nbytes > 0) {
+            pairs.resize(ah->second.nbytes / 4);
+            if (hipMemcpy(pairs.data(), ah->second.dev, ah->second.nbytes, hipMemcpyDeviceToHost) != hipSuccess) pairs.clear();
+        }
+        if (pairs.empty())            // default: every head of the upper half of the decoder (openai/whisper model.py)
+            for (int l = D.n_text_layer / 2; l < D.n_text_layer; ++l)
+                for (int h = 0; h < D.n_text_head; ++h) { pairs.push_back(l); pairs.push_back(h); }
         r = set_alignment_heads(m, pairs.data(), (int)pairs.size() / 2);
     }
     if (r) { wh_model_destroy(m); return r; }
@@ -271,14 +295,19 @@ extern "C" int wh_model_load(const char* path, int device, wh_model** out) {
     if (!path) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_model_load: null path");
     FILE* f = fopen(path, "rb");
     if (!f) return set_error(WH_ERR_MODELS_UNAVAILABLE, "cannot open model file '%s'", path);
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<unsigned char> buf((size_t)n);
-    size_t got = fread(buf.data(), 1, (size_t)n, f);
-    fclose(f);
-    if (got != (size_t)n) return set_error(WH_ERR_MODELS_UNAVAILABLE, "short read on '%s'", path);
-    return wh_model_create(buf.data(), buf.size(), device, out);
+    long n = -1;
+    if (fseek(f, 0, SEEK_END) == 0) n = ftell(f);
+    if (n < 56 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return set_error(WH_ERR_MODELS_UNAVAILABLE, "cannot size model file '%s'", path); }
+    try {
+        std::vector<unsigned char> buf((size_t)n);
+        size_t got = fread(buf.data(), 1, (size_t)n, f);
+        fclose(f);
+        if (got != (size_t)n) return set_error(WH_ERR_MODELS_UNAVAILABLE, "short read on '%s'", path);
+        return wh_model_create(buf.data(), buf.size(), device, out);
+    } catch (const std::exception& e) {
+        fclose(f);
+        return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_model_load('%s'): %s", path, e.what());
+    }
 }
 
 extern "C" void wh_model_destroy(wh_model* m) {
@@ -541,26 +570,47 @@ DecodeBuffers decode_buffers(wh_session* s, int batch) {
     db.hbuf = s->hbuf; db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
     { static const bool off = [] { const char* e = getenv("WH_NO_FUSED_CQ"); return e && e[0] == '1'; }(); db.fused_cq = off ? 0 : 1; }
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
-    db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = m->n_align;
+    db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = s->n_align_alloc;
     db.d32 = s->use32 ? &s->d32 : nullptr;
     return db;
 }
 }  // namespace whi
 
-static int ensure_align(wh_session* s) {
+namespace whi {
+int ensure_align(wh_session* s) {
+    // The raw score buffer is sized for the model's alignment-head count at allocation time; wh_model_set_alignment_heads may
+    // have changed it since (the captured step graphs bake the row stride in: they are keyed by n_align and dropped here).
+    if (s->align && s->n_align_alloc != s->m->n_align) {
+        WH_HIP(hipStreamSynchronize(s->st));
+        drop_session_graphs(s);
+        hipFree(s->align);
+        s->align = nullptr;
+    }
     if (!s->align && s->m->n_align > 0) {
         size_t n = (size_t)s->B * kMaxTok * s->m->n_align * kCtx;
         WH_HIP(hipMalloc((void**)&s->align, n * sizeof(float)));
         WH_HIP(hipMemsetAsync(s->align, 0, n * sizeof(float), s->st));
+        s->n_align_alloc = s->m->n_align;
     }
     return WH_OK;
 }
 
+int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active) {
+    // DecodingInputs.reset for the slots that decode again (temperature fallback): an accepted slot keeps its alignment rows
+    // until the window's word timestamps have been read (TranscribeTask.swift:374-398 resets only the task's own inputs)
+    for (int b = 0; b < batch; ++b) {
+        if (active && !active[b]) continue;
+        WH_HIP(hipMemsetAsync(s->seq + b, 0, sizeof(SeqState), s->st));
+        if (s->align) WH_HIP(hipMemsetAsync(s->align + (size_t)b * kMaxTok * s->n_align_alloc * kCtx, 0, (size_t)kMaxTok * s->n_align_alloc * kCtx * sizeof(float), s->st));
+    }
+    return WH_OK;
+}
+}  // namespace whi
+using whi::ensure_align;
+
 extern "C" int wh_reset_decoder_inputs(wh_session* s, int batch) {
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
-    WH_HIP(hipMemsetAsync(s->seq, 0, sizeof(SeqState) * batch, s->st));
-    if (s->align) WH_HIP(hipMemsetAsync(s->align, 0, (size_t)batch * kMaxTok * s->m->n_align * kCtx * sizeof(float), s->st));
-    return WH_OK;
+    return whi::reset_decoder_inputs_masked(s, batch, nullptr);
 }
 
 extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
@@ -604,11 +654,37 @@ extern "C" int wh_get_alignment_weights(wh_session* s, int b, float* out) {
     CHECK_SESSION(s); CHECK_SLOT(s, b);
     if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_alignment_weights: null output");
     if (!s->align) return set_error(WH_ERR_SEGMENTING_FAILED, "no alignment weights recorded (run a decode with word timestamps / the step API first)");
-    launch_alignment_mean(s->align, s->B, s->m->n_align, s->align_mean, s->st);
-    WH_CHECK_LAUNCH();
     size_t n = (size_t)kMaxTok * kCtx;
+    launch_alignment_mean(s->align + (size_t)b * n * s->n_align_alloc, 1, s->n_align_alloc, s->align_mean + b * n, s->st);   // this slot only
+    WH_CHECK_LAUNCH();
     WH_HIP(hipMemcpyAsync(out, s->align_mean + b * n, n * 4, hipMemcpyDeviceToHost, s->st));
     WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
+}
+
+// ---- device-resident hand-off (outputs may stay in HBM) -------------------------
+extern "C" int wh_get_mel_device(wh_session* s, int b, const float** mel_dev) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    if (!mel_dev) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_mel_device: null output");
+    *mel_dev = s->mel_f32 + (size_t)b * s->m->dims.n_mels * kFrames;
+    return WH_OK;
+}
+extern "C" int wh_get_encoder_output_device(wh_session* s, int b, const float** enc_f32_dev, const void** enc_f16_dev) {
+    CHECK_SESSION(s); CHECK_SLOT(s, b);
+    const size_t n = (size_t)kCtx * s->m->dims.n_audio_state;
+    if (enc_f32_dev) *enc_f32_dev = s->enc32 + b * n;
+    if (enc_f16_dev) *enc_f16_dev = s->enc16 + b * n;
+    return WH_OK;
+}
+extern "C" int wh_get_logits_device(wh_session* s, const float** logits_dev) {
+    CHECK_SESSION(s);
+    if (!logits_dev) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_logits_device: null output");
+    *logits_dev = s->logits;
+    return WH_OK;
+}
+extern "C" int wh_session_set_cancel_flag(wh_session* s, const volatile int32_t* flag) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_cancel_flag: null session");
+    s->cancel_flag = flag;
     return WH_OK;
 }
 

@@ -556,6 +556,7 @@ struct AttnArgs {
     SeqState* seq;
     // folded cross query (xq != null): a.q holds u; q = (u - mean(x') r) * rstd(x') + c is finished here, x' = xq [B][d]
     const float* xq; const float* qr; const float* qc;
+    int no_fence;
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
 #define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
@@ -759,8 +760,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         if (last) {
             // agent-scope acquire on the combining CU: the partial slots are rewritten by every layer's launch, and a copy
             // left in this XCD's L2 by an earlier combine must not be served to the sc1 loads below (the recipe of
-            // MI355X_MICROARCH.md: one relaxed ticket, one agent acquire; it is not measurable in the step time)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // MI355X_MICROARCH.md: one relaxed ticket, one agent acquire).  WH_XATT_NOFENCE=1 drops it (A/B knob).
+            if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         }
         last_flag = last;
@@ -1116,7 +1117,7 @@ void launch_rules_init(const SamplerCfg* cfg_dev, SeqState* seq, int batch, hipS
 // ---------------------------------------------------------------------------------------------- launchers
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static unsigned long long* g_dbg_buf = nullptr;   // [KK_COUNT][4096][8]
-static int g_dbg_kind = 0;
+static thread_local int g_dbg_kind = 0;
 unsigned long long* debug_buffer() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("WH_DBG"); on = (e && e[0] == '1'); if (on) { (void)hipMalloc((void**)&g_dbg_buf, (size_t)KK_COUNT * 4096 * 8 * 8); (void)hipMemset(g_dbg_buf, 0, (size_t)KK_COUNT * 4096 * 8 * 8); } }
@@ -1131,11 +1132,8 @@ static void launch_gemv_r(GemvArgs a, int passes, hipStream_t st) {
     const bool ln_mode = MODE == MODE_QKV || MODE == MODE_Q || MODE == MODE_FC1 || MODE == MODE_LOGITS;
     const size_t smem = (MODE == MODE_FC2) ? 0 : (size_t)(BT * a.K + (ln_mode ? 2 * a.d : 0)) * sizeof(float);
     if (smem > 64 * 1024) {   // above the default dynamic-LDS limit: raise it once per instantiation (160 KB per CU on gfx950)
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv_kernel<MODE, BT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // + static LDS <= 160 KB
-            raised = true;
-        }
+        static PerDeviceOnce raised;
+        raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv_kernel<MODE, BT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });   // + static LDS <= 160 KB
     }
     dec_gemv_kernel<MODE, BT, R><<<g, 256, smem, st>>>(a);
 }
@@ -1193,7 +1191,10 @@ int cross_attn_splits(int batch, int n_head) {
     return (kCtx + passes * 32 - 1) / (passes * 32);
 }
 
-static void launch_cross_attn(const AttnArgs& at, int S, int H, int B, hipStream_t st) {
+static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStream_t st) {
+    static const int nofence = env_int("WH_XATT_NOFENCE", 0);
+    AttnArgs at = at_in;
+    at.no_fence = nofence;
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
     const dim3 grid(S, H, B);
     static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
@@ -1383,6 +1384,7 @@ __global__ __launch_bounds__(256) void alignment_mean_kernel(const float* __rest
     for (int t = threadIdx.x; t < kCtx; t += 256) out[row * kCtx + t] = ((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) * invn;
 }
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st) {
+    // `align` / `out` point at the first of `batch` consecutive slots
     alignment_mean_kernel<<<batch * kMaxTok, 256, 0, st>>>(align, n_align, out);
 }
 

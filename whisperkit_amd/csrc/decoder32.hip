@@ -224,22 +224,23 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
 
-    // ---- K split across workgroups: publish, ticket, the last arriver sums the slices in index order
+    // ---- K split across workgroups: publish, ticket, the last arriver sums the slices in index order.  Write-through (sc1)
+    // 16-byte stores, a drained vmcnt in every storing wave, one relaxed ticket; the finisher reads the slabs with sc1 loads, which
+    // bypass its L1 and are served by L2 - no agent-scope fence on either side (MI355X_MICROARCH.md "handoff-flag", R1).
     if (a.ks > 1) {
         float* base = a.part + (((size_t)bt * n_rt + rt) * a.ks) * 1024 + tid * 4;
-        float* mine = base + (size_t)ksi * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) __hip_atomic_store(mine + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
+        {
+            const f32x4 pv4 = {v[0], v[1], v[2], v[3]};
+            float* mine = base + (size_t)ksi * 1024;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             int* cnt = a.ticket + bt * n_rt + rt;
             const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == a.ks - 1);
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
-            }
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
             last_flag = last;
         }
         __syncthreads();
@@ -374,12 +375,16 @@ static int env_int32(const char* name, int dflt) { const char* e = getenv(name);
 // K splits across workgroups: only the N = d projections need them (40 row tiles at d = 1280 would leave 5/6 of the chip idle);
 // the split must divide the K / 64 tile groups.  WH_D32_KS_* override (tuning).
 int dec32_ksplit(int mode, int N, int K, bool f16_input) {
-    static const int ks_resid = env_int32("WH_D32_KS_RESID", 4), ks_fc2 = env_int32("WH_D32_KS_FC2", 4), ks_q = env_int32("WH_D32_KS_Q", 4),
-                     ks_wide = env_int32("WH_D32_KS_WIDE", 1);
+    static const int ks_resid = env_int32("WH_D32_KS_RESID", 0), ks_fc2 = env_int32("WH_D32_KS_FC2", 0), ks_q = env_int32("WH_D32_KS_Q", 0),
+                     ks_wide = env_int32("WH_D32_KS_WIDE", 1), tile_kb = env_int32("WH_D32_TILE_KB", 96);
     int want = (mode == P32_RESID) ? (f16_input ? ks_fc2 : ks_resid) : (mode == P32_Q ? ks_q : ks_wide);
+    // default for the N = d projections: as many K slices as keep a workgroup's weight slab at <= tile_kb KB (a 32-row tile of K
+    // columns is K / 16 KB): d = 384 -> 1 (no ticket at all), d = 1280 -> 1 for K = d, 4 for fc2's K = 4d
+    if (want <= 0) want = (K / 16 + tile_kb - 1) / tile_kb;
     const int groups = K / 64;
     want = max(1, min(want, 8));
     while (want > 1 && groups % want) --want;
+    if ((long long)((N + 31) / 32) * want * 1024 > kD32PartFloats) want = 1;
     return want;
 }
 

@@ -351,11 +351,8 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
     if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            raised = true;
-        }
+        static PerDeviceOnce raised;
+        raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
         gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(a);
         return;
     }

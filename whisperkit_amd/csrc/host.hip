@@ -259,28 +259,16 @@ void finalize_decoding_result(const SeqState& sq, const wh_decoding_options* opt
 
 constexpr int kStepsPerGraph = 8;
 
-struct GraphKey {
-    int batch, align, fused;
-    bool operator<(const GraphKey& o) const { return std::tie(batch, align, fused) < std::tie(o.batch, o.align, o.fused); }
-};
-struct SessionGraphs { std::map<GraphKey, hipGraphExec_t> g; };
-static std::map<wh_session*, SessionGraphs>& graph_cache() { static std::map<wh_session*, SessionGraphs> c; return c; }
-static std::mutex g_graph_mu;   // sessions of one model decode concurrently from different host threads
-
 static bool use_graphs() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WH_NO_GRAPH"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
+    static const bool v = [] { const char* e = getenv("WH_NO_GRAPH"); return !(e && e[0] == '1'); }();
+    return v;
 }
 
+// Step graphs live in the session (a session is driven by one host thread at a time): no process-wide cache, no lock.
 static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
-    GraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0};
-    {
-        std::lock_guard<std::mutex> lk(g_graph_mu);
-        auto& cache = graph_cache()[s].g;
-        auto it = cache.find(key);
-        if (it != cache.end()) { *out = it->second; return WH_OK; }
-    }
+    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0};
+    auto it = s->graphs.find(key);
+    if (it != s->graphs.end()) { *out = it->second; return WH_OK; }
     DecodeBuffers db = whi::decode_buffers(s, batch);
     hipGraph_t graph;
     WH_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
@@ -289,23 +277,20 @@ static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
     hipGraphExec_t exec;
     WH_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
-    {
-        std::lock_guard<std::mutex> lk(g_graph_mu);
-        graph_cache()[s].g[key] = exec;
-    }
+    s->graphs[key] = exec;
     *out = exec;
     return WH_OK;
 }
 
 namespace whi {
 void drop_session_graphs(wh_session* s) {
-    std::lock_guard<std::mutex> lk(g_graph_mu);
-    auto it = graph_cache().find(s);
-    if (it == graph_cache().end()) return;
-    for (auto& kv : it->second.g) hipGraphExecDestroy(kv.second);
-    graph_cache().erase(it);
+    for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
+    s->graphs.clear();
 }
 }
+
+static inline bool cancelled(const wh_session* s) { return s->cancel_flag && *s->cancel_flag != 0; }
+#define CHECK_CANCEL(s) do { if (cancelled(s)) return set_error(WH_ERR_CANCELLED, "%s: cancelled through the session's cancel flag", __func__); } while (0)
 
 // TranscriptionCallback on a consistent snapshot of the slot states (the stream is idle): one call per unfinished slot; a zero
 // return marks the slot done on the device (stream-ordered, before the next step graph) - earlyStopActor semantics.
@@ -345,6 +330,7 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
         DecodeBuffers db = whi::decode_buffers(s, batch);
         if (use_graphs()) { int r = get_step_graph(s, batch, &exec); if (r) return r; }
         for (int step = 0; step < loop_count; step += kStepsPerGraph) {
+            CHECK_CANCEL(s);
             if (exec) WH_HIP(hipGraphLaunch(exec, s->st));
             else for (int i = 0; i < kStepsPerGraph && step + i < loop_count; ++i) { launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st); WH_CHECK_LAUNCH(); }
             WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
@@ -364,6 +350,7 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
         if (r) return r;
         const int n_graphs = (loop_count + kStepsPerGraph - 1) / kStepsPerGraph;
         for (int g = 0; g < n_graphs; ++g) {
+            if (cancelled(s)) { hipStreamSynchronize(s->st); return set_error(WH_ERR_CANCELLED, "decodeText: cancelled through the session's cancel flag"); }
             WH_HIP(hipGraphLaunch(exec, s->st));
             // snapshot the slot states behind graph g; while it runs, look at the snapshot behind graph g-1
             // (at most one graph of run-ahead; `done` is monotonic, so a torn snapshot is harmless)
@@ -391,8 +378,21 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
     return WH_OK;
 }
 
+static int decode_text_impl(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                            int n_prompt, const int32_t* language_tokens, const float* temperatures, const int32_t* active, uint64_t seed,
+                            wh_decoding_result* out);
 extern "C" int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
                               int n_prompt, const float* temperatures, const int32_t* active, uint64_t seed, wh_decoding_result* out) {
+    return decode_text_impl(s, batch, opt, st, prompt, n_prompt, nullptr, temperatures, active, seed, out);
+}
+extern "C" int wh_decode_text_languages(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                                        int n_prompt, const int32_t* language_tokens, const float* temperatures, const int32_t* active, uint64_t seed,
+                                        wh_decoding_result* out) {
+    return decode_text_impl(s, batch, opt, st, prompt, n_prompt, language_tokens, temperatures, active, seed, out);
+}
+static int decode_text_impl(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                            int n_prompt, const int32_t* language_tokens, const float* temperatures, const int32_t* active, uint64_t seed,
+                            wh_decoding_result* out) {
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
     if (!opt || !st || !prompt || !out) return set_error(WH_ERR_DECODING_FAILED, "wh_decode_text: null argument");
     if (n_prompt < 1 || n_prompt >= kMaxTok) return set_error(WH_ERR_PREFILL_FAILED, "wh_decode_text: prompt length %d out of range [1,%d)", n_prompt, kMaxTok);
@@ -402,17 +402,19 @@ extern "C" int wh_decode_text(wh_session* s, int batch, const wh_decoding_option
     const int prefilled_index = 0;   // decoderInputs.cacheLength after reset (Core/Models.swift:313)
     int r = whi::upload_sampler_cfg(s, opt, st, prefilled_index, n_prompt, 0, seed);
     if (r) return r;
-    if (opt->word_timestamps && s->m->n_align > 0 && !s->align) {
-        size_t n = (size_t)s->B * kMaxTok * s->m->n_align * kCtx;
-        WH_HIP(hipMalloc((void**)&s->align, n * sizeof(float)));
-        WH_HIP(hipMemsetAsync(s->align, 0, n * sizeof(float), s->st));
-    }
+    if (opt->word_timestamps && s->m->n_align > 0) { r = whi::ensure_align(s); if (r) return r; }
     s->align_enabled = opt->word_timestamps && s->align;
+    // per-slot language token (batched windows of different audios, each with its own detected language): it replaces the
+    // token that follows <|startoftranscript|> in the shared prompt (prefillDecoderInputs, TextDecoder.swift:183-188)
+    int lang_pos = -1;
+    if (language_tokens && wh_is_model_multilingual(s->m))
+        for (int i = 0; i + 1 < n_prompt; ++i) if (prompt[i] == st->start_of_transcript_token) { lang_pos = i + 1; break; }
     for (int b = 0; b < batch; ++b) {
         SeqState& q = s->seq_host[b];
         memset(&q, 0, sizeof(q));
         for (int i = 0; i < n_prompt; ++i) q.tokens[i] = prompt[i];
-        q.n_tokens = n_prompt; q.token_index = prefilled_index; q.next_token = prompt[0]; q.prompt_len = n_prompt;
+        if (lang_pos >= 0 && language_tokens[b] >= 0 && language_tokens[b] < V) q.tokens[lang_pos] = language_tokens[b];
+        q.n_tokens = n_prompt; q.token_index = prefilled_index; q.next_token = q.tokens[0]; q.prompt_len = n_prompt;
         q.active = active ? (active[b] != 0) : 1;
         q.temperature = f16_round(temperatures ? temperatures[b] : opt->temperature);
     }
@@ -570,6 +572,7 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             if (!jobs[ji].finished && job_next_window(jobs[ji], opt)) slot_job.push_back((int)ji);
         if (slot_job.empty()) break;
         const int nb = (int)slot_job.size();
+        CHECK_CANCEL(s);
         double t0 = now_s();
         for (int b = 0; b < nb; ++b) {
             AudioJob& j = jobs[slot_job[b]];
@@ -591,24 +594,33 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
         std::vector<int32_t> prompt(kMaxPrompt);
         int n_prompt = 1;
         prompt[0] = st->start_of_transcript_token;
-        int lang_tok = opt->language_token;
+        // language token per slot: every audio of the batch detects (and is prompted with) its own language, like the reference's
+        // one TranscribeTask per audio (WhisperKit.swift:735-792); -1 = the options' language / English default of prefillDecoderInputs
+        std::vector<int32_t> lang_slot(nb, opt->language_token);
         for (size_t ti = 0; ti < temps.size(); ++ti) {
+            CHECK_CANCEL(s);
             std::vector<float> tv(nb, temps[ti]);
+            bool per_slot_lang = false;
             if (multilingual && opt->language_token < 0 && detect) {
-                // detectLanguage runs once per window on slot order; the prompt is shared by the lock-stepped slots, so the
-                // language of the first active slot is used for this round (single-audio calls: exact reference behaviour)
                 std::vector<int32_t> lt(nb); std::vector<float> ll(nb);
                 r = wh_detect_language(s, nb, st, lt.data(), ll.data()); if (r) return r;
-                for (int b = 0; b < nb; ++b) if (active[b]) { lang_tok = lt[b]; break; }
-                for (int b = 0; b < nb; ++b) { wh_transcription* t = jobs[slot_job[b]].tr; if (!t->language_set) { t->language_token = lt[b]; t->language_set = true; } }
+                for (int b = 0; b < nb; ++b) {
+                    if (!active[b]) continue;
+                    lang_slot[b] = lt[b];
+                    wh_transcription* t = jobs[slot_job[b]].tr;
+                    if (!t->language_set) { t->language_token = lt[b]; t->language_set = true; }
+                }
+                per_slot_lang = true;
             }
             if (opt->use_prefill_prompt) {
-                n_prompt = wh_prefill_prompt(m, opt, st, lang_tok, prompt.data(), (int)prompt.size());
+                n_prompt = wh_prefill_prompt(m, opt, st, opt->language_token, prompt.data(), (int)prompt.size());
                 if (n_prompt <= 0) return set_error(WH_ERR_PREFILL_FAILED, "prefill prompt does not fit");
             }
-            r = wh_reset_decoder_inputs(s, nb); if (r) return r;
+            r = whi::reset_decoder_inputs_masked(s, nb, active.data()); if (r) return r;     // accepted slots keep their alignment rows
             uint64_t seed = opt->seed + 1000003ull * (uint64_t)jobs[slot_job[0]].windows + ti;
-            r = wh_decode_text(s, nb, opt, st, prompt.data(), n_prompt, tv.data(), active.data(), seed, tmp.data()); if (r) return r;
+            r = decode_text_impl(s, nb, opt, st, prompt.data(), n_prompt, (per_slot_lang && opt->use_prefill_prompt) ? lang_slot.data() : nullptr,
+                                 tv.data(), active.data(), seed, tmp.data());
+            if (r) return r;
             bool any = false;
             for (int b = 0; b < nb; ++b) {
                 if (!active[b]) continue;
@@ -635,7 +647,7 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             }
             const double windows_before = tr->timings.total_decoding_windows;
             int32_t seek = j.seek;
-            r = wh_transcription_add_window(tr, s->tok, opt, st, &res[b], alignment, lang_tok, j.cur_size, &seek); if (r) return r;
+            r = wh_transcription_add_window(tr, s->tok, opt, st, &res[b], alignment, lang_slot[b], j.cur_size, &seek); if (r) return r;
             j.seek = seek;
             if (tr->timings.total_decoding_windows > windows_before) j.windows += 1;
             tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
@@ -758,8 +770,8 @@ extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const in
 // ------------------------------------------------------------------------------------------------ measurement hook
 static const char* kKindNames[KK_COUNT] = {
     "mel_power", "mel_finalize", "gemm_conv1", "gemm_conv2", "layernorm", "gemm_enc_qkv", "enc_attention", "gemm_enc_o", "gemm_enc_fc1",
-    "gemm_enc_fc2", "gemm_cross_kv", "dec_gemv_qkv", "dec_self_attn", "dec_gemv_oproj", "dec_gemv_cq", "dec_cross_attn", "dec_gemv_coproj",
-    "dec_gemv_fc1", "dec_gemv_fc2", "dec_gemv_logits", "sampler", "dec_embed"};
+    "gemm_enc_fc2", "gemm_cross_kv", "dec_proj_qkv", "dec_self_attn", "dec_proj_oproj", "dec_proj_cq", "dec_cross_attn", "dec_proj_coproj",
+    "dec_proj_fc1", "dec_proj_fc2", "dec_proj_logits", "sampler", "dec_embed"};
 namespace wh { unsigned long long* debug_buffer(); }
 extern "C" int wh_debug_dump(const char* path) {
     unsigned long long* b = wh::debug_buffer();

@@ -1,6 +1,8 @@
 // Internal model / session structures behind the opaque C-ABI handles.
 #pragma once
+#include <map>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -42,6 +44,12 @@ struct wh_model {
     int* align_slot_dev = nullptr;
 };
 
+// step graphs are keyed by everything their captured launches bake in
+struct WhGraphKey {
+    int batch, align, fused, n_align;
+    bool operator<(const WhGraphKey& o) const { return std::tie(batch, align, fused, n_align) < std::tie(o.batch, o.align, o.fused, o.n_align); }
+};
+
 struct wh_session {
     wh_model* m = nullptr;
     int B = 0;
@@ -57,6 +65,9 @@ struct wh_session {
     int* ticket = nullptr;
     f16* hbuf = nullptr;
     float *align = nullptr, *align_mean = nullptr;
+    int n_align_alloc = 0;                // alignment heads the `align` allocation was sized for
+    std::map<WhGraphKey, hipGraphExec_t> graphs;   // captured 8-step decode graphs of THIS session (no process-wide state)
+    const volatile int32_t* cancel_flag = nullptr; // polled between step graphs and pipeline stages (Task.checkCancellation)
     wh::Dec32 d32{};                      // MFMA decode path buffers (one allocation: d32_blob)
     void* d32_blob = nullptr;
     bool use32 = false;
@@ -90,6 +101,8 @@ int set_error(int code, const char* fmt, ...);
 
 wh::DecodeBuffers decode_buffers(wh_session* s, int batch);
 void drop_session_graphs(wh_session* s);
+int ensure_align(wh_session* s);          // (re)allocate the raw alignment-head score buffer for the model's current head set
+int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active);
 // host logic shared by wh_decode_text / wh_transcribe (host.hip)
 void finalize_decoding_result(const wh::SeqState& sq, const wh_decoding_options* opt, const wh_special_tokens* st,
                               float temperature, wh_decoding_result* out);

@@ -2,9 +2,28 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace wh {
+
+// Run `f` once per HIP device of the process (hipFuncSetAttribute is per device): sessions of different GPUs may be driven from
+// different host threads of one process.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    template <class F> void run(F f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------- measurement
 // Every kernel launch of the hot path is tagged with a kind; when a KernelProfiler is armed on the calling thread

@@ -177,8 +177,8 @@ void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, in
     hipMemsetAsync(maxkey, 0, sizeof(unsigned) * batch, st);
     dim3 g1((kFrames + 16 * FG - 1) / (16 * FG), batch);
     const size_t smem1 = (size_t)(2 * FG * 16 * LDA + 16 * LDP) * sizeof(float);   // 116.8 KB
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1); raised = true; }
+    static PerDeviceOnce raised;
+    raised.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1); });
     { ProfScope ps_(KK_MEL_POWER, st); mel_power_kernel<<<g1, 256, smem1, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt_c, t.filt_off, t.filt_nnz, t.filt_range, t.n_mels, logspec, maxkey); }
     dim3 g2((kFrames + 63) / 64, batch);
     { ProfScope ps_(KK_MEL_FINALIZE, st); mel_finalize_kernel<<<g2, 256, t.n_mels * 65 * sizeof(float), st>>>(logspec, maxkey, t.n_mels, mel_t, mel_f32); }

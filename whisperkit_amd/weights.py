@@ -373,10 +373,15 @@ def kernel_tensors(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> List[Tuple[s
         return list(ex.map(realise, jobs))
 
 
-def pack_blob(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> np.ndarray:
+def pack_blob(dims: WhisperDims, sd: Dict[str, np.ndarray], alignment_heads: Optional[Iterable[Tuple[int, int]]] = None) -> np.ndarray:
     """Serialise to the `WHIPW001` container read by `wh_model_create` (include/whisperhip.h).
-    Returns a uint8 array (buffer protocol; `bytes(blob)` / `blob.tofile(path)` for a file)."""
+    Returns a uint8 array (buffer protocol; `bytes(blob)` / `blob.tofile(path)` for a file).
+    `alignment_heads` ((layer, head) pairs, e.g. HF generation_config.alignment_heads) travel inside the blob as the optional
+    int32 tensor `dec.alignment_heads` [n][2], so that a file-based `wh_model_load` selects the same word-timestamp heads."""
     tensors = kernel_tensors(dims, sd)
+    if alignment_heads:
+        ah = np.ascontiguousarray(np.array([(int(l), int(h)) for l, h in alignment_heads], dtype=np.int32).reshape(-1, 2))
+        tensors.append(("dec.alignment_heads", ah))
     n = len(tensors)
     entry = struct.Struct("<64sii4qqq")  # name, dtype, ndim, shape[4], offset, nbytes
     header_size = len(MAGIC) + 4 * 10 + 4 + 4 + entry.size * n
