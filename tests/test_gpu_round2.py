@@ -39,13 +39,16 @@ def test_fallback_of_one_slot_keeps_the_other_slots_alignment(micro):
     """a slot accepted at T = 0 must keep its alignment rows while another slot of the batch re-decodes at the
     next temperature (TranscribeTask.decodeWithFallback resets only the task's own DecodingInputs, TranscribeTask.swift:374-398)."""
     dims, _, model = micro
-    audios = [synthetic_chunk(901), synthetic_chunk(902)]
     # withoutTimestamps: no timestamp tokens -> the seek advances by the whole window -> exactly one window per audio
     base = dict(sampleLength=14, firstTokenLogProbThreshold=None, compressionRatioThreshold=None, wordTimestamps=True, seed=3, withoutTimestamps=True)
     s2 = api.Session(model, 2)
-    probe = s2.transcribe(audios, api.DecodingOptions(**base, logProbThreshold=None, temperatureFallbackCount=0))
-    lps = [r.segments[0].avgLogprob for r in probe]
-    assert abs(lps[0] - lps[1]) > 1e-3
+    for seed in range(901, 940, 2):           # two windows whose average log-probs are clearly apart
+        audios = [synthetic_chunk(seed), synthetic_chunk(seed + 1)]
+        probe = s2.transcribe(audios, api.DecodingOptions(**base, logProbThreshold=None, temperatureFallbackCount=0))
+        lps = [r.segments[0].avgLogprob for r in probe]
+        if abs(lps[0] - lps[1]) > 0.02:
+            break
+    assert abs(lps[0] - lps[1]) > 0.02, lps
     thr = 0.5 * (lps[0] + lps[1])                     # exactly one slot is below the threshold and falls back once
     opts = api.DecodingOptions(**base, logProbThreshold=thr, temperatureFallbackCount=1)
     got = s2.transcribe(audios, opts)
@@ -63,18 +66,22 @@ def test_batched_language_detection_prompts_every_slot_with_its_own_language(mic
     """detectLanguage runs per audio (one TranscribeTask each, WhisperKit.swift:735-792): in a device batch
     every slot's prompt carries ITS language token."""
     dims, _, model = micro_ml
-    s2, s1 = api.Session(model, 2), api.Session(model, 1)
-    pair = None
-    for seed in range(300, 340):                      # two windows whose detected languages differ
-        xs = [synthetic_chunk(seed), synthetic_chunk(seed + 100)]
-        for b, x in enumerate(xs):
-            s2.padOrTrim(x, b)
-        s2.logMelSpectrogram(2); s2.encodeFeatures(2); s2.prepareDecoderInputs(2)
-        lt, _ = s2.detectLanguage(2)
-        if lt[0] != lt[1]:
-            pair = (xs, lt)
-            break
-    assert pair is not None, "no pair of synthetic chunks with different detected languages"
+    s1 = api.Session(model, 1)
+    # candidate windows of very different character (random weights make the language logits depend only weakly on the audio)
+    t = np.arange(480000, dtype=np.float32) / 16000.0
+    cands = [synthetic_chunk(300 + i) for i in range(8)] + [synthetic_chunk(400) * g for g in (0.01, 0.2, 5.0, 20.0)] + \
+        [np.zeros(480000, np.float32), (0.5 * np.sin(2 * np.pi * 300 * t)).astype(np.float32), (0.5 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32),
+         np.sign(synthetic_chunk(401)).astype(np.float32) * 0.3]
+    sc = api.Session(model, len(cands))
+    for b, x in enumerate(cands):
+        sc.padOrTrim(x, b)
+    sc.logMelSpectrogram(len(cands)); sc.encodeFeatures(len(cands)); sc.prepareDecoderInputs(len(cands))
+    lts, _ = sc.detectLanguage(len(cands))
+    pair = next(((i, j) for i in range(len(cands)) for j in range(i + 1, len(cands)) if lts[i] != lts[j]), None)
+    assert pair is not None, f"every candidate window detects the same language token {set(lts)}"
+    xs, lt = [cands[pair[0]], cands[pair[1]]], [lts[pair[0]], lts[pair[1]]]
+    s2 = api.Session(model, 2)
+    pair = (xs, lt)
     xs, lt = pair
     opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12, detectLanguage=True)
     got = s2.transcribe(xs, opts)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU timing probe (development tool): decoder milliseconds per step and the per-kernel HIP-event table for one model at
-several batch sizes.   python tools/time_decode.py large-v3 8,32 [inflight]   (WH_DEC_PATH=gemv selects the GEMV path)"""
+several batch sizes.   python tools/time_decode.py large-v3 8,32 [inflight]"""
 import ctypes, json, os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ inflight = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dims = weights.MODEL_DIMS[name]
 t0 = time.perf_counter()
 model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
-print(f"# model {name} ready in {time.perf_counter() - t0:.1f}s path={os.environ.get('WH_DEC_PATH', 'mfma')}", flush=True)
+print(f"# model {name} ready in {time.perf_counter() - t0:.1f}s", flush=True)
 opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
                            noSpeechThreshold=None, temperatureFallbackCount=0)
 for B in batches:
@@ -36,7 +36,7 @@ for B in batches:
         for t in ths: t.join()
         ts.append(time.perf_counter() - a)
     wall = float(np.median(ts)); steps = out[0][1]
-    rec = {"model": name, "B": B, "inflight": inflight, "path": os.environ.get("WH_DEC_PATH", "mfma"), "steps": steps,
+    rec = {"model": name, "B": B, "inflight": inflight, "steps": steps,
            "ms_per_step_wall": round(wall * 1e3 / steps, 4), "seq_steps_per_s": round(inflight * B * steps / wall, 1)}
     lib = sessions[0].lib
     nk = lib.wh_kernel_kind_count()

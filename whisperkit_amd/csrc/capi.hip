@@ -151,18 +151,10 @@ static int bind_weights(wh_model* m) {
         GET16(p + ".o.w", w.o_w, d * d); GET32(p + ".o.b", w.o_b, d);
         GET32(p + ".ln2.g", w.ln2_g, d); GET32(p + ".ln2.b", w.ln2_b, d); GET16(p + ".cq.w", w.cq_w, d * d); GET32(p + ".cq.b", w.cq_b, d);
         GET16(p + ".co.w", w.co_w, d * d); GET32(p + ".co.b", w.co_b, d);
-        GET16(p + ".cqf.w", w.cqf_w, 4 * d * d); GET32(p + ".cqf.c0", w.cqf_c0, d); GET32(p + ".cqf.r", w.cqf_r, d); GET32(p + ".cqf.c", w.cqf_c, d);
         GET32(p + ".ln3.g", w.ln3_g, d); GET32(p + ".ln3.b", w.ln3_b, d);
         GET16(p + ".fc1.w", w.fc1_w, 4 * d * d); GET32(p + ".fc1.b", w.fc1_b, 4 * d); GET16(p + ".fc2.w", w.fc2_w, 4 * d * d); GET32(p + ".fc2.b", w.fc2_b, d);
     }
     return WH_OK;
-}
-
-// Decoder path selection, read once per process: WH_DEC_PATH=gemv keeps the lane-per-K GEMV kernels of decoder.hip (the A/B
-// side of the parity tests); default = the MFMA batch-tile path of decoder32.hip.
-static bool dec32_enabled() {
-    static const bool on = [] { const char* e = getenv("WH_DEC_PATH"); return !(e && strcmp(e, "gemv") == 0); }();
-    return on;
 }
 
 // Carve 256-byte aligned sub-buffers out of one allocation.
@@ -273,7 +265,7 @@ static int model_create_impl(const void* blob, size_t nbytes, int device, wh_mod
     }
     int r = bind_weights(m);
     if (!r) r = build_mel_tables(m);
-    if (!r && dec32_enabled()) r = build_dec32(m);
+    if (!r) r = build_dec32(m);
     if (!r) {
         std::vector<int32_t> pairs;
         auto ah = m->t.find("dec.alignment_heads");      // optional int32 [n][2] written by checkpoint conversion (generation_config.alignment_heads)
@@ -391,13 +383,12 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
-    DALLOC(s->xa, B * d); DALLOC(s->q, B * d); DALLOC(s->att, B * d); DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
+    DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
     DALLOC(s->logits, B * V);
-    DALLOC(s->hbuf, B * 4 * d);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
     DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress); DALLOC(s->sup_mask_dev, V); DALLOC(s->stats, B * kStatBlocks * 8);
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
-    if (!m->dec32.empty()) {
+    {
         const size_t n_bt = (B + 31) / 32, R = n_bt * 32;
         const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 16 * 256;
         if (hipMalloc(&s->d32_blob, bytes) != hipSuccess || hipMemset(s->d32_blob, 0, bytes) != hipSuccess) {
@@ -413,7 +404,6 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
         q.stat = c.take<float2>(n_bt * (d / 32) * 32);
         q.part = c.take<float>(n_bt * (size_t)kD32PartFloats); q.part_floats = kD32PartFloats;
         q.ticket = c.take<int>(n_bt * 4096);
-        s->use32 = true;
     }
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
@@ -431,7 +421,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     whi::drop_session_graphs(s);
     if (s->d32_blob) hipFree(s->d32_blob);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
-                    s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->xa, s->q, s->att, s->part, s->ticket, s->logits, s->hbuf,
+                    s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->seq_host) hipHostFree(s->seq_host);
@@ -566,12 +556,11 @@ DecodeBuffers decode_buffers(wh_session* s, int batch) {
     DecodeBuffers db{};
     db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
-    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v; db.x = s->xa; db.q = s->q; db.att = s->att;
-    db.hbuf = s->hbuf; db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
-    { static const bool off = [] { const char* e = getenv("WH_NO_FUSED_CQ"); return e && e[0] == '1'; }(); db.fused_cq = off ? 0 : 1; }
+    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v;
+    db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = s->n_align_alloc;
-    db.d32 = s->use32 ? &s->d32 : nullptr;
+    db.d32 = &s->d32; db.x = s->d32.x; db.q = s->d32.q;
     return db;
 }
 }  // namespace whi

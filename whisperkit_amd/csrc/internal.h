@@ -61,16 +61,14 @@ struct wh_session {
     f16* hmlp = nullptr; f16* enc16 = nullptr; float* enc32 = nullptr;
     // decoder
     f16 *cross_k = nullptr, *cross_v = nullptr, *self_k = nullptr, *self_v = nullptr;
-    float *xa = nullptr, *q = nullptr, *att = nullptr, *part = nullptr, *logits = nullptr;
+    float *part = nullptr, *logits = nullptr;
     int* ticket = nullptr;
-    f16* hbuf = nullptr;
     float *align = nullptr, *align_mean = nullptr;
     int n_align_alloc = 0;                // alignment heads the `align` allocation was sized for
     std::map<WhGraphKey, hipGraphExec_t> graphs;   // captured 8-step decode graphs of THIS session (no process-wide state)
     const volatile int32_t* cancel_flag = nullptr; // polled between step graphs and pipeline stages (Task.checkCancellation)
-    wh::Dec32 d32{};                      // MFMA decode path buffers (one allocation: d32_blob)
+    wh::Dec32 d32{};                      // decode-step activations: residual, planes, split-K scratch (one allocation: d32_blob)
     void* d32_blob = nullptr;
-    bool use32 = false;
     wh::SeqState* seq = nullptr;
     wh::SeqState* seq_host = nullptr;     // pinned
     wh::SamplerCfg* cfg_dev = nullptr;

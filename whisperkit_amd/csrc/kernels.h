@@ -116,7 +116,6 @@ struct DecLayerW {
     const f16* o_w; const float* o_b;
     const float *ln2_g, *ln2_b; const f16* cq_w; const float* cq_b;
     const f16* co_w; const float* co_b;
-    const f16* cqf_w; const float *cqf_c0, *cqf_r, *cqf_c;   // LN2 + cross query folded over the out projection (weights.py)
     const float *ln3_g, *ln3_b; const f16* fc1_w; const float* fc1_b; const f16* fc2_w; const float* fc2_b;
 };
 
@@ -165,22 +164,19 @@ struct DecodeBuffers {
     f16* self_v;
     const f16* cross_k;      // [L][Bmax][H][1500][64] head-major cross-attention K / V (written by the cross-K/V GEMM epilogue)
     const f16* cross_v;
-    float* x;                // [B][d] residual stream
-    float* q;                // [B][d] f32 query
-    float* att;              // [B][d] attention output before the out projection
-    f16* hbuf;               // [B][4d]
+    float* x;                // [n_bt*32][d] residual stream (= d32->x)
+    float* q;                // [n_bt*32][d] f32 query (= d32->q)
     float* part;             // [B][H][kMaxSplit][kPartStride] cross-attention split partials
     int* ticket;             // [B][H]
     float* logits;           // [B][V]
     float* stats;            // [B][kStatBlocks][8] per-workgroup softmax statistics of the logits kernel (fused greedy sampler)
     const unsigned char* sup_mask;   // [V] SuppressTokensFilter as a byte mask
-    int fused_cq;            // out-projection launch also computes the folded cross query (one launch less per layer)
     int fused_greedy;        // every active slot samples at T = 0: filters + statistics in the logits epilogue, tiny final kernel
     float* align;            // [B][224][n_align][1500] raw score rows of the alignment heads (or null)
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
-    const struct Dec32* d32; // MFMA batch-tile decode path (decoder32.hip); null: GEMV path
+    const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
 constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
 constexpr int kMaxSplit = 24;   // cross-attention key splits (64 keys per workgroup at the finest)

@@ -253,37 +253,6 @@ def default_alignment_heads(dims: WhisperDims) -> List[Tuple[int, int]]:
     return [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
 
 
-def _cq_fold(sd, s: str, scale: float):
-    """Memoised fold of LN2 + cross-query over the self-attention out projection of decoder block `s` (see kernel_tensors)."""
-    import threading
-    lock, box = threading.Lock(), []
-
-    def run():
-        with lock:
-            if box:
-                return box[0]
-            f64 = np.float64
-            r16 = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(f64)       # the values the unfused kernels see
-            wcq = r16(sd[s + ".cross_attn.query.weight"] * np.float32(scale))
-            bcq = (sd[s + ".cross_attn.query.bias"] * np.float32(scale)).astype(f64)
-            wo, bo = r16(sd[s + ".attn.out.weight"]), sd[s + ".attn.out.bias"].astype(f64)
-            g2, b2 = sd[s + ".cross_attn_ln.weight"].astype(f64), sd[s + ".cross_attn_ln.bias"].astype(f64)
-            wq = wcq * g2[None, :]
-            m = wq @ wo
-
-            def hilo(a):
-                hi = a.astype(np.float16)
-                lo = (a - hi.astype(f64)).astype(np.float16)
-                return hi, lo
-            wh, wl = hilo(wq)
-            mh, ml = hilo(m)
-            wrep = wh.astype(f64) + wl.astype(f64)
-            w4 = np.ascontiguousarray(np.concatenate([wh, wl, mh, ml], axis=1))
-            box.append((w4, (wrep @ bo).astype(np.float32), wrep.sum(1).astype(np.float32), (wcq @ b2 + bcq).astype(np.float32)))
-            return box[0]
-    return run
-
-
 def kernel_tensors(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray]]:
     """Derive the tensors the HIP kernels read, in their final layouts."""
     d, dt = dims.n_audio_state, dims.n_text_state
@@ -342,15 +311,6 @@ def kernel_tensors(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> List[Tuple[s
         f32(p + ".ln2.g", sd[s + ".cross_attn_ln.weight"]); f32(p + ".ln2.b", sd[s + ".cross_attn_ln.bias"])
         f16(p + ".cq.w", sd[s + ".cross_attn.query.weight"] * scale)
         f32(p + ".cq.b", sd[s + ".cross_attn.query.bias"] * scale)
-        # folded cross-attention query (decoder.hip, fused out-projection + cross-query launch):
-        #   q = W_cq LN2(x') + b_cq,  x' = x + W_o att + b_o   ==>   q = (u - mean(x') r) * rstd(x') + c  with
-        #   u = Wq' x + M att + c0,  Wq' = W_cq diag(gamma2),  M = Wq' W_o,  c0 = Wq' b_o,  r = Wq' 1,  c = W_cq beta2 + b_cq
-        # Wq' and M are products, so they are stored as an fp16 hi + lo pair (22-bit mantissa): cqf.w = [Wq'_hi | Wq'_lo | M_hi | M_lo]
-        fold = _cq_fold(sd, s, float(scale))
-        f16(p + ".cqf.w", lambda fold=fold: fold()[0])
-        f32(p + ".cqf.c0", lambda fold=fold: fold()[1])
-        f32(p + ".cqf.r", lambda fold=fold: fold()[2])
-        f32(p + ".cqf.c", lambda fold=fold: fold()[3])
         ckv_w += [sd[s + ".cross_attn.key.weight"], sd[s + ".cross_attn.value.weight"]]
         ckv_b += [np.zeros(dt, np.float32), sd[s + ".cross_attn.value.bias"]]
         f16(p + ".co.w", sd[s + ".cross_attn.out.weight"]); f32(p + ".co.b", sd[s + ".cross_attn.out.bias"])
