@@ -109,6 +109,11 @@ typedef struct wh_decoding_options {
     float first_token_log_prob_threshold;
     float no_speech_threshold;
     uint64_t seed;                /* seeds the T>0 multinomial draw (reference: unseeded system RNG) */
+    int32_t float16_logits;       /* reference-numerics switch, default 0 (fp32).  1: logits are rounded to Float16 before the filters
+                                     and the sampler - the TextDecoder output is a Float16 MLMultiArray on arm64 (Core/Models.swift:1041,
+                                     FloatType, ArgmaxCore/FloatType.swift:9-13) - and TimestampRulesFilter compares its two log-probabilities
+                                     in Float16 (Core/Text/LogitsFilter.swift:144-242: BNNS logSoftmax / logSumExp / max on FloatType) */
+    int32_t reserved_;
 } wh_decoding_options;
 
 /* DecodingFallback.fallbackReason, Core/Models.swift:357-381 */
@@ -217,6 +222,13 @@ int wh_reset_decoder_inputs(wh_session* s, int batch);  /* DecodingInputs.reset,
 int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens, const int32_t* positions,
                       float* logits_out_host /* [batch][n_vocab] or NULL */);
 int wh_get_alignment_weights(wh_session* s, int b, float* out_host /* [224][1500] */);
+
+/* Optional openai/whisper-style post-processing of the alignment heads inside wh_get_alignment_weights (and therefore in the
+ * word timestamps of wh_transcribe*): softmax rows -> z-normalise each (head, frame) over the decoded token rows -> median filter
+ * of odd width along the frames -> mean over heads (openai/whisper timing.py find_alignment; HF generation_whisper.py:341-349,
+ * median_filter_width 7).  The reference applies none of it on the host (Core/Text/SegmentSeeker.swift:195-237) and whether the
+ * CoreML bundles bake it in is not published: default off (z_normalize 0, median_filter_width 0). */
+int wh_session_set_alignment_postprocess(wh_session* s, int z_normalize, int median_filter_width);
 
 /* Device-resident hand-off (MLMultiArray outputs of the CoreML stages stay on the accelerator in the reference too): pointers
  * into the session's HBM buffers of slot b, valid until the session rewrites them; consume them on wh_session_stream(s) or after

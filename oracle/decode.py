@@ -98,6 +98,10 @@ class DecodingOptions:
     noSpeechThreshold: Optional[float] = 0.6
     concurrentWorkerCount: int = 4
     chunkingStrategy: Optional[str] = None
+    # Not a DecodingOptions field of the reference: the reference-numerics switch of the C ABI (wh_decoding_options.float16_logits).
+    # True emulates the arm64 FloatType = Float16 path: logits rounded to Float16 (Core/Models.swift:1041) and the
+    # TimestampRulesFilter comparison evaluated on Float16 log-probabilities (Core/Text/LogitsFilter.swift:144-242).
+    float16Logits: bool = False
 
     def __post_init__(self):
         if self.detectLanguage is None:   # Configurations.swift:222
@@ -239,9 +243,10 @@ class SuppressBlankFilter:
 class TimestampRulesFilter:
     """Core/Text/LogitsFilter.swift:54-243."""
     def __init__(self, specialTokens: SpecialTokens, sampleBegin: int, maxInitialTimestampIndex: Optional[int],
-                 isModelMultilingual: bool):
+                 isModelMultilingual: bool, float16: bool = False):
         self.specialTokens, self.sampleBegin = specialTokens, sampleBegin
         self.maxInitialTimestampIndex, self.isModelMultilingual = maxInitialTimestampIndex, isModelMultilingual
+        self.float16 = float16
 
     def _sampleBegin(self, tokens) -> Optional[int]:       # :131-142
         st = self.specialTokens
@@ -273,14 +278,17 @@ class TimestampRulesFilter:
                 timestampLast = last if (lastWasTimestamp and not penultimateWasTimestamp) else last + 1
                 logits[st.timeTokenBegin: timestampLast] = NEG_INF
         # :112-122 initial-timestamp rule is commented out in the reference - restated as absent.
-        if self._sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, st.timeTokenBegin):   # :125
+        if self._sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, st.timeTokenBegin, self.float16):   # :125
             logits[: st.timeTokenBegin] = NEG_INF
         return logits
 
     @staticmethod
-    def _sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, timeTokenBegin) -> bool:
+    def _sumOfProbabilityOverTimestampsIsAboveAnyOtherToken(logits, timeTokenBegin, float16: bool = False) -> bool:
         """:144-242  logsumexp(logprobs[tb:]) > max(logprobs[:tb]); the log-softmax normaliser is common
-        to both sides, so it is evaluated on the logits directly (float64)."""
+        to both sides, so it is evaluated on the logits directly (float64).
+        float16: the reference's arithmetic type is FloatType = Float16 there (BNNS logSoftmax -> logSumExp / max, each a
+        Float16 result); BNNS' internal precision is unspecified, so the emulation evaluates in float64 and rounds the two
+        log-probabilities that are compared to Float16."""
         x = np.asarray(logits, dtype=np.float64)
         ts, tx = x[timeTokenBegin:], x[:timeTokenBegin]
         mts = ts.max() if ts.size else NEG_INF
@@ -288,6 +296,12 @@ class TimestampRulesFilter:
             return False if mts == NEG_INF else True
         timestampLogProb = mts + math.log(float(np.exp(ts - mts).sum()))
         maxText = tx.max() if tx.size else NEG_INF
+        if float16:
+            if maxText == NEG_INF:
+                return True
+            m = x.max()
+            lse = m + math.log(float(np.exp(x - m).sum()))
+            return bool(np.float16(timestampLogProb - lse) > np.float16(maxText - lse))
         return bool(timestampLogProb > maxText)
 
 
@@ -318,7 +332,7 @@ def create_logits_filters(options: DecodingOptions, prefilledIndex: int, initial
         if options.maxInitialTimestamp is not None:
             mi = int(np.float32(options.maxInitialTimestamp) / np.float32(SECONDS_PER_TIME_TOKEN))
         fs.append(TimestampRulesFilter(st, sampleBegin=initialPromptIndex, maxInitialTimestampIndex=mi,
-                                       isModelMultilingual=isModelMultilingual))
+                                       isModelMultilingual=isModelMultilingual, float16=options.float16Logits))
     return fs
 
 
@@ -426,6 +440,8 @@ def decode_text(step: StepFn, initialPrompt: List[int], sampler: GreedyTokenSamp
             else:
                 currentTokens[tokenIndex] = nextToken
         logits = np.array(step(nextToken, tokenIndex), dtype=np.float32, copy=True)             # :616
+        if options.float16Logits:                        # MLMultiArray of FloatType (Core/Models.swift:1041)
+            logits = logits.astype(np.float16).astype(np.float32)
         steps += 1
         raw = logits.copy() if record_logits is not None else None
         for f in filters:                                                                       # :641-643

@@ -98,6 +98,8 @@ class DecoderState:
         self.k = [torch.zeros(self.MAX_CTX, d) for _ in range(dims.n_text_layer)]
         self.v = [torch.zeros(self.MAX_CTX, d) for _ in range(dims.n_text_layer)]
         self.alignment = np.zeros((self.MAX_CTX, dims.n_audio_ctx), dtype=np.float32)
+        self.alignment_heads = np.zeros((self.MAX_CTX, max(len(self.m.alignment_heads), 1), dims.n_audio_ctx), dtype=np.float32)
+        self.alignment_written = np.zeros(self.MAX_CTX, dtype=bool)
 
     def step(self, token: int, pos: int, want_alignment: bool = True):
         """One decoder call (TextDecoder.predictLogits + updateKVCache + updateAlignmentWeights,
@@ -129,4 +131,26 @@ class DecoderState:
             logits = F.linear(x, w["decoder.token_embedding.weight"])[0]
             if want_alignment and align_rows and pos + 1 < self.MAX_CTX:
                 self.alignment[pos + 1] = torch.stack(align_rows).mean(0).numpy()
+                self.alignment_heads[pos + 1] = torch.stack(align_rows).numpy()
+                self.alignment_written[pos + 1] = True
         return logits.numpy()
+
+    def postprocessed_alignment(self, z_normalize: bool = True, median_filter_width: int = 7) -> np.ndarray:
+        """openai/whisper timing.py find_alignment / transformers generation_whisper.py:341-349 on the rows written so far:
+        weights [heads, tokens, frames] -> (w - mean over tokens) / std over tokens (unbiased=False) -> median filter along the
+        frames (reflect padding, `_median_filter` :43-60) -> mean over heads.  Returns [224, 1500] (unwritten rows zero)."""
+        rows = np.nonzero(self.alignment_written)[0]
+        out = np.zeros_like(self.alignment)
+        if len(rows) == 0:
+            return out
+        w = torch.from_numpy(self.alignment_heads[rows]).permute(1, 0, 2).double()      # [heads, tokens, frames]
+        if z_normalize:
+            std = torch.std(w, dim=-2, keepdim=True, unbiased=False)
+            mean = torch.mean(w, dim=-2, keepdim=True)
+            w = torch.where(std > 0, (w - mean) / std, torch.zeros_like(w))
+        if median_filter_width and median_filter_width > 1:
+            p = median_filter_width // 2
+            w = F.pad(w, (p, p), mode="reflect")
+            w = w.unfold(-1, median_filter_width, 1).sort()[0][..., p]
+        out[rows] = w.mean(0).float().numpy()
+        return out

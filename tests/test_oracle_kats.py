@@ -355,3 +355,20 @@ def test_single_token_segment_word_duration():  # UnitTests.swift:2869-2937
     for w in ws:
         assert w.start >= prev_end and w.duration <= mx + 1e-6
         prev_end = w.end
+
+
+def test_float16_timestamp_rule_emulation_differs_from_fp32_exactly_where_float16_ties():
+    """Reference-numerics switch (wh_decoding_options.float16_logits, oracle DecodingOptions.float16Logits): the reference compares
+    logSumExp(timestamp log-probs) > max(text log-probs) on FloatType = Float16 values (Core/Text/LogitsFilter.swift:144-242).
+    Two log-probabilities 0.002 apart near -6.9 are distinct in fp32 and equal in Float16 (spacing 2^-8 there)."""
+    from oracle import decode as OD
+    f = OD.TimestampRulesFilter._sumOfProbabilityOverTimestampsIsAboveAnyOtherToken
+    x = np.zeros(20000, dtype=np.float32)        # log-sum-exp ~ 9.9
+    tb = 15000
+    x[10] = 3.0                                   # best text logit
+    x[tb + 5] = 3.002                             # a single dominant timestamp logit, everything else negligible
+    x[tb:tb + 5] = -30.0; x[tb + 6:] = -30.0
+    assert f(x, tb, False) is True                # fp32: -6.905 > -6.907
+    assert f(x, tb, True) is False                # Float16: both round to the same value -> not strictly greater
+    x[tb + 5] = 3.02
+    assert f(x, tb, True) is True

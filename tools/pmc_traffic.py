@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch per kernel kind from the two rocprofv3 PMC passes (tools/profile_gpu.sh): FETCH_SIZE and WRITE_SIZE are KB
+per dispatch; FETCH_SIZE is doubled (gfx950 tallies a 128-byte request of a wide coalesced read as 64 B - MI355X_MICROARCH.md,
+HBM section); WRITE_SIZE is used as reported.  Writes the JSON bench.py reads for `roofline.traffic`.
+
+    python tools/pmc_traffic.py gpurun_out/r02f_pmc_FETCH_SIZE.csv gpurun_out/r02f_pmc_WRITE_SIZE.csv large-v3 32 > profiles/r02_pmc_traffic.json
+"""
+import csv
+import json
+import re
+import sys
+
+KIND = [  # (regex on the kernel name, kernel kind of bench.py)
+    (r"dec_cross_attn_kernel", "dec_cross_attn"), (r"dec_self_attn_kernel", "dec_self_attn"),
+    (r"dec32_proj_kernel<0,", "dec_proj_qkv"), (r"dec32_proj_kernel<1,", "dec_proj_cq"),
+    (r"dec32_proj_kernel<2, true", "dec_proj_oproj"), (r"dec32_proj_kernel<2, false", "dec_proj_fc2"),
+    (r"dec32_proj_kernel<3,", "dec_proj_fc1"), (r"dec32_proj_kernel<4,", "dec_proj_logits"),
+    (r"dec32_embed_kernel", "dec_embed"), (r"sampler_final_kernel", "sampler"),
+    (r"gemm256_kernel<1>", "gemm_enc_fc1"), (r"gemm256_kernel<3>", "gemm_enc_qkv"), (r"gemm256_kernel<7>", "gemm_cross_kv"),
+    (r"gemm256_kernel<5>", "gemm_conv2"), (r"gemm256_kernel<4>", "gemm_conv1"), (r"gemm256_kernel<2>", "gemm_enc_o+fc2"),
+    (r"encoder_attention_kernel", "enc_attention"), (r"layernorm_kernel", "layernorm"), (r"mel_power_kernel", "mel_power"),
+    (r"mel_finalize_kernel", "mel_finalize"),
+]
+
+
+def read(path):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        for pat, kind in KIND:
+            if re.search(pat, row["Kernel"]):
+                out[kind] = (float(row["AvgValue"]) * 1024.0, int(row["Dispatches"]))
+                break
+    return out
+
+
+def main():
+    fetch, write = read(sys.argv[1]), read(sys.argv[2])
+    model, B = sys.argv[3], int(sys.argv[4])
+    bpl, detail = {}, {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, (0.0, 0))[0], write.get(k, (0.0, 0))[0]
+        bpl[k] = int(round(2.0 * f + w))
+        detail[k] = {"fetch_size_kb": round(f / 1024, 1), "write_size_kb": round(w / 1024, 1), "dispatches": fetch.get(k, write.get(k))[1]}
+    bpl["dec_proj_coproj"] = bpl.get("dec_proj_oproj")       # the two out projections run the same kernel on same-sized operands
+    json.dump({"config": f"whisper-{model}, {B} chunks per step (tools/pmc_run.py, eager launches, 8 decoder steps at positions 0..8)",
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace only); KB per "
+                         "dispatch averaged over all dispatches of the kernel; bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled per the "
+                         "gfx950 correction of MI355X_MICROARCH.md; Infinity-Cache hits are counted, so this is traffic at the L2's memory side)",
+               "model": model, "chunks_per_step": B, "bytes_per_launch": bpl, "counters": detail}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

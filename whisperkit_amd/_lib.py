@@ -40,6 +40,7 @@ class WhDecodingOptions(C.Structure):
         ("suppress_blank", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32)), ("n_suppress_tokens", C.c_int32),
         ("compression_ratio_threshold", C.c_float), ("log_prob_threshold", C.c_float),
         ("first_token_log_prob_threshold", C.c_float), ("no_speech_threshold", C.c_float), ("seed", C.c_uint64),
+        ("float16_logits", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -125,6 +126,7 @@ SYMBOLS = {
     "wh_get_encoder_output_device": (I, [VP, I, PVP, PVP]),
     "wh_get_logits_device": (I, [VP, PVP]),
     "wh_session_set_cancel_flag": (I, [VP, VP]),
+    "wh_session_set_alignment_postprocess": (I, [VP, I, I]),
     "wh_prefill_prompt": (I, [VP, POPT, PST, C.c_int32, PI32, I]),
     "wh_transcribe": (I, [VP, VP, I, POPT, PST, PVP]),
     "wh_transcribe_batch": (I, [VP, PVP, PI32, I, POPT, PST, PVP]),

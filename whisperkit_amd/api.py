@@ -67,6 +67,7 @@ class DecodingOptions:
     firstTokenLogProbThreshold: Optional[float] = -1.5
     noSpeechThreshold: Optional[float] = 0.6
     seed: int = 0
+    float16Logits: bool = False   # reference-numerics switch (wh_decoding_options.float16_logits): FloatType logits + Float16 timestamp rule
 
     def to_c(self):
         o = L.WhDecodingOptions()
@@ -105,6 +106,7 @@ class DecodingOptions:
         o.first_token_log_prob_threshold = nan if self.firstTokenLogProbThreshold is None else self.firstTokenLogProbThreshold
         o.no_speech_threshold = nan if self.noSpeechThreshold is None else self.noSpeechThreshold
         o.seed = self.seed
+        o.float16_logits = int(self.float16Logits)
         o._keep = keep
         return o
 
@@ -515,6 +517,11 @@ class Session:
                                                      lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF),
                                                      None if act is None else act.ctypes.data_as(L.PI32), seed, res))
         return [DecodingResult.from_c(r) for r in res]
+
+    def setAlignmentPostprocess(self, zNormalize: bool = False, medianFilterWidth: int = 0):
+        """openai/whisper-style normalisation of the alignment heads (z-norm over the token rows, median filter over the frames)
+        applied by getAlignmentWeights and the word timestamps; default off like the reference's host code."""
+        _check(self.lib.wh_session_set_alignment_postprocess(self.handle, int(zNormalize), int(medianFilterWidth)))
 
     def setCancelFlag(self, flag: Optional["C.c_int32"]):
         """Task.checkCancellation: a ctypes.c_int32 polled by the running call (non-zero -> WhisperError code 102); None removes it.

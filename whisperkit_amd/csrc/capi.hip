@@ -355,7 +355,7 @@ extern "C" void wh_decoding_options_default(wh_decoding_options* o) {
     o->window_clip_time = 1.0f; o->prompt_tokens = nullptr; o->n_prompt_tokens = 0; o->prefix_tokens = nullptr; o->n_prefix_tokens = 0;
     o->suppress_blank = 0; o->suppress_tokens = nullptr; o->n_suppress_tokens = 0;
     o->compression_ratio_threshold = 2.4f; o->log_prob_threshold = -1.0f; o->first_token_log_prob_threshold = -1.5f;
-    o->no_speech_threshold = 0.6f; o->seed = 0;
+    o->no_speech_threshold = 0.6f; o->seed = 0; o->float16_logits = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ session
@@ -420,6 +420,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->st) hipStreamSynchronize(s->st);
     whi::drop_session_graphs(s);
     if (s->d32_blob) hipFree(s->d32_blob);
+    if (s->align_tmp) hipFree(s->align_tmp);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
@@ -551,9 +552,11 @@ extern "C" int wh_set_encoder_output(wh_session* s, int b, const float* enc) {
 
 // ------------------------------------------------------------------------------------------------ decoder
 namespace whi {
-DecodeBuffers decode_buffers(wh_session* s, int batch) {
+DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
+    // max_position: the largest token_index any live slot can have during the launches built from this description
     const wh_model* m = s->m;
     DecodeBuffers db{};
+    db.self_passes = std::min(7, std::max(1, (std::min(std::max(max_position, 0), kMaxTok - 1) + 32) / 32));
     db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
     db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v;
@@ -631,7 +634,7 @@ extern "C" int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens
     }
     // only the control fields are refreshed; token history on the device is not used by the bare step
     WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
-    DecodeBuffers db = whi::decode_buffers(s, batch);
+    DecodeBuffers db = whi::decode_buffers(s, batch, *std::max_element(positions, positions + batch));
     launch_decoder_step(db, nullptr, nullptr, false, s->st);
     WH_CHECK_LAUNCH();
     if (logits_out) WH_HIP(hipMemcpyAsync(logits_out, s->logits, sizeof(float) * (size_t)batch * V, hipMemcpyDeviceToHost, s->st));
@@ -644,7 +647,19 @@ extern "C" int wh_get_alignment_weights(wh_session* s, int b, float* out) {
     if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_alignment_weights: null output");
     if (!s->align) return set_error(WH_ERR_SEGMENTING_FAILED, "no alignment weights recorded (run a decode with word timestamps / the step API first)");
     size_t n = (size_t)kMaxTok * kCtx;
-    launch_alignment_mean(s->align + (size_t)b * n * s->n_align_alloc, 1, s->n_align_alloc, s->align_mean + b * n, s->st);   // this slot only
+    if (s->align_znorm || s->align_median > 1) {
+        const size_t H = (size_t)s->n_align_alloc;
+        if (s->align_tmp && s->align_tmp_heads != s->n_align_alloc) { WH_HIP(hipStreamSynchronize(s->st)); hipFree(s->align_tmp); s->align_tmp = nullptr; }
+        if (!s->align_tmp) {
+            WH_HIP(hipMalloc((void**)&s->align_tmp, ((size_t)kMaxTok * H * kCtx + 2 * H * kCtx + 256) * sizeof(float)));
+            s->align_tmp_heads = s->n_align_alloc;
+        }
+        float* stat = s->align_tmp + (size_t)kMaxTok * H * kCtx;
+        launch_alignment_postprocess(s->align + (size_t)b * n * H, s->n_align_alloc, s->align_tmp, stat, reinterpret_cast<int*>(stat + 2 * H * kCtx),
+                                     s->align_znorm, s->align_median, s->align_mean + b * n, s->st);
+    } else {
+        launch_alignment_mean(s->align + (size_t)b * n * s->n_align_alloc, 1, s->n_align_alloc, s->align_mean + b * n, s->st);   // this slot only
+    }
     WH_CHECK_LAUNCH();
     WH_HIP(hipMemcpyAsync(out, s->align_mean + b * n, n * 4, hipMemcpyDeviceToHost, s->st));
     WH_HIP(hipStreamSynchronize(s->st));
@@ -671,6 +686,14 @@ extern "C" int wh_get_logits_device(wh_session* s, const float** logits_dev) {
     *logits_dev = s->logits;
     return WH_OK;
 }
+extern "C" int wh_session_set_alignment_postprocess(wh_session* s, int z_normalize, int median_filter_width) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_alignment_postprocess: null session");
+    if (median_filter_width < 0 || median_filter_width > 15 || (median_filter_width > 1 && median_filter_width % 2 == 0))
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_alignment_postprocess: the median filter width must be 0 / 1 (off) or odd and <= 15");
+    s->align_znorm = z_normalize != 0;
+    s->align_median = median_filter_width;
+    return WH_OK;
+}
 extern "C" int wh_session_set_cancel_flag(wh_session* s, const volatile int32_t* flag) {
     if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_cancel_flag: null session");
     s->cancel_flag = flag;
@@ -694,6 +717,7 @@ static int upload_cfg(wh_session* s, const wh_decoding_options* opt, const wh_sp
     c.has_first_token_threshold = opt && !isnan(opt->first_token_log_prob_threshold);
     c.first_token_log_prob_threshold = opt ? opt->first_token_log_prob_threshold : 0.f;
     c.seed = seed;
+    c.f16_logits = opt ? (opt->float16_logits != 0) : 0;
     // createLogitsFilters: suppressTokens filtered to ids < specialTokenBegin (TextDecoder.swift:876-879)
     std::vector<int> sup;
     if (opt && opt->suppress_tokens)

@@ -20,6 +20,21 @@ __device__ __forceinline__ void stat_merge(SoftStat& a, float em, float es, int 
     }
 }
 
+// "timestamp mass beats every text token" (TimestampRulesFilter, LogitsFilter.swift:144-242) from the merged softmax statistics of
+// the unmasked text ids (t) and timestamp ids (u).  fp32: logsumexp(ts) > max(text).  Float16 mode: the reference takes logSoftmax
+// over all logits, then logSumExp(ts) and max(text), each a FloatType (Float16) value - emulated as the fp32 quantities relative to
+// the common log-sum-exp, rounded to Float16 before the comparison (BNNS' internal precision is not specified).
+__device__ __forceinline__ bool timestamp_mass_wins(const SoftStat& t, const SoftStat& u, bool f16_mode) {
+    if (u.m == -INFINITY) return false;
+    const float ts = u.m + logf(u.s);
+    if (!f16_mode) return ts > t.m;
+    if (t.m == -INFINITY) return true;
+    SoftStat g = t;
+    stat_merge(g, u.m, u.s, u.i);
+    const float lse = g.m + logf(g.s);
+    return (float)(f16)(ts - lse) > (float)(f16)(t.m - lse);
+}
+
 // element (slot b, channel n) of an activation plane of K channels: Z[b / 32][n / 16][(n / 8) & 1][b & 31][n & 7]
 __device__ __forceinline__ size_t plane_index(int b, int n, int K) {
     return ((((size_t)(b >> 5) * (K >> 4) + (n >> 4)) * 2 + ((n >> 3) & 1)) * 32 + (b & 31)) * 8 + (n & 7);

@@ -185,6 +185,10 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
     return true;
 }
 
+// PASSES x 32 cached positions are FETCHED (speculatively, before the slot state is known): the launcher passes the smallest
+// bound that covers every live slot's position, so the cache traffic follows the decoded length instead of always being 224 rows
+// (PMC, 32 slots at positions < 9: 37 MB fetched per launch with the fixed 7 passes against 1.5 MB needed).
+template <int PASSES>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     __shared__ float red[16], osum[256], o_l[64];
     const int h = blockIdx.x, b = blockIdx.y;
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     const size_t base = ((size_t)b * a.n_head + h) * kMaxTok * kHeadDim;
     float m, l;
     float* raw = nullptr;
-    auto get_n = [&]() { return (s_act && !s_done) ? min(max(s_ti, 0), kMaxTok - 1) + 1 : -1; };
+    auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, PASSES * 32) : -1; };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<7>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, kMaxTok, get_n, qfix, &raw, red, osum, o_l, &m, &l))
+    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, PASSES * 32, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
@@ -425,6 +429,7 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
         float v = -INFINITY;
         if (n < V) {
             v = logits[n];
+            if (cfg.f16_logits) v = (float)(f16)v;          // idempotent for logits the projection kernel already rounded
             if (DO_FILTER) {
                 if (cfg.language_filter) {                                           // LanguageLogitsFilter :259-265
                     if (n < cfg.language_token_begin || n >= cfg.language_token_begin + cfg.n_language_tokens) v = -INFINITY;
@@ -441,14 +446,16 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
         // sumOfProbabilityOverTimestampsIsAboveAnyOtherToken (:144-242): logsumexp(ts) > max(text)
         const float m_text = block_max(mx_text, &br);
         const float m_ts = block_max(mx_ts, &br);
-        float s = 0.0f;
+        float s = 0.0f, st = 0.0f;
 #pragma unroll
         for (int e = 0; e < SAMP_E; ++e) {
             int n = tid + SAMP_T * e;
-            if (n < V && n >= tb && x[e] != -INFINITY) s += expf(x[e] - m_ts);
+            if (n < V && x[e] != -INFINITY) { if (n >= tb) s += expf(x[e] - m_ts); else st += expf(x[e] - m_text); }
         }
         s = block_sum(s, &br);
-        bool cond = (m_ts != -INFINITY) && (m_ts + logf(s) > m_text);
+        st = block_sum(st, &br);
+        const SoftStat t_{m_text, st, 0}, u_{m_ts, s, 0};
+        const bool cond = timestamp_mass_wins(t_, u_, cfg.f16_logits != 0);
         if (cond) {
 #pragma unroll
             for (int e = 0; e < SAMP_E; ++e) {
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
         const SamplerCfg cfg = *cfgp;
         const bool ts_active = sq_l.f_rules[1] != 0;
         int tok; float lp;
-        const bool cond = ts_active && u.m != -INFINITY && (u.m + logf(u.s) > t.m);
+        const bool cond = ts_active && timestamp_mass_wins(t, u, cfg.f16_logits != 0);
         if (cond || t.m == -INFINITY) {          // text ids masked: the candidates are the timestamp ids
             tok = u.i; lp = -logf(u.s);
         } else {
@@ -619,6 +626,20 @@ int cross_attn_splits(int batch, int n_head) {
     static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 16 / 12 / 8 / 4 / 2
     const int passes = forced ? forced : (n_head >= 12 ? 8 : n_head >= 4 ? 4 : 2);
     return (kCtx + passes * 32 - 1) / (passes * 32);
+}
+
+static void launch_self_attn(const AttnArgs& at, int passes, int H, int B, hipStream_t st) {
+    ProfScope ps_(KK_DEC_SELF_ATTN, st);
+    const dim3 grid(H, B);
+    switch (passes) {
+        case 1: dec_self_attn_kernel<1><<<grid, 256, 0, st>>>(at); break;
+        case 2: dec_self_attn_kernel<2><<<grid, 256, 0, st>>>(at); break;
+        case 3: dec_self_attn_kernel<3><<<grid, 256, 0, st>>>(at); break;
+        case 4: dec_self_attn_kernel<4><<<grid, 256, 0, st>>>(at); break;
+        case 5: dec_self_attn_kernel<5><<<grid, 256, 0, st>>>(at); break;
+        case 6: dec_self_attn_kernel<6><<<grid, 256, 0, st>>>(at); break;
+        default: dec_self_attn_kernel<7><<<grid, 256, 0, st>>>(at);
+    }
 }
 
 static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStream_t st) {
@@ -662,7 +683,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
-        { ProfScope ps_(KK_DEC_SELF_ATTN, st); dec_self_attn_kernel<<<dim3(H, B), 256, 0, st>>>(at); }
+        launch_self_attn(at, db.self_passes, H, B, st);
         a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
         a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
@@ -689,7 +710,8 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
     P32Args a = base;           // final LayerNorm (folded) + tied-embedding logits (+ the fused greedy sampler statistics)
     a.N = V; a.K = d; a.Wt = D.emb_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = D.lg_g; a.fold_c = D.lg_c;
     a.logits = fused ? nullptr : db.logits; a.prof_kind = KK_DEC_LOGITS;
-    if (fused) { a.stats = db.stats; a.sup_mask = db.sup_mask; a.cfg = cfg_dev; }
+    if (sample) a.cfg = cfg_dev;                 // Float16-logits switch
+    if (fused) { a.stats = db.stats; a.sup_mask = db.sup_mask; }
     launch_dec32_proj(P32_LOGITS, a, n_bt, st);
     if (fused) {
         ProfScope ps_(KK_SAMPLER, st);
@@ -749,6 +771,101 @@ __global__ __launch_bounds__(256) void alignment_mean_kernel(const float* __rest
     const float invn = 1.0f / (float)n_align;
     for (int t = threadIdx.x; t < kCtx; t += 256) out[row * kCtx + t] = ((acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t])) * invn;
 }
+// ---- optional openai/whisper-style post-processing of the alignment heads before the head mean (timing.py find_alignment =
+// transformers generation_whisper.py:341-349): softmax rows -> z-normalise every (head, frame) over the decoded token rows ->
+// median filter of odd width along the frames (reflect padding) -> mean over heads.  SegmentSeeker applies none of it
+// (Core/Text/SegmentSeeker.swift:195-237: whatever the CoreML model outputs is used as is), so this is an OPTION, default off.
+__global__ __launch_bounds__(256) void align_softmax_kernel(const float* __restrict__ align, int n_align, float* __restrict__ prob, int* __restrict__ row_written) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x, j = blockIdx.y * 4 + wave;
+    if (j >= n_align) return;
+    const float* sp = align + ((size_t)row * n_align + j) * kCtx;
+    float* dp = prob + ((size_t)row * n_align + j) * kCtx;
+    float v[24];
+    float mx = -INFINITY, amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int t = lane + 64 * i;
+        v[i] = t < kCtx ? sp[t] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+        if (t < kCtx) amax = fmaxf(amax, fabsf(v[i]));
+    }
+    mx = wave_max(mx);
+    amax = wave_max(amax);
+    const bool written = amax != 0.0f;
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { v[i] = written ? __expf(v[i] - mx) : 0.0f; sum += v[i]; }
+    sum = wave_sum(sum);
+    const float inv = written ? 1.0f / sum : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const int t = lane + 64 * i; if (t < kCtx) dp[t] = v[i] * inv; }
+    if (j == 0 && lane == 0) row_written[row] = written ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void align_stats_kernel(const float* __restrict__ prob, int n_align, const int* __restrict__ row_written,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+    const int j = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= kCtx) return;
+    float s = 0.0f; int n = 0;
+    for (int r = 0; r < kMaxTok; ++r) if (row_written[r]) { s += prob[((size_t)r * n_align + j) * kCtx + t]; ++n; }
+    const float m = n ? s / (float)n : 0.0f;
+    float q = 0.0f;
+    for (int r = 0; r < kMaxTok; ++r) if (row_written[r]) { const float e = prob[((size_t)r * n_align + j) * kCtx + t] - m; q = fmaf(e, e, q); }
+    const float sd = n ? sqrtf(q / (float)n) : 0.0f;        // torch.std(unbiased=False)
+    mean[(size_t)j * kCtx + t] = m;
+    rstd[(size_t)j * kCtx + t] = sd > 0.0f ? 1.0f / sd : 0.0f;
+}
+__global__ __launch_bounds__(256) void align_norm_mean_kernel(const float* __restrict__ prob, int n_align, const int* __restrict__ row_written,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int znorm, int width,
+                                                              float* __restrict__ out) {
+    __shared__ float zr[kCtx];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    constexpr int NT = (kCtx + 255) / 256;
+    float acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = 0.0f;
+    const bool written = row_written[row] != 0;
+    const int p = width / 2;
+    for (int j = 0; j < n_align && written; ++j) {
+        __syncthreads();
+        for (int t = tid; t < kCtx; t += 256) {
+            float v = prob[((size_t)row * n_align + j) * kCtx + t];
+            if (znorm) v = (v - mean[(size_t)j * kCtx + t]) * rstd[(size_t)j * kCtx + t];
+            zr[t] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = tid + 256 * i;
+            if (t >= kCtx) continue;
+            float w[15];
+            for (int k = 0; k < width; ++k) {
+                int u = t - p + k;
+                if (u < 0) u = -u;                          // reflect: x[1], x[2], ... left of the edge
+                if (u >= kCtx) u = 2 * (kCtx - 1) - u;
+                w[k] = zr[u];
+            }
+            for (int a_ = 1; a_ < width; ++a_) {           // insertion sort of <= 15 values
+                const float key = w[a_];
+                int b_ = a_ - 1;
+                while (b_ >= 0 && w[b_] > key) { w[b_ + 1] = w[b_]; --b_; }
+                w[b_ + 1] = key;
+            }
+            acc[i] += w[p];
+        }
+    }
+    const float invn = 1.0f / (float)n_align;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { const int t = tid + 256 * i; if (t < kCtx) out[(size_t)row * kCtx + t] = acc[i] * invn; }
+}
+void launch_alignment_postprocess(const float* align, int n_align, float* prob_tmp, float* stat_tmp, int* row_written, int znorm, int median_width,
+                                  float* out, hipStream_t st) {
+    // one slot: align / prob_tmp [224][n_align][1500], stat_tmp [2][n_align][1500], out [224][1500]
+    align_softmax_kernel<<<dim3(kMaxTok, (n_align + 3) / 4), 256, 0, st>>>(align, n_align, prob_tmp, row_written);
+    if (znorm) align_stats_kernel<<<dim3((kCtx + 255) / 256, n_align), 256, 0, st>>>(prob_tmp, n_align, row_written, stat_tmp, stat_tmp + (size_t)n_align * kCtx);
+    align_norm_mean_kernel<<<kMaxTok, 256, 0, st>>>(prob_tmp, n_align, row_written, stat_tmp, stat_tmp + (size_t)n_align * kCtx, znorm, median_width > 1 ? median_width : 1, out);
+}
+
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st) {
     // `align` / `out` point at the first of `batch` consecutive slots
     alignment_mean_kernel<<<batch * kMaxTok, 256, 0, st>>>(align, n_align, out);

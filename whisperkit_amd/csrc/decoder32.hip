@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     if (valid) { live_l = slot_live(a.seq + gb); if constexpr (MODE == P32_QKV) pos_l = a.seq[gb].token_index; }
     int rules[6] = {0, 0, 0, 0, 0, 0};
     unsigned masked4 = 0xffffffffu;
-    int tb = 0, ws_tok = 0, eot_tok = 0, nots_tok = 0;
+    int tb = 0, ws_tok = 0, eot_tok = 0, nots_tok = 0, r16 = 0;
     if constexpr (MODE == P32_LOGITS) {
+        if (a.cfg) r16 = a.cfg->f16_logits;
         if (a.stats) {
             if (valid) {
 #pragma unroll
@@ -298,6 +299,10 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
         for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[i] + b4[i]);
         d32_resid_tail(xn, valid && live_l, bt, rt, n_rt, n, j, gb, tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out, xs);
     } else {    // P32_LOGITS
+        if (r16) {      // reference-numerics switch: the TextDecoder output is a Float16 array (Core/Models.swift:1041)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (float)(f16)y[i];
+        }
         if (a.logits && valid && live_l) {
             float* lo = a.logits + (size_t)gb * a.N + n;
             if (n + 3 < a.N) {

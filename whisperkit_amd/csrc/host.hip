@@ -265,11 +265,14 @@ static bool use_graphs() {
 }
 
 // Step graphs live in the session (a session is driven by one host thread at a time): no process-wide cache, no lock.
-static int get_step_graph(wh_session* s, int batch, hipGraphExec_t* out) {
-    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0};
+// `first_step`: token_index of the live slots at the graph's first step (decodeText starts every slot at 0 and advances them in
+// lock step): the graph's self-attention launches fetch only the cache rows its 8 steps can reach, so there is one graph per
+// 32-position band (7 per key at most).
+static int get_step_graph(wh_session* s, int batch, int first_step, hipGraphExec_t* out) {
+    DecodeBuffers db = whi::decode_buffers(s, batch, first_step + kStepsPerGraph - 1);
+    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_passes};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WH_OK; }
-    DecodeBuffers db = whi::decode_buffers(s, batch);
     hipGraph_t graph;
     WH_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < kStepsPerGraph; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
@@ -326,13 +329,15 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
     auto all_done = [&]() { for (int b = 0; b < batch; ++b) if (s->seq_host[b].active && !s->seq_host[b].done) return false; return true; };
     if (s->progress_cb) {
         // with a callback installed the host needs whole snapshots: no run-ahead, one synchronisation per 8 steps
-        hipGraphExec_t exec = nullptr;
-        DecodeBuffers db = whi::decode_buffers(s, batch);
-        if (use_graphs()) { int r = get_step_graph(s, batch, &exec); if (r) return r; }
         for (int step = 0; step < loop_count; step += kStepsPerGraph) {
             CHECK_CANCEL(s);
+            hipGraphExec_t exec = nullptr;
+            if (use_graphs()) { int r = get_step_graph(s, batch, step, &exec); if (r) return r; }
             if (exec) WH_HIP(hipGraphLaunch(exec, s->st));
-            else for (int i = 0; i < kStepsPerGraph && step + i < loop_count; ++i) { launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st); WH_CHECK_LAUNCH(); }
+            else for (int i = 0; i < kStepsPerGraph && step + i < loop_count; ++i) {
+                DecodeBuffers db = whi::decode_buffers(s, batch, step + i);
+                launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st); WH_CHECK_LAUNCH();
+            }
             WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
             WH_HIP(hipStreamSynchronize(s->st));
             if (all_done()) break;
@@ -345,12 +350,12 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
         return WH_OK;
     }
     if (use_graphs()) {
-        hipGraphExec_t exec;
-        int r = get_step_graph(s, batch, &exec);
-        if (r) return r;
         const int n_graphs = (loop_count + kStepsPerGraph - 1) / kStepsPerGraph;
         for (int g = 0; g < n_graphs; ++g) {
             if (cancelled(s)) { hipStreamSynchronize(s->st); return set_error(WH_ERR_CANCELLED, "decodeText: cancelled through the session's cancel flag"); }
+            hipGraphExec_t exec;
+            int r = get_step_graph(s, batch, g * kStepsPerGraph, &exec);
+            if (r) return r;
             WH_HIP(hipGraphLaunch(exec, s->st));
             // snapshot the slot states behind graph g; while it runs, look at the snapshot behind graph g-1
             // (at most one graph of run-ahead; `done` is monotonic, so a torn snapshot is harmless)
@@ -362,8 +367,8 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
             }
         }
     } else {
-        DecodeBuffers db = whi::decode_buffers(s, batch);
         for (int step = 0; step < loop_count; ++step) {
+            DecodeBuffers db = whi::decode_buffers(s, batch, step);
             launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
             WH_CHECK_LAUNCH();
             if ((step & 7) == 7 && step + 1 < loop_count) {
@@ -452,7 +457,7 @@ extern "C" int wh_detect_language(wh_session* s, int batch, const wh_special_tok
     WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st));
     bool keep = s->align_enabled;
     s->align_enabled = false;
-    DecodeBuffers db = whi::decode_buffers(s, batch);
+    DecodeBuffers db = whi::decode_buffers(s, batch, 0);
     s->align_enabled = keep;
     launch_decoder_step(db, nullptr, nullptr, false, s->st);
     launch_filter_sample(s->cfg_dev, s->suppress_dev, s->seq, s->logits, batch, s->tok_out_dev, s->lp_out_dev, s->st);
@@ -816,8 +821,10 @@ extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double*
         }
         hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * batch, hipMemcpyHostToDevice, s->st);
         launch_rules_init(s->cfg_dev, s->seq, batch, s->st);
-        DecodeBuffers db = whi::decode_buffers(s, batch);
-        for (int i = 0; i < n_steps; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
+        for (int i = 0; i < n_steps; ++i) {
+            DecodeBuffers db = whi::decode_buffers(s, batch, i);
+            launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
+        }
     }
     g_prof = nullptr;
     hipError_t le = hipGetLastError();

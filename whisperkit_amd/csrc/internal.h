@@ -46,8 +46,10 @@ struct wh_model {
 
 // step graphs are keyed by everything their captured launches bake in
 struct WhGraphKey {
-    int batch, align, fused, n_align;
-    bool operator<(const WhGraphKey& o) const { return std::tie(batch, align, fused, n_align) < std::tie(o.batch, o.align, o.fused, o.n_align); }
+    int batch, align, fused, n_align, self_passes;
+    bool operator<(const WhGraphKey& o) const {
+        return std::tie(batch, align, fused, n_align, self_passes) < std::tie(o.batch, o.align, o.fused, o.n_align, o.self_passes);
+    }
 };
 
 struct wh_session {
@@ -65,6 +67,8 @@ struct wh_session {
     int* ticket = nullptr;
     float *align = nullptr, *align_mean = nullptr;
     int n_align_alloc = 0;                // alignment heads the `align` allocation was sized for
+    int align_znorm = 0, align_median = 0;   // optional openai/whisper-style post-processing (wh_session_set_alignment_postprocess)
+    float* align_tmp = nullptr; int align_tmp_heads = 0;   // [224][n_align][1500] softmax rows + [2][n_align][1500] statistics + 224 flags
     std::map<WhGraphKey, hipGraphExec_t> graphs;   // captured 8-step decode graphs of THIS session (no process-wide state)
     const volatile int32_t* cancel_flag = nullptr; // polled between step graphs and pipeline stages (Task.checkCancellation)
     wh::Dec32 d32{};                      // decode-step activations: residual, planes, split-K scratch (one allocation: d32_blob)
@@ -97,7 +101,7 @@ int set_error(int code, const char* fmt, ...);
     } while (0)
 #define WH_CHECK_LAUNCH() WH_HIP(hipGetLastError())
 
-wh::DecodeBuffers decode_buffers(wh_session* s, int batch);
+wh::DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position = wh::kMaxTok - 1);
 void drop_session_graphs(wh_session* s);
 int ensure_align(wh_session* s);          // (re)allocate the raw alignment-head score buffer for the model's current head set
 int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active);

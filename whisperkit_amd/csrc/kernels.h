@@ -131,6 +131,7 @@ struct SamplerCfg {
     int top_k;
     int loop_count;                          // min(sampleLength, 223)
     int has_first_token_threshold; float first_token_log_prob_threshold;
+    int f16_logits;                          // reference-numerics switch: Float16 logits + Float16 timestamp-mass comparison
     unsigned long long seed;
 };
 
@@ -176,6 +177,7 @@ struct DecodeBuffers {
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
+    int self_passes;         // self-attention fetch bound: ceil((largest live token_index + 1) / 32), 1..7 (0 = 7: the whole cache)
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
 constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
@@ -240,6 +242,9 @@ void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits,
 void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st);
 // mean over alignment heads -> [B][224][1500]
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st);
+// openai/whisper-style alignment post-processing of one slot (z-normalise over the token rows, median filter, head mean)
+void launch_alignment_postprocess(const float* align, int n_align, float* prob_tmp, float* stat_tmp, int* row_written, int znorm, int median_width,
+                                  float* out, hipStream_t st);
 void launch_f32_to_f16(const float* in, f16* out, size_t n, hipStream_t st);
 void launch_f16_to_f32(const f16* in, float* out, size_t n, hipStream_t st);
 
