@@ -4,6 +4,7 @@
 //      let config = WhisperKitConfig(featureExtractor: HIPFeatureExtractor(model: m, session: s!),
 //                                    audioEncoder: HIPAudioEncoder(model: m, session: s!),
 //                                    textDecoder: HIPTextDecoder(model: m, session: s!))
+import CoreML
 import Foundation
 import WhisperKit
 import CWhisperHIP
@@ -54,31 +55,144 @@ public final class HIPAudioEncoder: AudioEncoding {
     }
 }
 
-public final class HIPTextDecoder /* : TextDecoding */ {
+/// TextDecoding (Core/TextDecoder.swift:60-105) over the C ABI: every requirement of the protocol, with the protocol's own
+/// signatures.  The KV cache, masks and alignment matrix live in the wh_session (HBM), so the MLMultiArray fields of
+/// `DecodingInputs` are only the carrier of `initialPrompt` / `inputIds` / `cacheLength` that TranscribeTask reads and resets
+/// (Core/TranscribeTask.swift:83,271,398); `updateKVCache` has nothing left to do.
+public final class HIPTextDecoder: TextDecoding {
     let model: HIPModel; let session: OpaquePointer
+    public var tokenizer: WhisperTokenizer?
+    public var isModelMultilingual: Bool
+    public var logitsFilters: [any LogitsFiltering]?        // user filters run only on the step API (predictLogits); the fused loop
+                                                            // applies the built-in chain of createLogitsFilters (TextDecoder.swift:857-899)
+    public var supportsWordTimestamps: Bool { wh_supports_word_timestamps(model.handle) != 0 }
     public var logitsSize: Int? { Int(wh_logits_size(model.handle)) }
     public var kvCacheEmbedDim: Int? { Int(wh_kv_cache_embed_dim(model.handle)) }
     public var kvCacheMaxSequenceLength: Int? { Int(wh_kv_cache_max_sequence_length(model.handle)) }
     public var windowSize: Int? { Int(wh_window_size(model.handle)) }
-    public var isModelMultilingual: Bool { wh_is_model_multilingual(model.handle) != 0 }
-    init(model: HIPModel, session: OpaquePointer) { self.model = model; self.session = session }
+    public var embedSize: Int? { Int(wh_embed_size(model.handle)) }
 
-    /// decodeText(from:using:sampler:options:callback:) — the whole token loop runs on the device.
-    public func decodeText(options: DecodingOptions, special: SpecialTokens, temperature: Float) throws -> DecodingResult {
-        var o = wh_decoding_options(); wh_decoding_options_default(&o)
-        o.temperature = temperature; o.sample_length = Int32(options.sampleLength); o.top_k = Int32(options.topK)
-        o.without_timestamps = options.withoutTimestamps ? 1 : 0; o.word_timestamps = options.wordTimestamps ? 1 : 0
-        o.suppress_blank = options.suppressBlank ? 1 : 0
-        o.compression_ratio_threshold = options.compressionRatioThreshold ?? .nan
-        o.log_prob_threshold = options.logProbThreshold ?? .nan
-        o.first_token_log_prob_threshold = options.firstTokenLogProbThreshold ?? .nan
-        o.no_speech_threshold = options.noSpeechThreshold ?? .nan
-        var st = wh_special_tokens(end_token: Int32(special.endToken), english_token: Int32(special.englishToken), /* ... */)
+    init(model: HIPModel, session: OpaquePointer) {
+        self.model = model; self.session = session
+        self.isModelMultilingual = wh_is_model_multilingual(model.handle) != 0
+    }
+
+    /// predictLogits (TextDecoder.swift:361-418): one decoder call; the session writes this step's K/V at `cacheLength` and the
+    /// alignment row at cacheLength + 1 itself (updateKVCache / updateAlignmentWeights, :218-296).
+    public func predictLogits(_ inputs: any TextDecoderInputType) async throws -> TextDecoderOutputType? {
+        guard let inputs = inputs as? TextDecoderMLMultiArrayInputType, let V = logitsSize else {
+            throw WhisperError.decodingLogitsFailed("HIPTextDecoder expects TextDecoderMLMultiArrayInputType")
+        }
+        var token = Int32(truncating: inputs.inputIds[0]), pos = Int32(truncating: inputs.cacheLength[0])
+        let logits = try MLMultiArray(shape: [1, 1, NSNumber(value: V)], dataType: .float32)
+        try check(wh_predict_logits(session, 1, &token, &pos, logits.dataPointer.assumingMemoryBound(to: Float.self)))
+        return TextDecoderMLMultiArrayOutputType(logits: logits, cache: nil)
+    }
+
+    /// prepareDecoderInputs(withPrompt:) (TextDecoder.swift:109-161): DecodingInputs.reset analogue on the device + the host carrier.
+    public func prepareDecoderInputs(withPrompt initialPrompt: [Int]) throws -> any DecodingInputsType {
+        try check(wh_reset_decoder_inputs(session, 1))
+        let one = try MLMultiArray(shape: [1], dataType: .int32), tok = try MLMultiArray(shape: [1], dataType: .int32)
+        one[0] = 0; tok[0] = NSNumber(value: initialPrompt.last ?? 0)
+        let empty = try MLMultiArray(shape: [1], dataType: .float16)
+        return DecodingInputs(initialPrompt: initialPrompt, inputIds: tok, cacheLength: one, keyCache: empty, valueCache: empty,
+                              alignmentWeights: empty, kvCacheUpdateMask: one, decoderKeyPaddingMask: empty)
+    }
+
+    /// prefillDecoderInputs (TextDecoder.swift:163-216): the forced prompt, built by the library's restatement of the same code.
+    public func prefillDecoderInputs(_ decoderInputs: any DecodingInputsType, withOptions options: DecodingOptions?) async throws -> any DecodingInputsType {
+        guard let tokenizer else { throw WhisperError.tokenizerUnavailable() }
+        var o = cOptions(options ?? DecodingOptions(), tokenizer: tokenizer); var st = cSpecial(tokenizer.specialTokens)
         var prompt = [Int32](repeating: 0, count: 256)
-        let n = wh_prefill_prompt(model.handle, &o, &st, -1, &prompt, 256)
-        var temps = [temperature]; var res = wh_decoding_result()
-        try check(wh_decode_text(session, 1, &o, &st, prompt, n, &temps, nil, 0, &res))
-        return DecodingResult(hip: res)      // tokens SOT...EOT, tokenLogProbs, avgLogProb, compressionRatio, fallback
+        let n = wh_prefill_prompt(model.handle, &o, &st, o.language_token, &prompt, 256)
+        guard n > 0 else { throw WhisperError.prefillFailed("prefill prompt does not fit") }
+        var out = decoderInputs
+        out.initialPrompt = prompt.prefix(Int(n)).map(Int.init)
+        return out
+    }
+
+    /// decodeText (TextDecoder.swift:541-855): the whole token loop - forced prompt, predictLogits, filters, sampler, stop rules,
+    /// KV / alignment update, progress callback with early stop - runs on the device behind ONE call.
+    public func decodeText(from encoderOutput: any AudioEncoderOutputType, using decoderInputs: any DecodingInputsType,
+                           sampler tokenSampler: TokenSampling, options decoderOptions: DecodingOptions,
+                           callback: TranscriptionCallback?) async throws -> DecodingResult {
+        guard let tokenizer else { throw WhisperError.tokenizerUnavailable() }
+        var o = cOptions(decoderOptions, tokenizer: tokenizer); var st = cSpecial(tokenizer.specialTokens)
+        let prompt = decoderInputs.initialPrompt.map(Int32.init)
+        var temps = [Float((tokenSampler as? GreedyTokenSampler)?.temperature ?? 0)]
+        var res = wh_decoding_result()
+        let box = callback.map { CallbackBox($0, tokenizer) }
+        if let box {        // TranscriptionCallback (Core/Models.swift:728): false stops this window early (earlyStopActor, :731-755)
+            wh_session_set_progress_callback(session, { user, p in
+                let b = Unmanaged<CallbackBox>.fromOpaque(user!).takeUnretainedValue(); let p = p!.pointee
+                let toks = (0..<Int(p.n_tokens)).map { Int(p.tokens[$0]) }
+                let progress = TranscriptionProgress(timings: TranscriptionTimings(), text: p.text.map { String(cString: $0) } ?? "", tokens: toks,
+                                                     avgLogprob: p.avg_logprob, compressionRatio: p.compression_ratio)
+                return (b.fn(progress) ?? true) ? 1 : 0
+            }, Unmanaged.passUnretained(box).toOpaque())
+        }
+        defer { if box != nil { wh_session_set_progress_callback(session, nil, nil) } }
+        try check(wh_decode_text(session, 1, &o, &st, prompt, Int32(prompt.count), &temps, nil, 0, &res))
+        return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
+    }
+
+    /// detectLanguage (TextDecoder.swift:420-539): one step on <|startoftranscript|>, LanguageLogitsFilter, greedy.
+    public func detectLanguage(from encoderOutput: any AudioEncoderOutputType, using decoderInputs: any DecodingInputsType,
+                               sampler tokenSampler: TokenSampling, options: DecodingOptions, temperature: FloatType) async throws -> DecodingResult {
+        guard let tokenizer else { throw WhisperError.tokenizerUnavailable() }
+        var st = cSpecial(tokenizer.specialTokens); var lang: Int32 = -1; var lp: Float = 0
+        try check(wh_detect_language(session, 1, &st, &lang, &lp))
+        let code = tokenizer.decode(tokens: [Int(lang)]).trimmingSpecialTokenCharacters()
+        var r = DecodingResult.emptyResults
+        r.language = code; r.languageProbs = [code: exp(lp)]; r.tokens = [Int(lang)]; r.tokenLogProbs = [[Int(lang): lp]]
+        r.temperature = Float(temperature)
+        return r
+    }
+
+    /// The cache is written in place by the decoder kernels at `token_index`; nothing to scatter on the host.
+    public static func updateKVCache(keyTensor: MLMultiArray, keySlice: MLMultiArray, valueTensor: MLMultiArray, valueSlice: MLMultiArray,
+                                     insertAtIndex index: Int) {}
+
+    // ---- value conversions
+    final class CallbackBox { let fn: TranscriptionCallback; let tok: WhisperTokenizer; init(_ f: @escaping TranscriptionCallback, _ t: WhisperTokenizer) { fn = f; tok = t } }
+
+    func cSpecial(_ s: SpecialTokens) -> wh_special_tokens {
+        var st = wh_special_tokens(); wh_special_tokens_default(model.handle, &st)      // language-token range of the vocabulary size
+        st.end_token = Int32(s.endToken); st.english_token = Int32(s.englishToken); st.no_speech_token = Int32(s.noSpeechToken)
+        st.no_timestamps_token = Int32(s.noTimestampsToken); st.special_token_begin = Int32(s.specialTokenBegin)
+        st.start_of_previous_token = Int32(s.startOfPreviousToken); st.start_of_transcript_token = Int32(s.startOfTranscriptToken)
+        st.time_token_begin = Int32(s.timeTokenBegin); st.transcribe_token = Int32(s.transcribeToken)
+        st.translate_token = Int32(s.translateToken); st.whitespace_token = Int32(s.whitespaceToken)
+        return st
+    }
+
+    func cOptions(_ d: DecodingOptions, tokenizer: WhisperTokenizer) -> wh_decoding_options {
+        var o = wh_decoding_options(); wh_decoding_options_default(&o)
+        o.task = d.task == .translate ? 1 : 0
+        o.language_token = d.language.flatMap { tokenizer.convertTokenToId("<|\($0)|>") }.map(Int32.init) ?? -1
+        o.temperature = d.temperature; o.temperature_increment_on_fallback = d.temperatureIncrementOnFallback
+        o.temperature_fallback_count = Int32(d.temperatureFallbackCount); o.sample_length = Int32(d.sampleLength); o.top_k = Int32(d.topK)
+        o.use_prefill_prompt = d.usePrefillPrompt ? 1 : 0; o.detect_language = d.detectLanguage ? 1 : 0
+        o.skip_special_tokens = d.skipSpecialTokens ? 1 : 0; o.without_timestamps = d.withoutTimestamps ? 1 : 0
+        o.word_timestamps = d.wordTimestamps ? 1 : 0; o.suppress_blank = d.suppressBlank ? 1 : 0
+        o.window_clip_time = d.windowClipTime; o.max_window_seek = d.maxWindowSeek.map(Int32.init) ?? -1
+        o.compression_ratio_threshold = d.compressionRatioThreshold ?? .nan; o.log_prob_threshold = d.logProbThreshold ?? .nan
+        o.first_token_log_prob_threshold = d.firstTokenLogProbThreshold ?? .nan; o.no_speech_threshold = d.noSpeechThreshold ?? .nan
+        o.float16_logits = 1        // FloatType == Float16 on arm64: follow the reference's own numerics
+        // promptTokens / prefixTokens / suppressTokens / clipTimestamps: pointers into arrays the caller keeps alive for the call
+        return o
+    }
+
+    func decodingResult(_ r: wh_decoding_result, options: DecodingOptions, tokenizer: WhisperTokenizer) -> DecodingResult {
+        let n = Int(r.n_tokens)
+        let toks = withUnsafeBytes(of: r.tokens) { Array($0.bindMemory(to: Int32.self).prefix(n)).map(Int.init) }
+        let lps = withUnsafeBytes(of: r.token_logprobs) { Array($0.bindMemory(to: Float.self).prefix(n)) }
+        let lang = r.language_token >= 0 ? tokenizer.decode(tokens: [Int(r.language_token)]).trimmingSpecialTokenCharacters() : (options.language ?? "en")
+        return DecodingResult(language: lang, languageProbs: [lang: 1.0], tokens: toks, tokenLogProbs: zip(toks, lps).map { [$0: $1] },
+                              text: tokenizer.decode(tokens: toks), avgLogProb: r.avg_logprob, noSpeechProb: r.no_speech_prob,
+                              temperature: r.temperature, compressionRatio: r.compression_ratio, cache: nil, timings: nil,
+                              fallback: DecodingFallback(options: options, isFirstTokenLogProbTooLow: r.is_first_token_logprob_too_low != 0,
+                                                         noSpeechProb: r.no_speech_prob, compressionRatio: r.compression_ratio, avgLogProb: r.avg_logprob))
     }
 }
 

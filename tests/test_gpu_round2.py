@@ -45,7 +45,7 @@ def _audio_sensitive(name, seed):
 
 
 def _words(r):
-    return [(w.tokens, round(w.start, 4), round(w.end, 4)) for w in r.allWords()]
+    return [(w.tokens, round(w.start, 4), round(w.end, 4)) for w in r.allWords]
 
 
 def test_fallback_of_one_slot_keeps_the_other_slots_alignment():
@@ -72,7 +72,7 @@ def test_fallback_of_one_slot_keeps_the_other_slots_alignment():
     assert got[keeper].tokens == alone.tokens
     assert _words(got[keeper]) == _words(alone)
     for i in (0, 1):
-        assert len(got[i].allWords()) > 0 and any(w.end > w.start for w in got[i].allWords()), i
+        assert len(got[i].allWords) > 0 and any(w.end > w.start for w in got[i].allWords), i
 
 
 def test_batched_language_detection_prompts_every_slot_with_its_own_language():
@@ -257,11 +257,19 @@ def test_float16_logits_reference_numerics_mode(micro_ml):
     sess = api.Session(model, 1)
     # (1) the filter alone on crafted logits: fp32 and Float16 verdicts differ, the device agrees with the oracle in both modes
     V = dims.n_vocab
-    x = np.zeros(V, np.float32)
-    x[10] = 3.0
-    x[st.timeTokenBegin:] = -30.0
-    x[st.timeTokenBegin + 5] = 3.002
     toks = [st.startOfTranscriptToken, st.englishToken, st.transcribeToken]
+    rule = OD.TimestampRulesFilter._sumOfProbabilityOverTimestampsIsAboveAnyOtherToken
+    x = None
+    for delta in np.arange(1e-4, 4e-3, 1e-4):          # a timestamp logit `delta` above the best text logit: fp32 says "wins",
+        c = np.zeros(V, np.float32)                     # Float16 says "tie" for the deltas below one Float16 ulp of the log-prob
+        c[10] = 3.0
+        c[st.timeTokenBegin:] = -30.0
+        c[st.timeTokenBegin + 5] = np.float32(3.0 + delta)
+        c[st.noTimestampsToken] = -np.inf               # what the filter chain has written before the rule runs
+        if rule(c, st.timeTokenBegin, False) and not rule(c, st.timeTokenBegin, True):
+            x = c
+            break
+    assert x is not None
     for f16 in (False, True):
         got = sess.filterLogits(x, toks, api.DecodingOptions(float16Logits=f16), initialPromptIndex=3)
         flt = OD.create_logits_filters(OD.DecodingOptions(float16Logits=f16), 0, 3, st, True)
@@ -269,7 +277,7 @@ def test_float16_logits_reference_numerics_mode(micro_ml):
         for f in flt:
             ref = f.filterLogits(ref, toks)
         np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
-        assert np.isneginf(got[10]) == (not f16)           # fp32: timestamp mass wins, text masked; Float16: a tie, text stays
+        assert bool(np.isneginf(got[10])) == (not f16)  # fp32: timestamp mass wins, text masked; Float16: a tie, text stays
     # (2) the whole loop
     sess.padOrTrim(synthetic_chunk(31)); sess.logMelSpectrogram(1); sess.encodeFeatures(1); sess.prepareDecoderInputs(1)
     enc = sess.getEncoderOutput(0)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""GPU timing probe (development tool): encoder + cross-K/V milliseconds per chunk and the per-kernel HIP-event table.
+    python tools/time_encoder.py large-v3 8,32      (WH_GEMM_TUNE / WH_NO_GEMM256 select kernel variants)"""
+import ctypes, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whisperkit_amd import api, weights
+from whisperkit_amd.synth import synthetic_chunk
+
+name = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
+batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "8").split(",")]
+dims = weights.MODEL_DIMS[name]
+model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
+for B in batches:
+    s = api.Session(model, B)
+    for b in range(B):
+        s.padOrTrim(synthetic_chunk(1234 + b), b)
+    s.logMelSpectrogram(B)
+    ts = []
+    for _ in range(6):
+        s.synchronize(); a = time.perf_counter(); s.encodeFeatures(B); s.synchronize(); b_ = time.perf_counter(); s.prepareDecoderInputs(B); s.synchronize()
+        ts.append((b_ - a, time.perf_counter() - b_))
+    med = np.median(np.array(ts[1:]), axis=0)
+    lib = s.lib
+    nk = lib.wh_kernel_kind_count()
+    avg = (ctypes.c_double * nk)(); cnt = (ctypes.c_int32 * nk)()
+    api._check(lib.wh_measure_kernels(s.handle, B, 0, avg, cnt))
+    print(json.dumps({"model": name, "B": B, "tune": os.environ.get("WH_GEMM_TUNE", "0"), "encoder_ms_per_chunk": round(med[0] * 1e3 / B, 4),
+                      "cross_kv_ms_per_chunk": round(med[1] * 1e3 / B, 4),
+                      "kernels_us": {lib.wh_kernel_kind_name(k).decode(): round(avg[k], 1) for k in range(nk) if cnt[k]}}), flush=True)
+    s.close()

@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 // K-tile.  An LDS row is the 128-byte K-slice of one operand row; the DMA image is lane-linear, so the bank swizzle
 // (16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for every lane group) is applied
 // to the SOURCE address: a row's 8 chunks are fetched permuted inside the same 128-byte line, coalescing intact.
-// Workgroup ids are remapped so that the 8 XCDs (id % 8) each walk their own contiguous range of tiles, N fastest:
-// an XCD's L2 keeps one 256-row A panel and the weight panel it is sweeping.
+// Workgroup ids are remapped so that the 8 XCDs (id % 8) each walk their own contiguous range of tiles, in 8 x 4 blocks
+// (grouped walk below): the tiles an XCD works on concurrently share their A and weight panels through its L2.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     constexpr int TM = 4, TN = 2;
@@ -269,8 +269,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int tiles_n = (a.N + 255) >> 8;
-    const int m0 = (wg / tiles_n) << 8, n0 = (wg % tiles_n) << 8;
+    // Grouped tile walk: ids run M-fastest inside groups of 8 tile rows, so the 32 workgroups an XCD runs at a time form an
+    // 8 x 4 block of output tiles that shares 8 A panels and 4 weight panels through that XCD's L2 (12 panel streams per 32 tiles
+    // instead of 1 + 32 with an N-fastest walk: PMC, large-v3 fc1 at 32 chunks fetched 2.8 GB for 0.14 GB of operands).
+    const int tiles_n = (a.N + 255) >> 8, tiles_m = (a.M + 255) >> 8;
+    constexpr int GM = 8;
+    const int gsz = GM * tiles_n, grp = wg / gsz, first_m = grp * GM;
+    const int gm = min(tiles_m - first_m, GM), in_g = wg - grp * gsz;
+    const int m0 = (first_m + in_g % gm) << 8, n0 = (in_g / gm) << 8;
 
     // ---- staging addresses: round j of an operand covers rows j*64 + (tid >> 3), LDS slot tid & 7
     const int srow = tid >> 3;
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 4096 + slot);
+                if (a.tune & 1) __builtin_amdgcn_s_setprio(1);     // WH_GEMM_TUNE bit 0 (A/B knob): matrix cluster above the partner wave's DMA / LDS issue
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
                         if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
                     }
+                if (a.tune & 1) __builtin_amdgcn_s_setprio(0);
             }
         }
         if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
@@ -350,10 +358,13 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
     // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
+    static const int tune = [] { const char* e = getenv("WH_GEMM_TUNE"); return e ? atoi(e) : 0; }();
     if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
         static PerDeviceOnce raised;
         raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
-        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(a);
+        GemmArgs at = a;
+        at.tune = tune;
+        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(at);
         return;
     }
     // small problems get 64x64 tiles so that more than a handful of CUs are busy

@@ -98,6 +98,7 @@ struct GemmArgs {
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
     int max_batch = 0;         // EPI_CROSS_KV: slot stride of the head-major cross K/V layout
     int prof_kind = -1;        // KernelKind of this launch (measurement only)
+    int tune = 0;              // WH_GEMM_TUNE bits (A/B knobs of the 256-tile kernel)
 };
 
 void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st);
