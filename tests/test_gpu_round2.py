@@ -333,3 +333,28 @@ def test_alignment_postprocess_option_matches_openai_style_normalisation(micro):
         np.testing.assert_array_equal(sess.getAlignmentWeights(b), plain[b])
     with pytest.raises(api.WhisperError):
         sess.setAlignmentPostprocess(True, 4)                      # even width
+
+
+def test_batch_above_32_slots_uses_two_batch_tiles(micro):
+    """The decoder's MFMA batch tile is 32 slots wide; a session of 40 runs two tiles (the second one 8 live + 24 padding columns).
+    Every slot must decode exactly like it does alone, on both sides of the tile boundary."""
+    dims, _, model = micro
+    B = 40
+    xs = [synthetic_chunk(1500 + b) for b in range(B)]
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12, wordTimestamps=True)
+    sb = api.Session(model, B)
+    for b, x in enumerate(xs):
+        sb.padOrTrim(x, b)
+    sb.logMelSpectrogram(B); sb.encodeFeatures(B); sb.prepareDecoderInputs(B)
+    prompt = sb.prefillPrompt(opts)
+    rb = sb.decodeText(prompt, opts, batch=B)
+    s1 = api.Session(model, 1)
+    for b in (0, 31, 32, 39):
+        s1.padOrTrim(xs[b]); s1.logMelSpectrogram(1); s1.encodeFeatures(1); s1.prepareDecoderInputs(1)
+        r1 = s1.decodeText(prompt, opts)[0]
+        assert rb[b].tokens == r1.tokens and rb[b].tokenLogProbs == r1.tokenLogProbs, b
+        np.testing.assert_array_equal(sb.getAlignmentWeights(b)[:13], s1.getAlignmentWeights(0)[:13])
+    # the step API across the tile boundary
+    got = sb.predictLogits([50257] * B, [0] * B)
+    s1.padOrTrim(xs[33]); s1.logMelSpectrogram(1); s1.encodeFeatures(1); s1.prepareDecoderInputs(1)
+    np.testing.assert_array_equal(got[33], s1.predictLogits([50257], [0])[0])

@@ -97,7 +97,16 @@ __device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float
 // key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
 // before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
 // o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
-template <int PASSES, typename GetN, typename QFix>
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 load_kv16(const f16* p) {      // 16 bytes of a K / V row; NT: non-temporal (streamed once per step)
+    if constexpr (NT) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return uint4{v[0], v[1], v[2], v[3]};
+    } else return *reinterpret_cast<const uint4*>(p);
+}
+
+template <int PASSES, bool NT, typename GetN, typename QFix>
 __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
                                              GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
                                              float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
@@ -109,12 +118,12 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = kg + 32 * i;
-        kreg[i] = key < n_load ? *reinterpret_cast<const uint4*>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        kreg[i] = key < n_load ? load_kv16<NT>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = kg + 32 * i;
-        vreg[i] = key < n_load ? *reinterpret_cast<const uint4*>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        vreg[i] = key < n_load ? load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
     float qv[8];
     {
@@ -200,12 +209,12 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     float* raw = nullptr;
     auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, PASSES * 32) : -1; };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, PASSES * 32, get_n, qfix, &raw, red, osum, o_l, &m, &l))
+    if (!attend_block<PASSES, false>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, PASSES * 32, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
 
-template <int PASSES>
+template <int PASSES, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     constexpr int KPB = PASSES * 32;
     __shared__ float red[16], osum[256], o_l[64];
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         return n;
     };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<PASSES>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
+    if (!attend_block<PASSES, NT>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
         return;
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
@@ -649,11 +658,20 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
     const dim3 grid(S, H, B);
     static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
-    if (S == 3) dec_cross_attn_kernel<16><<<grid, 256, xlds, st>>>(at);
-    else if (S == 4) dec_cross_attn_kernel<12><<<grid, 256, xlds, st>>>(at);
-    else if (S == 6) dec_cross_attn_kernel<8><<<grid, 256, xlds, st>>>(at);
-    else if (S == 12) dec_cross_attn_kernel<4><<<grid, 256, xlds, st>>>(at);
-    else dec_cross_attn_kernel<2><<<grid, 256, xlds, st>>>(at);
+    static const int nt = env_int("WH_XATT_NT", 0);      // A/B knob: non-temporal K / V loads
+    if (nt) {
+        if (S == 3) dec_cross_attn_kernel<16, true><<<grid, 256, xlds, st>>>(at);
+        else if (S == 4) dec_cross_attn_kernel<12, true><<<grid, 256, xlds, st>>>(at);
+        else if (S == 6) dec_cross_attn_kernel<8, true><<<grid, 256, xlds, st>>>(at);
+        else if (S == 12) dec_cross_attn_kernel<4, true><<<grid, 256, xlds, st>>>(at);
+        else dec_cross_attn_kernel<2, true><<<grid, 256, xlds, st>>>(at);
+        return;
+    }
+    if (S == 3) dec_cross_attn_kernel<16, false><<<grid, 256, xlds, st>>>(at);
+    else if (S == 4) dec_cross_attn_kernel<12, false><<<grid, 256, xlds, st>>>(at);
+    else if (S == 6) dec_cross_attn_kernel<8, false><<<grid, 256, xlds, st>>>(at);
+    else if (S == 12) dec_cross_attn_kernel<4, false><<<grid, 256, xlds, st>>>(at);
+    else dec_cross_attn_kernel<2, false><<<grid, 256, xlds, st>>>(at);
 }
 
 // One decoder step for all slots: embed -> per layer [QKV, self-attention, out projection, cross query, cross-attention, cross out
