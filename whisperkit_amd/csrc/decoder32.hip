@@ -118,7 +118,12 @@ __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, flo
 }
 
 // ---------------------------------------------------------------------------------------------- the projection kernel
-template <int MODE, bool HILO, int TC>
+// TWA > 0: the wave's k-tile count is the compile-time constant TWA and ALL of its weight tiles are requested in one burst
+// (4 VGPRs each) right after the first two plane chunks - one HBM round trip per wave instead of one per chunk pair; the planes
+// (L2 hits) stream in chunks of TC tiles.  Memory returns are in order per wave, so what is issued before the weight burst
+// (plane chunks 0, 1) can be consumed while the burst is still landing and what is issued after it arrives behind it.
+// TWA == 0: generic fallback, weights and planes in double-buffered chunks of TC tiles (any tw that is a multiple of TC).
+template <int MODE, bool HILO, int TC, int TWA>
 __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
     __shared__ float red[4][16][64];                 // the four waves' partial tiles
@@ -182,41 +187,75 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
 
     // ---- weight stream x activation planes on the matrix cores
     f32x16 acc_h = {0}, acc_l = {0};
-    u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
-    auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
+    auto stats_to_lds = [&]() {
+        // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
+        if constexpr (kLN) {
+            float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < TC; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64);     // streamed once: nt
-#pragma unroll
-        for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
-        if constexpr (HILO) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
+            for (int i = 0; i < 5; ++i)
+                if (sub + 8 * i < a.n_stat) chan32(cn, cm, cM2, sp[i].x, sp[i].y);
+            st_l[sub][j][0] = cn; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
         }
     };
-    auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
+    if constexpr (TWA > 0) {
+        constexpr int NPC = TWA / TC;                  // plane chunks
+        u32x4 w[TWA], pa[TC], qa[HILO ? TC : 1], pb[TC], qb[HILO ? TC : 1];
+        auto ldp = [&](u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
-            acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h, 0, 0, 0);
-            if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l, 0, 0, 0);
+            for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
+            if constexpr (HILO) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
+            }
+        };
+        ldp(pa, qa, 0);
+        if constexpr (NPC > 1) ldp(pb, qb, 1);
+#pragma unroll
+        for (int i = 0; i < TWA; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);     // the whole weight slab of this wave: nt, one burst
+        __builtin_amdgcn_sched_barrier(0);     // pin the burst here: the scheduler would otherwise sink the loads next to their MFMAs (depth 2)
+        stats_to_lds();
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const f16x8 wf = __builtin_bit_cast(f16x8, w[c * TC + i]);
+                acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, (c & 1) ? pb[i] : pa[i]), acc_h, 0, 0, 0);
+                if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, (c & 1) ? qb[i] : qa[i]), acc_l, 0, 0, 0);
+            }
+            if (c + 2 < NPC) { if (c & 1) ldp(pb, qb, c + 2); else ldp(pa, qa, c + 2); }
         }
-    };
-    const int nch = a.tw / TC;
-    ld(wa, ha, la, 0);
-    // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
-    if constexpr (kLN) {
-        float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
+    } else {
+        u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
+        auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (sub + 8 * i < a.n_stat) chan32(cn, cm, cM2, sp[i].x, sp[i].y);
-        st_l[sub][j][0] = cn; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
-    }
+            for (int i = 0; i < TC; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64);     // streamed once: nt
+#pragma unroll
+            for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
+            if constexpr (HILO) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
+            }
+        };
+        auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
+                acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h, 0, 0, 0);
+                if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l, 0, 0, 0);
+            }
+        };
+        const int nch = a.tw / TC;
+        ld(wa, ha, la, 0);
+        stats_to_lds();
 #pragma unroll 1
-    for (int c = 0; c < nch; c += 2) {
-        if (c + 1 < nch) ld(wb, hb, lb, c + 1);
-        mm(wa, ha, la);
-        if (c + 2 < nch) ld(wa, ha, la, c + 2);
-        if (c + 1 < nch) mm(wb, hb, lb);
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) ld(wb, hb, lb, c + 1);
+            __builtin_amdgcn_sched_barrier(0);      // loads of the next chunk stay ahead of this chunk's MFMAs
+            mm(wa, ha, la);
+            if (c + 2 < nch) ld(wa, ha, la, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nch) mm(wb, hb, lb);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = HILO ? fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]) : acc_h[r];
@@ -396,11 +435,26 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
 template <int MODE, bool HILO>
 static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
-    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
-    else if (tw % 6 == 0) dec32_proj_kernel<MODE, HILO, 6><<<grid, 256, 0, st>>>(a);
-    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
-    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
-    else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
+    static const int no_burst = env_int32("WH_D32_NO_BURST", 0);      // A/B knob: 1 = the chunked fallback for every shape
+    if (!no_burst) {        // whole-slab weight burst for the per-wave tile counts of the Whisper widths (d = 128 ... 1280)
+        switch (tw) {
+            case 20: dec32_proj_kernel<MODE, HILO, 5, 20><<<grid, 256, 0, st>>>(a); return;
+            case 16: dec32_proj_kernel<MODE, HILO, 4, 16><<<grid, 256, 0, st>>>(a); return;
+            case 12: dec32_proj_kernel<MODE, HILO, 4, 12><<<grid, 256, 0, st>>>(a); return;
+            case 8: dec32_proj_kernel<MODE, HILO, 4, 8><<<grid, 256, 0, st>>>(a); return;
+            case 6: dec32_proj_kernel<MODE, HILO, 3, 6><<<grid, 256, 0, st>>>(a); return;
+            case 5: dec32_proj_kernel<MODE, HILO, 5, 5><<<grid, 256, 0, st>>>(a); return;
+            case 4: dec32_proj_kernel<MODE, HILO, 4, 4><<<grid, 256, 0, st>>>(a); return;
+            case 3: dec32_proj_kernel<MODE, HILO, 3, 3><<<grid, 256, 0, st>>>(a); return;
+            case 2: dec32_proj_kernel<MODE, HILO, 2, 2><<<grid, 256, 0, st>>>(a); return;
+            case 1: dec32_proj_kernel<MODE, HILO, 1, 1><<<grid, 256, 0, st>>>(a); return;
+            default: break;
+        }
+    }
+    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5, 0><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4, 0><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, 0><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1, 0><<<grid, 256, 0, st>>>(a);
 }
 
 void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) {
