@@ -100,30 +100,29 @@ __device__ __forceinline__ void d32_resid_tail(const float (&xn)[4], bool valid,
     }
 }
 
-// Chan's pairwise update of (count, mean, M2) with a 32-sample partial (mean_b, M2_b)
-__device__ __forceinline__ void chan32(float& cn, float& cm, float& cM2, float mb, float M2b) {
-    const float nn = cn + 32.0f;
+// Chan's pairwise update of (count, mean, M2).  chan32_k: the k-th 32-sample partial (mean_b, M2_b) joins k earlier ones, so the
+// weights 32 / n and n_a 32 / n are the constants 1 / (k + 1) and 32 k / (k + 1) - no division on the dependent chain.
+template <int K>
+__device__ __forceinline__ void chan32_k(float& cm, float& cM2, float mb, float M2b) {
+    constexpr float w = 1.0f / (float)(K + 1), w2 = 32.0f * (float)K / (float)(K + 1);
     const float delta = mb - cm;
-    cm += delta * (32.0f / nn);
-    cM2 += M2b + delta * delta * (cn * 32.0f / nn);
-    cn = nn;
+    cm = fmaf(delta, w, cm);
+    cM2 += fmaf(delta * delta, w2, M2b);
 }
 __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, float nb, float mb, float M2b) {
     if (nb == 0.0f) return;
-    const float nn = cn + nb;
+    const float nn = cn + nb, rn = __frcp_rn(nn);
     const float delta = mb - cm;
-    cm += delta * (nb / nn);
-    cM2 += M2b + delta * delta * (cn * nb / nn);
+    cm = fmaf(delta, nb * rn, cm);
+    cM2 += fmaf(delta * delta, cn * nb * rn, M2b);
     cn = nn;
 }
 
 // ---------------------------------------------------------------------------------------------- the projection kernel
-// TWA > 0: the wave's k-tile count is the compile-time constant TWA and ALL of its weight tiles are requested in one burst
-// (4 VGPRs each) right after the first two plane chunks - one HBM round trip per wave instead of one per chunk pair; the planes
-// (L2 hits) stream in chunks of TC tiles.  Memory returns are in order per wave, so what is issued before the weight burst
-// (plane chunks 0, 1) can be consumed while the burst is still landing and what is issued after it arrives behind it.
-// TWA == 0: generic fallback, weights and planes in double-buffered chunks of TC tiles (any tw that is a multiple of TC).
-template <int MODE, bool HILO, int TC, int TWA>
+// Weights and planes stream in double-buffered chunks of TC k-tiles (tw is a multiple of TC); sched_barriers keep the loads of the
+// next chunk ahead of the current chunk's MFMAs.  Measured and rejected: requesting a wave's whole weight slab (20 tiles, 80 VGPRs) in
+// one burst ahead of the MFMAs - 2-3 % slower at 8 and 32 slots (profiles/r02j_*): the per-launch latency is not the weight round trips.
+template <int MODE, bool HILO, int TC>
 __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
     __shared__ float red[4][16][64];                 // the four waves' partial tiles
@@ -146,6 +145,8 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     const int gb = bt * 32 + j;
     const bool valid = gb < a.batch;
 
+#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(blockIdx.x & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+    D32_STAMP(0);
     // ---- small epilogue operands, requested first (memory returns are in order per wave: they arrive under the weight stream)
     float2 sp[5] = {};
     if constexpr (kLN) {
@@ -190,41 +191,16 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     auto stats_to_lds = [&]() {
         // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
         if constexpr (kLN) {
-            float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-                if (sub + 8 * i < a.n_stat) chan32(cn, cm, cM2, sp[i].x, sp[i].y);
-            st_l[sub][j][0] = cn; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
+            float cm = sp[0].x, cM2 = sp[0].y;                     // n_stat >= 8 is not required: a thread without partials writes count 0
+            const int mine = sub < a.n_stat ? (a.n_stat - sub + 7) >> 3 : 0;
+            if (mine > 1) chan32_k<1>(cm, cM2, sp[1].x, sp[1].y);
+            if (mine > 2) chan32_k<2>(cm, cM2, sp[2].x, sp[2].y);
+            if (mine > 3) chan32_k<3>(cm, cM2, sp[3].x, sp[3].y);
+            if (mine > 4) chan32_k<4>(cm, cM2, sp[4].x, sp[4].y);
+            st_l[sub][j][0] = 32.0f * (float)mine; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
         }
     };
-    if constexpr (TWA > 0) {
-        constexpr int NPC = TWA / TC;                  // plane chunks
-        u32x4 w[TWA], pa[TC], qa[HILO ? TC : 1], pb[TC], qb[HILO ? TC : 1];
-        auto ldp = [&](u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
-            if constexpr (HILO) {
-#pragma unroll
-                for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
-            }
-        };
-        ldp(pa, qa, 0);
-        if constexpr (NPC > 1) ldp(pb, qb, 1);
-#pragma unroll
-        for (int i = 0; i < TWA; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);     // the whole weight slab of this wave: nt, one burst
-        __builtin_amdgcn_sched_barrier(0);     // pin the burst here: the scheduler would otherwise sink the loads next to their MFMAs (depth 2)
-        stats_to_lds();
-#pragma unroll
-        for (int c = 0; c < NPC; ++c) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-                const f16x8 wf = __builtin_bit_cast(f16x8, w[c * TC + i]);
-                acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, (c & 1) ? pb[i] : pa[i]), acc_h, 0, 0, 0);
-                if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, (c & 1) ? qb[i] : qa[i]), acc_l, 0, 0, 0);
-            }
-            if (c + 2 < NPC) { if (c & 1) ldp(pb, qb, c + 2); else ldp(pa, qa, c + 2); }
-        }
-    } else {
+    {
         u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
         auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
@@ -246,20 +222,24 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
         };
         const int nch = a.tw / TC;
         ld(wa, ha, la, 0);
-        stats_to_lds();
+        D32_STAMP(1);
 #pragma unroll 1
         for (int c = 0; c < nch; c += 2) {
             if (c + 1 < nch) ld(wb, hb, lb, c + 1);
             __builtin_amdgcn_sched_barrier(0);      // loads of the next chunk stay ahead of this chunk's MFMAs
             mm(wa, ha, la);
+            if (c == 0) D32_STAMP(2);
             if (c + 2 < nch) ld(wa, ha, la, c + 2);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < nch) mm(wb, hb, lb);
         }
     }
+    stats_to_lds();       // after the stream: the statistics are epilogue operands (timeline probe: waiting for them up front cost 1 us per launch)
+    D32_STAMP(3);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = HILO ? fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]) : acc_h[r];
     __syncthreads();
+    D32_STAMP(4);
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
@@ -301,6 +281,7 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
         }
     }
 
+    D32_STAMP(5);
     // ---- epilogues
     float y[4];
     if constexpr (kLN) {
@@ -382,6 +363,7 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
             }
         }
     }
+    D32_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------- embedding
@@ -435,30 +417,17 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
 template <int MODE, bool HILO>
 static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
-    static const int no_burst = env_int32("WH_D32_NO_BURST", 0);      // A/B knob: 1 = the chunked fallback for every shape
-    if (!no_burst) {        // whole-slab weight burst for the per-wave tile counts of the Whisper widths (d = 128 ... 1280)
-        switch (tw) {
-            case 20: dec32_proj_kernel<MODE, HILO, 5, 20><<<grid, 256, 0, st>>>(a); return;
-            case 16: dec32_proj_kernel<MODE, HILO, 4, 16><<<grid, 256, 0, st>>>(a); return;
-            case 12: dec32_proj_kernel<MODE, HILO, 4, 12><<<grid, 256, 0, st>>>(a); return;
-            case 8: dec32_proj_kernel<MODE, HILO, 4, 8><<<grid, 256, 0, st>>>(a); return;
-            case 6: dec32_proj_kernel<MODE, HILO, 3, 6><<<grid, 256, 0, st>>>(a); return;
-            case 5: dec32_proj_kernel<MODE, HILO, 5, 5><<<grid, 256, 0, st>>>(a); return;
-            case 4: dec32_proj_kernel<MODE, HILO, 4, 4><<<grid, 256, 0, st>>>(a); return;
-            case 3: dec32_proj_kernel<MODE, HILO, 3, 3><<<grid, 256, 0, st>>>(a); return;
-            case 2: dec32_proj_kernel<MODE, HILO, 2, 2><<<grid, 256, 0, st>>>(a); return;
-            case 1: dec32_proj_kernel<MODE, HILO, 1, 1><<<grid, 256, 0, st>>>(a); return;
-            default: break;
-        }
-    }
-    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5, 0><<<grid, 256, 0, st>>>(a);
-    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4, 0><<<grid, 256, 0, st>>>(a);
-    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, 0><<<grid, 256, 0, st>>>(a);
-    else dec32_proj_kernel<MODE, HILO, 1, 0><<<grid, 256, 0, st>>>(a);
+    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
+    else if (tw % 6 == 0) dec32_proj_kernel<MODE, HILO, 6><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
 }
 
+unsigned long long* debug_buffer();
 void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) {
     P32Args a = a_in;
+    a.dbg = (debug_buffer() && a.prof_kind >= 0) ? debug_buffer() + (size_t)a.prof_kind * 4096 * 8 : nullptr;   // WH_DBG=1 timeline probe
     const bool hilo = a.zlo != nullptr;
     a.ks = dec32_ksplit(mode, a.N, a.K, !hilo);
     a.tw = a.K / (64 * a.ks);

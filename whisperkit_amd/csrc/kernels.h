@@ -223,6 +223,7 @@ struct P32Args {
     float* part; int* ticket;
     const SeqState* seq;
     int prof_kind;
+    unsigned long long* dbg;     // WH_DBG=1: 8 wall-clock stamps per workgroup (tools/probe_dec32.py)
 };
 void launch_dec32_proj(int mode, const P32Args& a, int n_bt, hipStream_t st);
 void launch_dec32_embed(const f16* emb, const float* pos, const SeqState* seq, int batch, int d, int n_vocab, int n_bt, float* x,
