@@ -8,9 +8,11 @@ it - "PCM in host memory -> token ids + segments on host": padOrTrim from host f
 encoder -> cross-K/V projection -> greedy token loop (WhisperKit decodeText semantics, filters + sampler on device) ->
 findSeekPointAndSegments per chunk on the host -> result records (+ all-gather over RCCL when N > 1).
 
-Default workload = BASELINE.json configs[3]'s model and chunk shape: whisper-large-v3 (128 mel), 96 x 30 s chunks resident per GPU
-as 3 decode batches of 32 in flight (one session / HIP stream / host thread each: the encoder GEMMs and the latency-bound
-projection kernels of one batch overlap the HBM-bound cross-attention stream of the others), greedy.  A step processes one batch of 32 chunks.  Weights are random-init (no checkpoints in
+Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step and GPU
+(two 32-slot MFMA batch tiles per decode launch), 3 steps in flight (one session / HIP stream / host thread each: the encoder
+GEMMs and the latency-bound projection kernels of one batch overlap the HBM-bound cross-attention stream of the others), greedy.
+Measured alternatives on one MI355X (profiles/r02n_*, r02o_*): 32 x 3 in flight 1521 audio-s/s, 64 x 2 1621, 64 x 3 1674, 64 x 4 1715,
+96 x 2 1695, 128 x 1 1615, 128 x 2 1735.  Weights are random-init (no checkpoints in
 the image), so EOT is never the argmax and the loop runs to the reference's length cap (sampleLength 224 -> 223 decoder forward
 passes per chunk): the decode length is fixed and comparable across runs.  Round 1's configuration (8 chunks per step, 3 in
 flight) and the other BASELINE configs are measured after the headline and reported under "other_configs".
@@ -381,7 +383,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="steps (batches of --batch chunks) in flight per GPU, each on its own session / HIP stream")
     ap.add_argument("--serial-reference", action="store_true", default=True)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--batch", type=int, default=32, help="30 s chunks per GPU per step (one decode batch)")
+    ap.add_argument("--batch", type=int, default=64, help="30 s chunks per GPU per step (one decode batch = batch / 32 MFMA batch tiles)")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")
@@ -416,7 +418,7 @@ def main():
     main_cfg = run_config(args, args.model, args.batch, args.inflight, args.steps, args.warmup, world, rank, local_rank, dev,
                           want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline))
     other = {}
-    headline = (args.model, args.batch) == ("large-v3", 32)
+    headline = (args.model, args.batch) == ("large-v3", 64)
     extra = rank == 0 and world == 1 and not args.no_other_configs
 
     def brief(o, n):
@@ -428,9 +430,9 @@ def main():
         other["round-1 headline configuration: whisper-large-v3, 8 x 30 s chunks per step, 3 steps in flight, greedy, 1 GPU"] = brief(o, 9)
         saved = args.sample_length
         args.sample_length = 64
-        o = run_config(args, "large-v3", 32, 2, 6, 2, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        o = run_config(args, "large-v3", 64, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
         args.sample_length = saved
-        other["whisper-large-v3, 32 chunks per step, 2 in flight, 64-token run (sampleLength 64, SURVEY 8d)"] = brief(o, 6)
+        other["whisper-large-v3, 64 chunks per step, 3 in flight, 64-token run (sampleLength 64, SURVEY 8d)"] = brief(o, 6)
         other["configs[4] whisper-large-v3, 10 min audio in 30 s VAD chunks, temperature ladder forced once, 1 GPU"] = long_audio_config(args, local_rank)
         _MODELS.pop("large-v3")[0].close()
     if extra and (args.model, args.batch) != ("tiny.en", 1):

@@ -9,7 +9,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- py
 DB=$(ls /tmp/${TAG}_prof/*.db /tmp/${TAG}_prof/*/*.db 2>/dev/null | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats.csv 2> $R/${TAG}_summary.err; head -12 $R/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d /tmp/${TAG}_pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_run.py large-v3 32 8 > $R/${TAG}_pmc_$C.log 2>&1; echo pmc $C rc=$?
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d /tmp/${TAG}_pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_run.py large-v3 64 8 > $R/${TAG}_pmc_$C.log 2>&1; echo pmc $C rc=$?
   DB=$(ls /tmp/${TAG}_pmc_$C/*.db /tmp/${TAG}_pmc_$C/*/*.db 2>/dev/null | head -1)
   python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $DB > $R/${TAG}_pmc_$C.csv 2>> $R/${TAG}_pmc_$C.log
 done

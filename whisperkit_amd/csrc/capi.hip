@@ -369,7 +369,7 @@ static int dalloc(T** p, size_t n, bool zero = true) {
 
 extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
-    if (max_batch < 1 || max_batch > 64) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 64]", max_batch);
+    if (max_batch < 1 || max_batch > 128) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 128]", max_batch);
     WH_HIP(hipSetDevice(m->device));
     wh_session* s = new wh_session();
     s->m = m; s->B = max_batch;

@@ -417,9 +417,10 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
 template <int MODE, bool HILO>
 static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
+    // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
     if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
-    else if (tw % 6 == 0) dec32_proj_kernel<MODE, HILO, 6><<<grid, 256, 0, st>>>(a);
     else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
+    else if (tw % 3 == 0) dec32_proj_kernel<MODE, HILO, 3><<<grid, 256, 0, st>>>(a);
     else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
     else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
 }
