@@ -132,7 +132,13 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_rt = (a.N + 31) >> 5;
-    const int rt = blockIdx.x % n_rt, ksi = blockIdx.x / n_rt, bt = blockIdx.y;
+    // Workgroup id -> (row tile, K slice, batch tile): ids x + 8 t of one group of 8 share the weight slab x and differ in the batch
+    // tile t, so the readers of a slab are dispatched back to back onto the SAME XCD (id % 8) and the slab crosses HBM once, whatever
+    // the parity of the tile count (PMC at 64 slots before this: the 1621 logits tiles fetched 273 MB for 133 MB of weights).
+    const int grp8 = blockIdx.x / (8 * a.n_bt), in8 = blockIdx.x % (8 * a.n_bt);
+    const int xw = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
+    if (xw >= n_rt * a.ks) return;          // padding of the last group (workgroup-uniform)
+    const int rt = xw % n_rt, ksi = xw / n_rt;
     const int KT = a.K >> 4;
     const int kt0 = (ksi * 4 + wave) * a.tw;
     const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)rt * KT + kt0) * 64 + lane;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
     const int gb = bt * 32 + j;
     const bool valid = gb < a.batch;
 
-#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(blockIdx.x & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(xw & 4095) * 8 + (i)] = wall_clock64(); } while (0)
     D32_STAMP(0);
     // ---- small epilogue operands, requested first (memory returns are in order per wave: they arrive under the weight stream)
     float2 sp[5] = {};
@@ -432,7 +438,9 @@ void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) 
     const bool hilo = a.zlo != nullptr;
     a.ks = dec32_ksplit(mode, a.N, a.K, !hilo);
     a.tw = a.K / (64 * a.ks);
-    const dim3 grid(((a.N + 31) / 32) * a.ks, n_bt);
+    a.n_bt = n_bt;
+    const int nx = ((a.N + 31) / 32) * a.ks;
+    const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * n_bt));
     ProfScope ps_(a.prof_kind, st);
     switch (mode) {
         case P32_QKV: launch_tc<P32_QKV, true>(a, grid, st); break;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
                     if constexpr (EPI == EPI_F16) {
                         a.out16[(size_t)m * a.ldc + n] = (f16)x;
                     } else if constexpr (EPI == EPI_GELU_F16) {
-                        a.out16[(size_t)m * a.ldc + n] = (f16)gelu_erf(x);
+                        a.out16[(size_t)m * a.ldc + n] = (f16)gelu_erf_fast(x);
                     } else if constexpr (EPI == EPI_RESID_F32) {
                         a.out32[(size_t)m * a.ldc + n] += x;
                     } else if constexpr (EPI == EPI_F32) {
@@ -80,10 +80,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
                         dst[((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63)] = (f16)x;
                     } else if constexpr (EPI == EPI_CONV1) {
                         int bb = m / a.rows_per_batch_out, t = m - bb * a.rows_per_batch_out;
-                        a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf(x);
+                        a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf_fast(x);
                     } else if constexpr (EPI == EPI_CONV2) {
                         int t = m % a.rows_per_batch_out;
-                        a.out32[(size_t)m * a.ldc + n] = gelu_erf(x) + a.pos[(size_t)t * a.ldc + n];
+                        a.out32[(size_t)m * a.ldc + n] = gelu_erf_fast(x) + a.pos[(size_t)t * a.ldc + n];
                     }
                 }
             }
@@ -117,7 +117,7 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
                     *reinterpret_cast<f16x4*>(a.out16 + (size_t)m * a.ldc + n) = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
                 } else if constexpr (EPI == EPI_GELU_F16) {
                     *reinterpret_cast<f16x4*>(a.out16 + (size_t)m * a.ldc + n) =
-                        f16x4{(f16)gelu_erf(v0), (f16)gelu_erf(v1), (f16)gelu_erf(v2), (f16)gelu_erf(v3)};
+                        f16x4{(f16)gelu_erf_fast(v0), (f16)gelu_erf_fast(v1), (f16)gelu_erf_fast(v2), (f16)gelu_erf_fast(v3)};
                 } else if constexpr (EPI == EPI_RESID_F32) {
                     float4* p = reinterpret_cast<float4*>(a.out32 + (size_t)m * a.ldc + n);
                     float4 o = *p;
@@ -136,11 +136,11 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
                     *reinterpret_cast<f16x4*>(dst) = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
                 } else if constexpr (EPI == EPI_CONV1) {
                     *reinterpret_cast<f16x4*>(a.out16 + ((size_t)bb * kFramesPad + t + 1) * a.ldc + n) =
-                        f16x4{(f16)gelu_erf(v0), (f16)gelu_erf(v1), (f16)gelu_erf(v2), (f16)gelu_erf(v3)};
+                        f16x4{(f16)gelu_erf_fast(v0), (f16)gelu_erf_fast(v1), (f16)gelu_erf_fast(v2), (f16)gelu_erf_fast(v3)};
                 } else if constexpr (EPI == EPI_CONV2) {
                     const float4 ps = *reinterpret_cast<const float4*>(a.pos + (size_t)t * a.ldc + n);
                     *reinterpret_cast<float4*>(a.out32 + (size_t)m * a.ldc + n) =
-                        float4{gelu_erf(v0) + ps.x, gelu_erf(v1) + ps.y, gelu_erf(v2) + ps.z, gelu_erf(v3) + ps.w};
+                        float4{gelu_erf_fast(v0) + ps.x, gelu_erf_fast(v1) + ps.y, gelu_erf_fast(v2) + ps.z, gelu_erf_fast(v3) + ps.w};
                 }
             }
         }
@@ -249,15 +249,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- 256 x 256 x 64 tile
-// Large-problem path (encoder GEMMs at batch >= 2, cross-K/V projection): 8 waves (2 along M x 4 along N, wave tile
-// 128 x 64 = 4 x 2 MFMA tiles), operands staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
-// ds_write pass) into two 64 KB stages - the DMA of K-tile t+1 is in flight under the MFMAs of tile t, one barrier per
-// K-tile.  An LDS row is the 128-byte K-slice of one operand row; the DMA image is lane-linear, so the bank swizzle
-// (16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for every lane group) is applied
-// to the SOURCE address: a row's 8 chunks are fetched permuted inside the same 128-byte line, coalescing intact.
-// Workgroup ids are remapped so that the 8 XCDs (id % 8) each walk their own contiguous range of tiles, in 8 x 4 blocks
-// (grouped walk below): the tiles an XCD works on concurrently share their A and weight panels through its L2.
+// ---------------------------------------------------------------------------------------------- 256 x 256 x 64 tile, ping-pong
+// Large-problem path (encoder GEMMs at batch >= 2, cross-K/V projection): 8 waves (2 along M x 4 along N, wave tile 128 x 64 =
+// 4 x 2 MFMA tiles), operands staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two 64 KB
+// stages.  An LDS row is the 128-byte K-slice of one operand row; the DMA image is lane-linear, so the bank swizzle (16-byte chunk
+// c of row r lives in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for every lane group) is applied to the SOURCE address:
+// a row's 8 chunks are fetched permuted inside the same 128-byte line, coalescing intact.  Workgroup ids are remapped so that the
+// 8 XCDs (id % 8) each walk their own contiguous range of tiles, in 8 x 4 blocks (grouped walk below): the tiles an XCD works on
+// concurrently share their A and weight panels through its L2.  The k-steps of a tile accumulate in ascending order into one
+// accumulator per output tile, the same order as gemm_kernel: both kernels produce the same bits.
+// The two wave groups of a workgroup (wm = 0 / 1: waves w and w + 4 share a SIMD) run half a K-tile apart.  A K-tile is two half-tiles of
+// two 16-wide k-steps; a wave alternates X (12 ds_read_b128: the fragments of one half-tile into registers) and Y (its 16 MFMAs),
+// one raw s_barrier per slot, and in every slot one group is in X while the other is in Y: the matrix pipe of a SIMD always has a
+// wave's MFMAs queued while its partner fetches.  The LDS-DMA of a K-tile is issued among the MFMAs of a Y slot and waited for
+// (the issuing wave's vmcnt) three slots later, a barrier before the first read.  Slots (barrier b_s ends slot s):
+//     group 0:  X(t,0) = 4t      Y(t,0) = 4t+1 [+ DMA(t+1)]   X(t,1) = 4t+2   Y(t,1) = 4t+3 [vmcnt(0) before b]      (+ one barrier at the end)
+//     group 1:  (one barrier first: slot 0, DMA(1))   X(t,0) = 4t+1   Y(t,0) = 4t+2   X(t,1) = 4t+3 [vmcnt(0) before b]   Y(t,1) = 4t+4 [+ DMA(t+2)]
+// Hazards: tile t is read in slots 4t .. 4t+3 (every X ends with lgkmcnt(0) before its barrier); DMA(t+1) overwrites the stage of
+// tile t-1 from slot 4t on (its last read was slot 4t-1) and every wave has waited for its pieces before b_{4t+3}; the first read
+// of tile t+1 is slot 4t+4.  Both groups execute 4 nk + 1 barriers.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     constexpr int TM = 4, TN = 2;
@@ -265,48 +275,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
 
-    // XCD-aware bijective remap of the linear workgroup id
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    // Grouped tile walk: ids run M-fastest inside groups of 8 tile rows, so the 32 workgroups an XCD runs at a time form an
-    // 8 x 4 block of output tiles that shares 8 A panels and 4 weight panels through that XCD's L2 (12 panel streams per 32 tiles
-    // instead of 1 + 32 with an N-fastest walk: PMC, large-v3 fc1 at 32 chunks fetched 2.8 GB for 0.14 GB of operands).
     const int tiles_n = (a.N + 255) >> 8, tiles_m = (a.M + 255) >> 8;
     constexpr int GM = 8;
     const int gsz = GM * tiles_n, grp = wg / gsz, first_m = grp * GM;
     const int gm = min(tiles_m - first_m, GM), in_g = wg - grp * gsz;
     const int m0 = (first_m + in_g % gm) << 8, n0 = (in_g / gm) << 8;
 
-    // ---- staging addresses: round j of an operand covers rows j*64 + (tid >> 3), LDS slot tid & 7
     const int srow = tid >> 3;
-    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk of LDS slot (tid & 7) in row srow (+64 j: same swizzle)
-    const f16* a_src[4];
-    const f16* b_src[4];
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const f16* src[8];      // pieces 0..3: A rows j*64 + srow, 4..7: W rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = min(m0 + j * 64 + srow, a.M - 1);
-        a_src[j] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + chunk * 8;
+        src[j] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + chunk * 8;
         const int n = min(n0 + j * 64 + srow, a.N - 1);
-        b_src[j] = a.W + (long long)n * a.K + chunk * 8;
+        src[4 + j] = a.W + (long long)n * a.K + chunk * 8;
     }
-    auto stage = [&](int kt, int buf) {
-        unsigned char* base = smem + buf * 65536 + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(base + 32768 + j * 8192), 16, 0, 0);
+    auto piece = [&](int p, int kt) {
+        unsigned char* dst = smem + (kt & 1) * 65536 + wave * 1024 + (p >> 2) * 32768 + (p & 3) * 8192;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
 
     const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
     const int a_row_off = (wm * 128 + fr) * 128, b_row_off = 32768 + (wn * 64 + fr) * 128;
     const int nk = a.K >> 6;
-    // SWAP: operands swapped so that a lane owns 4 consecutive output columns (row-major outputs); the V^T tiles of the
-    // encoder QKV projection keep the unswapped order (a lane owns 4 consecutive rows = 4 consecutive time steps)
+#define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_XBAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_VMWAIT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
     auto body = [&](auto swap_tag) {
         constexpr bool SWAP = decltype(swap_tag)::value;
         f32x16 acc[TM][TN];
@@ -316,35 +315,78 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        stage(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt have landed
-            __syncthreads();                                   // ... everyone's; and every wave is done reading stage buf ^ 1
-            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-            const unsigned char* sb = smem + buf * 65536;
+        f16x8 af[2][TM], bf[2][TN];
+        auto X = [&](int kt, int h) {
+            const unsigned char* sb = smem + (kt & 1) * 65536;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int slot = ((2 * ks + fh) ^ swz) * 16;
-                f16x8 af[TM], bf[TN];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int slot = ((2 * (2 * h + s2) + fh) ^ swz) * 16;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
+                for (int j = 0; j < TN; ++j) bf[s2][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 4096 + slot);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 4096 + slot);
-                if (a.tune & 1) __builtin_amdgcn_s_setprio(1);     // WH_GEMM_TUNE bit 0 (A/B knob): matrix cluster above the partner wave's DMA / LDS issue
+                for (int i = 0; i < TM; ++i) af[s2][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
+            }
+        };
+        auto Y = [&](auto dma_tag, int dma_kt) {   // 16 MFMAs; DMA: the wave's 8 LDS-DMA pieces of K-tile dma_kt go out among them
+            constexpr bool DMA = decltype(dma_tag)::value;
+            __builtin_amdgcn_s_setprio(1);      // the matrix cluster outranks the partner wave's fetch slot
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
                     }
-                if (a.tune & 1) __builtin_amdgcn_s_setprio(0);
+                    if constexpr (DMA) { __builtin_amdgcn_sched_barrier(0); piece(s2 * 4 + i, dma_kt); __builtin_amdgcn_sched_barrier(0); }
+                }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        constexpr std::true_type kDma{};
+        constexpr std::false_type kNoDma{};
+        // prologue: tile 0 (all waves), landed and visible
+#pragma unroll
+        for (int p = 0; p < 8; ++p) piece(p, 0);
+        PP_VMWAIT();
+        PP_BAR();
+        if (wm == 0) {
+            for (int t = 0; t + 1 < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kDma, t + 1); PP_BAR();
+                X(t, 1); PP_XBAR();
+                Y(kNoDma, 0); PP_VMWAIT(); PP_BAR();
+            }
+            X(nk - 1, 0); PP_XBAR();
+            Y(kNoDma, 0); PP_BAR();
+            X(nk - 1, 1); PP_XBAR();
+            Y(kNoDma, 0); PP_BAR();
+            PP_BAR();
+        } else {
+            if (nk > 1) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) piece(p, 1);
+            }
+            PP_BAR();
+            for (int t = 0; t + 2 < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
+                X(t, 1); PP_VMWAIT(); PP_XBAR();
+                Y(kDma, t + 2); PP_BAR();
+            }
+            for (int t = max(nk - 2, 0); t < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
+                X(t, 1); PP_VMWAIT(); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
             }
         }
         if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
         else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
     };
+#undef PP_BAR
+#undef PP_XBAR
+#undef PP_VMWAIT
     if constexpr (EPI == EPI_QKV_ENC) {
         if (n0 + wn * 64 >= 2 * a.d_model) body(std::false_type{});
         else body(std::true_type{});
@@ -358,13 +400,12 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
     // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
-    static const int tune = [] { const char* e = getenv("WH_GEMM_TUNE"); return e ? atoi(e) : 0; }();
     if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
         static PerDeviceOnce raised;
         raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
-        GemmArgs at = a;
-        at.tune = tune;
-        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(at);
+        // measured and rejected (profiles/r02s_*): staggering the first-round workgroups by up to a tile time to spread the store
+        // epilogues of the 256 CUs over each other's K loops - no change (1476 vs 1475 us, large-v3 fc1 at 64 chunks)
+        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(a);
         return;
     }
     // small problems get 64x64 tiles so that more than a handful of CUs are busy

@@ -98,7 +98,6 @@ struct GemmArgs {
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
     int max_batch = 0;         // EPI_CROSS_KV: slot stride of the head-major cross K/V layout
     int prof_kind = -1;        // KernelKind of this launch (measurement only)
-    int tune = 0;              // WH_GEMM_TUNE bits (A/B knobs of the 256-tile kernel)
 };
 
 void launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t st);
@@ -213,6 +212,7 @@ enum { P32_QKV = 0, P32_Q = 1, P32_RESID = 2, P32_FC1 = 3, P32_LOGITS = 4 };
 struct P32Args {
     int batch, N, K, d, n_head, n_vocab;
     int ks, tw;              // K splits across workgroups; 16-wide k tiles per wave = K / (64 ks)
+    int n_bt;                // batch tiles of this launch (set by the launcher)
     const f16* Wt;
     const f16 *zhi, *zlo;    // input planes (zlo == null: single f16 plane)
     const float2* stat_in; int n_stat; const float *fold_g, *fold_c;           // LayerNorm fold (QKV, Q, FC1, LOGITS)
