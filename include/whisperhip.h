@@ -113,6 +113,11 @@ typedef struct wh_decoding_options {
                                      and the sampler - the TextDecoder output is a Float16 MLMultiArray on arm64 (Core/Models.swift:1041,
                                      FloatType, ArgmaxCore/FloatType.swift:9-13) - and TimestampRulesFilter compares its two log-probabilities
                                      in Float16 (Core/Text/LogitsFilter.swift:144-242: BNNS logSoftmax / logSumExp / max on FloatType) */
+    int32_t beam_size;            /* <= 1: greedy (the reference).  > 1: the temperature-0 pass of the fallback ladder is a beam search
+                                     (wh_decode_text_beam: openai/whisper semantics, NO REFERENCE BEHAVIOUR - the reference's
+                                     BeamSearchTokenSampler is fatalError); fallback temperatures > 0 sample as usual.  A transcribe call
+                                     then batches max_batch / beam_size windows per round; not combinable with word_timestamps */
+    float beam_patience;          /* maxCandidates = Int(Float(beamSize) * patience), TokenSampler.swift:269; default 1 */
     int32_t reserved_;
 } wh_decoding_options;
 
@@ -277,6 +282,41 @@ int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, con
 int wh_decode_text_languages(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,
                              const int32_t* prompt, int n_prompt, const int32_t* language_tokens, const float* temperatures,
                              const int32_t* active, uint64_t seed, wh_decoding_result* out /* [batch] */);
+/* ---- beam search: NO REFERENCE BEHAVIOUR ------------------------------------------------------------------------------
+ * BeamSearchTokenSampler (Core/Text/TokenSampler.swift:254-290) exists in the reference as a class whose update / finalize are
+ * fatalError("Not implemented").  These entry points keep its construction parameters (beamSize, eotToken, patience,
+ * maxCandidates = Int(Float(beamSize) * patience)) and implement openai/whisper's BeamSearchDecoder (whisper/decoding.py
+ * v20231117 :343-424 + MaximumLikelihoodRanker with length_penalty None) - what BASELINE configs[4] asks for, labelled as such.
+ * The sampler object is plain host code (one audio): update takes the live beams (n_beams sequences of `len` tokens, their
+ * per-token log-probs or NULL, their log-prob sums) and per beam the beam_size + 1 best (log-prob, token) pairs of the
+ * log-softmax of its filtered logits, best first (topk_stride floats / ints per beam); it returns the next beams (<= beam_size
+ * sequences of len + 1 tokens), the beam each one continues (`sources`, the cache rearrangement) and whether max_candidates
+ * sequences have finished.  finalize adds the live beams (EOT appended) when fewer than beam_size finished and returns the
+ * best finished sequence by sum / sampled length. */
+typedef struct wh_beam_sampler wh_beam_sampler;
+int wh_beam_sampler_create(int beam_size, int32_t eot_token, float patience, wh_beam_sampler** out);
+void wh_beam_sampler_destroy(wh_beam_sampler* h);
+void wh_beam_sampler_reset(wh_beam_sampler* h);
+int wh_beam_sampler_max_candidates(const wh_beam_sampler* h);
+int wh_beam_sampler_finished_count(const wh_beam_sampler* h);
+int wh_beam_sampler_update(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs,
+                           const float* sums, const float* topk_logprobs, const int32_t* topk_tokens, int topk_stride,
+                           int32_t* new_tokens /* [beam_size][len + 1] */, float* new_token_logprobs /* same shape or NULL */,
+                           float* new_sums, int32_t* sources, int32_t* n_new, int32_t* completed);
+int wh_beam_sampler_finalize(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs,
+                             const float* sums, int sample_begin, int capacity, int32_t* best_tokens, float* best_token_logprobs,
+                             int32_t* best_len, float* best_sum, int32_t* n_finished);
+/* decodeText at temperature 0 with that sampler, for n_audio windows whose decoder inputs were prepared in slots
+ * [0, n_audio) (wh_prepare_decoder_inputs): the prompt is pre-filled exactly like wh_decode_text, every audio's cross K/V and
+ * cache are then copied into its beam_size slots (audio a -> slots a * beam_size ...; n_audio * beam_size <= max_batch, and the
+ * slots' previous decoder inputs are overwritten - prepare them again before another decode), and every position expands the
+ * beams: decoder step, the LogitsFilters of opt per beam, log-softmax + top (beam_size + 1) on the device, candidate ranking on
+ * the host, cache rearrangement.  language_tokens: per audio or NULL, as in wh_decode_text_languages.  Results follow the
+ * DecodingResult conventions of wh_decode_text (temperature 0); word timestamps are not recorded along beams. */
+int wh_decode_text_beam(wh_session* s, int n_audio, int beam_size, float patience, const wh_decoding_options* opt,
+                        const wh_special_tokens* st, const int32_t* prompt, int n_prompt, const int32_t* language_tokens,
+                        wh_decoding_result* out /* [n_audio] */);
+
 /* TextDecoding.detectLanguage (Core/TextDecoder.swift:420-539) */
 int wh_detect_language(wh_session* s, int batch, const wh_special_tokens* st, int32_t* language_tokens_out,
                        float* logprobs_out);

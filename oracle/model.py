@@ -72,8 +72,8 @@ class OracleWhisper:
         return x.numpy()
 
     # ---------------------------------------------------------------- decoder
-    def new_state(self, enc: np.ndarray) -> "DecoderState":
-        return DecoderState(self, enc)
+    def new_state(self, enc: np.ndarray, kvFloat16: bool = False) -> "DecoderState":
+        return DecoderState(self, enc, kvFloat16)
 
 
 class DecoderState:
@@ -82,15 +82,22 @@ class DecoderState:
 
     MAX_CTX = 224
 
-    def __init__(self, model: OracleWhisper, enc: np.ndarray):
+    def __init__(self, model: OracleWhisper, enc: np.ndarray, kvFloat16: bool = False):
+        """kvFloat16: keys and values (cross and self) are rounded to Float16 when they are stored - the storage type of the
+        reference's caches (FloatType key/value MLMultiArrays, Core/Models.swift:291-323) and of the device's.  Default off: the
+        fp32 model the logits tolerance is quoted against; on for fixtures whose sharpened attention amplifies that rounding."""
         self.m = model
+        self.kv16 = kvFloat16
         w, dims = model.w, model.dims
         xa = _t(enc)
         with torch.no_grad():
-            self.cross_k = [F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.key.weight"]) for i in range(dims.n_text_layer)]
-            self.cross_v = [F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.value.weight"],
-                                     w[f"decoder.blocks.{i}.cross_attn.value.bias"]) for i in range(dims.n_text_layer)]
+            self.cross_k = [self._store(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.key.weight"])) for i in range(dims.n_text_layer)]
+            self.cross_v = [self._store(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.value.weight"],
+                                                 w[f"decoder.blocks.{i}.cross_attn.value.bias"])) for i in range(dims.n_text_layer)]
         self.reset()
+
+    def _store(self, t):
+        return t.half().float() if self.kv16 else t
 
     def reset(self):
         dims = self.m.dims
@@ -100,6 +107,12 @@ class DecoderState:
         self.alignment = np.zeros((self.MAX_CTX, dims.n_audio_ctx), dtype=np.float32)
         self.alignment_heads = np.zeros((self.MAX_CTX, max(len(self.m.alignment_heads), 1), dims.n_audio_ctx), dtype=np.float32)
         self.alignment_written = np.zeros(self.MAX_CTX, dtype=bool)
+
+    def copy_from(self, other: "DecoderState"):
+        """Key / value cache of another state of the same audio (beam search: openai/whisper's rearrange_kv_cache)."""
+        for i in range(len(self.k)):
+            self.k[i].copy_(other.k[i])
+            self.v[i].copy_(other.v[i])
 
     def step(self, token: int, pos: int, want_alignment: bool = True):
         """One decoder call (TextDecoder.predictLogits + updateKVCache + updateAlignmentWeights,
@@ -114,8 +127,8 @@ class DecoderState:
                 p = f"decoder.blocks.{i}"
                 xn = F.layer_norm(x, (x.shape[-1],), w[p + ".attn_ln.weight"], w[p + ".attn_ln.bias"])
                 q = F.linear(xn, w[p + ".attn.query.weight"], w[p + ".attn.query.bias"])
-                self.k[i][pos] = F.linear(xn, w[p + ".attn.key.weight"])[0]
-                self.v[i][pos] = F.linear(xn, w[p + ".attn.value.weight"], w[p + ".attn.value.bias"])[0]
+                self.k[i][pos] = self._store(F.linear(xn, w[p + ".attn.key.weight"])[0])
+                self.v[i][pos] = self._store(F.linear(xn, w[p + ".attn.value.weight"], w[p + ".attn.value.bias"])[0])
                 x = x + m._attend(p + ".attn", q, self.k[i][: pos + 1], self.v[i][: pos + 1], nh)
                 xn = F.layer_norm(x, (x.shape[-1],), w[p + ".cross_attn_ln.weight"], w[p + ".cross_attn_ln.bias"])
                 q = F.linear(xn, w[p + ".cross_attn.query.weight"], w[p + ".cross_attn.query.bias"])

@@ -40,7 +40,7 @@ class WhDecodingOptions(C.Structure):
         ("suppress_blank", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32)), ("n_suppress_tokens", C.c_int32),
         ("compression_ratio_threshold", C.c_float), ("log_prob_threshold", C.c_float),
         ("first_token_log_prob_threshold", C.c_float), ("no_speech_threshold", C.c_float), ("seed", C.c_uint64),
-        ("float16_logits", C.c_int32), ("reserved_", C.c_int32),
+        ("float16_logits", C.c_int32), ("beam_size", C.c_int32), ("beam_patience", C.c_float), ("reserved_", C.c_int32),
     ]
 
 
@@ -122,6 +122,14 @@ SYMBOLS = {
     "wh_decode_text": (I, [VP, I, POPT, PST, PI32, I, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
     "wh_decode_text_languages": (I, [VP, I, POPT, PST, PI32, I, PI32, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
     "wh_detect_language": (I, [VP, I, PST, PI32, PF]),
+    "wh_decode_text_beam": (I, [VP, I, I, F, POPT, PST, PI32, I, PI32, C.POINTER(WhDecodingResult)]),
+    "wh_beam_sampler_create": (I, [I, C.c_int32, F, PVP]),
+    "wh_beam_sampler_destroy": (None, [VP]),
+    "wh_beam_sampler_reset": (None, [VP]),
+    "wh_beam_sampler_max_candidates": (I, [VP]),
+    "wh_beam_sampler_finished_count": (I, [VP]),
+    "wh_beam_sampler_update": (I, [VP, I, I, PI32, PF, PF, PF, PI32, I, PI32, PF, PF, PI32, PI32, PI32]),
+    "wh_beam_sampler_finalize": (I, [VP, I, I, PI32, PF, PF, I, I, PI32, PF, PI32, PF, PI32]),
     "wh_get_mel_device": (I, [VP, I, PVP]),
     "wh_get_encoder_output_device": (I, [VP, I, PVP, PVP]),
     "wh_get_logits_device": (I, [VP, PVP]),

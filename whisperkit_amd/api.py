@@ -68,6 +68,8 @@ class DecodingOptions:
     noSpeechThreshold: Optional[float] = 0.6
     seed: int = 0
     float16Logits: bool = False   # reference-numerics switch (wh_decoding_options.float16_logits): FloatType logits + Float16 timestamp rule
+    beamSize: int = 0             # > 1: the T = 0 pass is a beam search (openai/whisper semantics; NO REFERENCE BEHAVIOUR - fatalError there)
+    beamPatience: float = 1.0
 
     def to_c(self):
         o = L.WhDecodingOptions()
@@ -107,6 +109,8 @@ class DecodingOptions:
         o.no_speech_threshold = nan if self.noSpeechThreshold is None else self.noSpeechThreshold
         o.seed = self.seed
         o.float16_logits = int(self.float16Logits)
+        o.beam_size = int(self.beamSize)
+        o.beam_patience = float(self.beamPatience)
         o._keep = keep
         return o
 
@@ -318,6 +322,72 @@ class Tokenizer:
         return words, wt
 
 
+class BeamSearchTokenSampler:
+    """Core/Text/TokenSampler.swift:254-290 by name and construction parameters; update / finalize are fatalError in the reference,
+    here they follow openai/whisper's BeamSearchDecoder for ONE audio (wh_beam_sampler_*, host code).  NO REFERENCE BEHAVIOUR."""
+
+    def __init__(self, beamSize: int, eotToken: int, patience: float = 1.0):
+        self.lib = L.load()
+        self.beamSize, self.eotToken, self.patience = beamSize, eotToken, patience
+        h = C.c_void_p()
+        _check(self.lib.wh_beam_sampler_create(beamSize, eotToken, patience, C.byref(h)))
+        self.handle = h
+        self.maxCandidates = self.lib.wh_beam_sampler_max_candidates(h)
+
+    def reset(self):
+        self.lib.wh_beam_sampler_reset(self.handle)
+
+    @property
+    def finishedCount(self) -> int:
+        return self.lib.wh_beam_sampler_finished_count(self.handle)
+
+    def update(self, tokens, tokenLogProbs, sums, topkLogProbs, topkTokens):
+        """tokens [n_beams][len], tokenLogProbs same shape, sums [n_beams], topk* [n_beams][beamSize + 1] (best first).
+        Returns (new tokens [n][len + 1], new log-probs, new sums, sources, completed)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        n, ln = t.shape
+        lp = np.ascontiguousarray(tokenLogProbs, dtype=np.float32)
+        sm = np.ascontiguousarray(sums, dtype=np.float32)
+        kl = np.ascontiguousarray(topkLogProbs, dtype=np.float32)
+        kt = np.ascontiguousarray(topkTokens, dtype=np.int32)
+        assert lp.shape == t.shape and kl.shape == kt.shape == (n, self.beamSize + 1)
+        nt = np.zeros((self.beamSize, ln + 1), dtype=np.int32)
+        nl = np.zeros((self.beamSize, ln + 1), dtype=np.float32)
+        ns = np.zeros(self.beamSize, dtype=np.float32)
+        src = np.zeros(self.beamSize, dtype=np.int32)
+        nn, done = C.c_int32(0), C.c_int32(0)
+        _check(self.lib.wh_beam_sampler_update(self.handle, n, ln, t.ctypes.data_as(L.PI32), lp.ctypes.data_as(L.PF), sm.ctypes.data_as(L.PF),
+                                               kl.ctypes.data_as(L.PF), kt.ctypes.data_as(L.PI32), self.beamSize + 1, nt.ctypes.data_as(L.PI32),
+                                               nl.ctypes.data_as(L.PF), ns.ctypes.data_as(L.PF), src.ctypes.data_as(L.PI32), C.byref(nn), C.byref(done)))
+        k = nn.value
+        return nt[:k], nl[:k], ns[:k], src[:k], bool(done.value)
+
+    def finalize(self, tokens, tokenLogProbs, sums, sampleBegin: int):
+        """Returns (best tokens, their log-probs, sum, number of finished sequences)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        n, ln = t.shape
+        lp = np.ascontiguousarray(tokenLogProbs, dtype=np.float32)
+        sm = np.ascontiguousarray(sums, dtype=np.float32)
+        cap = ln + 8
+        bt = np.zeros(cap, dtype=np.int32)
+        bl = np.zeros(cap, dtype=np.float32)
+        blen, nf, bs = C.c_int32(0), C.c_int32(0), C.c_float(0)
+        _check(self.lib.wh_beam_sampler_finalize(self.handle, n, ln, t.ctypes.data_as(L.PI32), lp.ctypes.data_as(L.PF), sm.ctypes.data_as(L.PF),
+                                                 sampleBegin, cap, bt.ctypes.data_as(L.PI32), bl.ctypes.data_as(L.PF), C.byref(blen), C.byref(bs), C.byref(nf)))
+        return bt[: blen.value].tolist(), bl[: blen.value].tolist(), float(bs.value), nf.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.wh_beam_sampler_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Model:
     """The three loaded model stages (weights on one GPU)."""
 
@@ -516,6 +586,20 @@ class Session:
             _check(self.lib.wh_decode_text_languages(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
                                                      lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF),
                                                      None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+        return [DecodingResult.from_c(r) for r in res]
+
+    def decodeTextBeam(self, prompt: Sequence[int], options: DecodingOptions, nAudio: int = 1, beamSize: int = 5, patience: float = 1.0,
+                       specialTokens=None, languageTokens: Optional[Sequence[int]] = None) -> List[DecodingResult]:
+        """Beam search at temperature 0 (wh_decode_text_beam) for the windows prepared in slots [0, nAudio); audio a then occupies
+        slots a * beamSize ... (prepareDecoderInputs again before another decode).  NO REFERENCE BEHAVIOUR: the reference's
+        BeamSearchTokenSampler is fatalError; openai/whisper's BeamSearchDecoder semantics."""
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = options.to_c()
+        p = np.ascontiguousarray(list(prompt), dtype=np.int32)
+        lt = None if languageTokens is None else np.ascontiguousarray(languageTokens, dtype=np.int32)
+        res = (L.WhDecodingResult * nAudio)()
+        _check(self.lib.wh_decode_text_beam(self.handle, nAudio, beamSize, patience, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                                            None if lt is None else lt.ctypes.data_as(L.PI32), res))
         return [DecodingResult.from_c(r) for r in res]
 
     def setAlignmentPostprocess(self, zNormalize: bool = False, medianFilterWidth: int = 0):

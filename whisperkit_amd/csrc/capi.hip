@@ -355,7 +355,7 @@ extern "C" void wh_decoding_options_default(wh_decoding_options* o) {
     o->window_clip_time = 1.0f; o->prompt_tokens = nullptr; o->n_prompt_tokens = 0; o->prefix_tokens = nullptr; o->n_prefix_tokens = 0;
     o->suppress_blank = 0; o->suppress_tokens = nullptr; o->n_suppress_tokens = 0;
     o->compression_ratio_threshold = 2.4f; o->log_prob_threshold = -1.0f; o->first_token_log_prob_threshold = -1.5f;
-    o->no_speech_threshold = 0.6f; o->seed = 0; o->float16_logits = 0;
+    o->no_speech_threshold = 0.6f; o->seed = 0; o->float16_logits = 0; o->beam_size = 0; o->beam_patience = 1.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ session
@@ -423,7 +423,8 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->align_tmp) hipFree(s->align_tmp);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
-                    s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits};
+                    s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits,
+                    s->beam_k, s->beam_v, s->beam_pairs, s->beam_tok, s->beam_lp};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->seq_host) hipHostFree(s->seq_host);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);

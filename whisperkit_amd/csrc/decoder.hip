@@ -749,6 +749,70 @@ void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits,
     sampler_kernel<0, 1, 0, 0><<<1, SAMP_T, 0, st>>>(cfg_dev, nullptr, seq, logits, counter, token_out, logprob_out);
 }
 
+void launch_filter_batch(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, hipStream_t st) {
+    sampler_kernel<1, 0, 0, 1><<<batch, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, seq, logits, 0, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------- beam search support
+// BeamSearchTokenSampler.update, device part: log-softmax of a slot's FILTERED logits and its K best entries, descending, ties to the
+// lower token id (openai/whisper decoding.py:361 logprobs[idx].topk(beam_size + 1)).  One workgroup per slot; the row (200 KB) is
+// re-read from L2 for each of the K + 2 passes.  The reference's sampler of this name is fatalError: no reference behaviour.
+__global__ __launch_bounds__(SAMP_T) void beam_topk_kernel(const float* __restrict__ logits_all, const SeqState* __restrict__ seqs, int V, int K,
+                                                           float* __restrict__ lp_out, int* __restrict__ tok_out) {
+    __shared__ BlockRed br;
+    __shared__ int taken[kBeamTopK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!slot_live(seqs + b)) return;
+    const float* x = logits_all + (size_t)b * V;
+    float mx = -INFINITY;
+    for (int n = tid; n < V; n += SAMP_T) mx = fmaxf(mx, x[n]);
+    mx = block_max(mx, &br);
+    float se = 0.0f;
+    for (int n = tid; n < V; n += SAMP_T) { const float v = x[n]; if (v != -INFINITY) se += expf(v - mx); }
+    se = block_sum(se, &br);
+    const float lse = mx + logf(se);
+    for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int n = tid; n < V; n += SAMP_T) {
+            bool skip = false;
+            for (int j = 0; j < k; ++j) skip |= taken[j] == n;
+            if (skip) continue;
+            const float v = x[n];
+            if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+        }
+        float rv; int ri;
+        block_argmax(bv, bi, &br, &rv, &ri);
+        if (tid == 0) {
+            taken[k] = ri;
+            lp_out[(size_t)b * kBeamTopK + k] = rv - lse;
+            tok_out[(size_t)b * kBeamTopK + k] = ri;
+        }
+        __syncthreads();
+    }
+}
+void launch_beam_topk(const float* logits, const SeqState* seq, int batch, int V, int K, float* lp_out, int* tok_out, hipStream_t st) {
+    beam_topk_kernel<<<batch, SAMP_T, 0, st>>>(logits, seq, V, K, lp_out, tok_out);
+}
+
+// Slot-to-slot copies inside a [layers][max_batch][segments][seg_stride] f16 buffer (self / cross K and V): pair p copies the first
+// seg_copy halves of every segment of slot pairs[2p] of `src` to slot pairs[2p+1] of `dst`.  Beam search: replication of an audio's
+// cross K/V and pre-filled cache into its beam slots, and the per-step cache rearrangement (openai rearrange_kv_cache) through a
+// scratch buffer (src != dst), so no pair reads a slot another pair writes.
+__global__ __launch_bounds__(256) void copy_slots_kernel(const f16* __restrict__ src, f16* __restrict__ dst, size_t layer_stride, size_t slot_stride,
+                                                         int n_seg, int seg_stride, int seg_copy, const int* __restrict__ pairs) {
+    const int p = blockIdx.x, seg = blockIdx.y, l = blockIdx.z;
+    const int from = pairs[2 * p], to = pairs[2 * p + 1];
+    const uint4* s4 = reinterpret_cast<const uint4*>(src + (size_t)l * layer_stride + (size_t)from * slot_stride + (size_t)seg * seg_stride);
+    uint4* d4 = reinterpret_cast<uint4*>(dst + (size_t)l * layer_stride + (size_t)to * slot_stride + (size_t)seg * seg_stride);
+    for (int i = threadIdx.x; i < seg_copy / 8; i += 256) d4[i] = s4[i];
+}
+void launch_copy_slots(const f16* src, f16* dst, int n_layer, size_t layer_stride, size_t slot_stride, int n_seg, int seg_stride, int seg_copy,
+                       const int* pairs_dev, int n_pairs, hipStream_t st) {
+    if (n_pairs <= 0 || seg_copy <= 0) return;
+    copy_slots_kernel<<<dim3(n_pairs, n_seg, n_layer), 256, 0, st>>>(src, dst, layer_stride, slot_stride, n_seg, seg_stride, seg_copy, pairs_dev);
+}
+
 void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st) {
     sampler_kernel<1, 1, 0, 0><<<batch, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, seq, logits, 0, token_out, logprob_out);
 }

@@ -569,11 +569,16 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
     for (int i = 0; i <= opt->temperature_fallback_count; ++i)
         temps.push_back(f16_round(f16_round(opt->temperature) + f16_round(f16_round((float)i) * f16_round(opt->temperature_increment_on_fallback))));
 
+    // beam search (no reference behaviour, wh_decode_text_beam): the T = 0 pass expands every window into beam_size slots
+    const int beam = opt->beam_size > 1 ? opt->beam_size : 1;
+    if (beam > 1 && opt->word_timestamps) return set_error(WH_ERR_INVALID_ARGUMENT, "beam_size > 1 cannot be combined with word_timestamps");
+    if (beam > s->B) return set_error(WH_ERR_INVALID_ARGUMENT, "beam_size %d exceeds the session's %d slots", beam, s->B);
+    const int round_cap = s->B / beam;
     std::vector<int> slot_job;   // job index per slot for the current round
     while (true) {
         // gather up to B jobs that still have a window (each job contributes one window per round: windows of one audio are sequential)
         slot_job.clear();
-        for (size_t ji = 0; ji < jobs.size() && (int)slot_job.size() < s->B; ++ji)
+        for (size_t ji = 0; ji < jobs.size() && (int)slot_job.size() < round_cap; ++ji)
             if (!jobs[ji].finished && job_next_window(jobs[ji], opt)) slot_job.push_back((int)ji);
         if (slot_job.empty()) break;
         const int nb = (int)slot_job.size();
@@ -623,9 +628,19 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             }
             r = whi::reset_decoder_inputs_masked(s, nb, active.data()); if (r) return r;     // accepted slots keep their alignment rows
             uint64_t seed = opt->seed + 1000003ull * (uint64_t)jobs[slot_job[0]].windows + ti;
-            r = decode_text_impl(s, nb, opt, st, prompt.data(), n_prompt, (per_slot_lang && opt->use_prefill_prompt) ? lang_slot.data() : nullptr,
-                                 tv.data(), active.data(), seed, tmp.data());
-            if (r) return r;
+            const int32_t* langs = (per_slot_lang && opt->use_prefill_prompt) ? lang_slot.data() : nullptr;
+            bool all_active = true;
+            for (int b = 0; b < nb; ++b) all_active &= active[b] != 0;
+            if (beam > 1 && temps[ti] == 0.0f && all_active) {
+                r = wh_decode_text_beam(s, nb, beam, opt->beam_patience, opt, st, prompt.data(), n_prompt, langs, tmp.data());
+                if (r) return r;
+                bool again = false;
+                for (int b = 0; b < nb; ++b) again |= tmp[b].needs_fallback != 0;
+                if (again && ti + 1 < temps.size()) { r = wh_prepare_decoder_inputs(s, nb); if (r) return r; }   // the beam slots overwrote the windows' cross K/V
+            } else {
+                r = decode_text_impl(s, nb, opt, st, prompt.data(), n_prompt, langs, tv.data(), active.data(), seed, tmp.data());
+                if (r) return r;
+            }
             bool any = false;
             for (int b = 0; b < nb; ++b) {
                 if (!active[b]) continue;

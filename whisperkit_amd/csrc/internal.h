@@ -82,6 +82,9 @@ struct wh_session {
     bool fused_greedy = false;
     int *tok_out_dev = nullptr; float* lp_out_dev = nullptr;
     float* scratch_logits = nullptr;       // [V] for the filter / sample KAT entry points
+    // beam search (wh_decode_text_beam, allocated on first use): scratch self K/V for the cache rearrangement, slot pairs, top-k outputs
+    f16 *beam_k = nullptr, *beam_v = nullptr;
+    int *beam_pairs = nullptr, *beam_tok = nullptr; float* beam_lp = nullptr;
     hipEvent_t ev[8]{};
     bool align_enabled = false;
     wh_timings last_timings{};

@@ -242,6 +242,11 @@ void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqS
 void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits, int n_vocab, int counter, int* token_out, float* logprob_out, hipStream_t st);
 // filter + sample without advancing the decode state (detectLanguage)
 void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st);
+void launch_filter_batch(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, hipStream_t st);
+constexpr int kBeamTopK = 16;   // row stride of the top-k outputs: beam sizes up to 15 (topk(beam_size + 1))
+void launch_beam_topk(const float* logits, const SeqState* seq, int batch, int V, int K, float* lp_out, int* tok_out, hipStream_t st);
+void launch_copy_slots(const f16* src, f16* dst, int n_layer, size_t layer_stride, size_t slot_stride, int n_seg, int seg_stride, int seg_copy,
+                       const int* pairs_dev, int n_pairs, hipStream_t st);
 // mean over alignment heads -> [B][224][1500]
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st);
 // openai/whisper-style alignment post-processing of one slot (z-normalise over the token rows, median filter, head mean)
