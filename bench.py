@@ -346,29 +346,37 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
 def long_audio_config(args, local_rank):
     """BASELINE configs[4] at 1 GPU: whisper-large-v3, one 10 min audio cut into 30 s VAD chunks (WhisperKit.transcribe with
     chunkingStrategy .vad), temperature ladder forced once per window (log-prob threshold random weights always violate,
-    temperatureFallbackCount 1 -> T = 0 then 0.2).  Beam search is omitted: the reference's BeamSearchTokenSampler is a
-    fatalError stub (Core/Text/TokenSampler.swift:254-290), so there is no reference behaviour to match."""
+    temperatureFallbackCount 1 -> T = 0 then 0.2).  Two lines: the reference's behaviour (greedy T = 0 pass) and, labelled NO
+    REFERENCE BEHAVIOUR, the beam = 5 variant configs[4] names - the reference's BeamSearchTokenSampler is a fatalError stub
+    (Core/Text/TokenSampler.swift:254-290); wh_decode_text_beam follows openai/whisper's BeamSearchDecoder for the T = 0 pass."""
     from whisperkit_amd import api
     from whisperkit_amd.synth import synthetic_chunk
     model, dims, _ = get_model("large-v3", local_rank)
     audio = np.concatenate([synthetic_chunk(5000 + i) for i in range(20)]).astype(np.float32)
-    sess = api.Session(model, 20)
-    opts = api.DecodingOptions(firstTokenLogProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
-                               logProbThreshold=-1.0, temperatureFallbackCount=1, temperatureIncrementOnFallback=0.2,
-                               sampleLength=args.sample_length, seed=7)
-    sess.transcribeChunked(audio, opts)      # warm-up (graph capture)
-    t0 = time.perf_counter()
-    got = sess.transcribeChunked(audio, opts)
-    el = time.perf_counter() - t0
-    windows = sum(int(r.timings["total_decoding_windows"]) for _, r in got)
-    fallbacks = sum(int(r.timings["total_decoding_fallbacks"]) for _, r in got)
-    loops = sum(int(r.timings["total_decoding_loops"]) for _, r in got)
-    sess.close()
-    return {"value": round(600.0 / el, 2), "unit": "audio-sec/sec", "seconds": round(el, 3), "chunks": len(got), "windows": windows,
-            "temperature_fallbacks": fallbacks, "decoder_forward_passes": loops,
-            "note": "10 min synthetic audio -> VADAudioChunker (30 s chunks, one device batch) -> decodeWithFallback with the ladder "
-                    "forced once per window (T = 0, then 0.2 with the seeded top-5 sampler) -> segments; beam=5 omitted: no reference "
-                    "behaviour (BeamSearchTokenSampler is a fatalError stub, Core/Text/TokenSampler.swift:254-290)"}
+    kw = dict(firstTokenLogProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None, logProbThreshold=-1.0,
+              temperatureFallbackCount=1, temperatureIncrementOnFallback=0.2, sampleLength=args.sample_length, seed=7)
+
+    def run(slots, **extra):
+        sess = api.Session(model, slots)
+        opts = api.DecodingOptions(**kw, **extra)
+        sess.transcribeChunked(audio, opts)      # warm-up (graph capture)
+        t0 = time.perf_counter()
+        got = sess.transcribeChunked(audio, opts)
+        el = time.perf_counter() - t0
+        sess.close()
+        return {"value": round(600.0 / el, 2), "unit": "audio-sec/sec", "seconds": round(el, 3), "chunks": len(got),
+                "windows": sum(int(r.timings["total_decoding_windows"]) for _, r in got),
+                "temperature_fallbacks": sum(int(r.timings["total_decoding_fallbacks"]) for _, r in got),
+                "decoder_forward_passes": sum(int(r.timings["total_decoding_loops"]) for _, r in got)}
+    out = run(20)
+    out["note"] = ("10 min synthetic audio -> VADAudioChunker (30 s chunks, one device batch) -> decodeWithFallback with the ladder "
+                   "forced once per window (T = 0 greedy, then 0.2 with the seeded top-5 sampler) -> segments")
+    beam = run(100, beamSize=5)
+    beam["note"] = ("NO REFERENCE BEHAVIOUR: the same workload with beam = 5 for the T = 0 pass (20 windows x 5 beams = 100 decoder slots, "
+                    "openai/whisper BeamSearchDecoder semantics, host-ranked candidates per step), then the same sampled fallback; the "
+                    "reference's BeamSearchTokenSampler is a fatalError stub (Core/Text/TokenSampler.swift:254-290)")
+    out["beam5_no_reference_behaviour"] = beam
+    return out
 
 
 def main():

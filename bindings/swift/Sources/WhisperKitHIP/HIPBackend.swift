@@ -132,6 +132,12 @@ public final class HIPTextDecoder: TextDecoding {
             }, Unmanaged.passUnretained(box).toOpaque())
         }
         defer { if box != nil { wh_session_set_progress_callback(session, nil, nil) } }
+        if let beam = tokenSampler as? BeamSearchTokenSampler {
+            // The reference's BeamSearchTokenSampler is fatalError (TokenSampler.swift:254-290) and TokenSampling.update sees one sequence:
+            // the session needs beamSize slots, the library runs openai/whisper's BeamSearchDecoder (no reference behaviour).
+            try check(wh_decode_text_beam(session, 1, Int32(beam.beamSize), beam.patience, &o, &st, prompt, Int32(prompt.count), nil, &res))
+            return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
+        }
         try check(wh_decode_text(session, 1, &o, &st, prompt, Int32(prompt.count), &temps, nil, 0, &res))
         return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
     }

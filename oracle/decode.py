@@ -10,6 +10,9 @@ The oracle keeps logits in float32/float64; the product does the same (DESIGN.md
 NOTE(parity) sampling at T>0 uses the unseeded system RNG in the reference
 (Core/Text/TokenSampler.swift:61,169); oracle and product share a seeded counter-based
 generator (`uniform01`) so that T>0 decoding is reproducible.
+NOTE(parity) beam search (BeamSearchTokenSampler, decode_text_beam): PARITY UNPINNED.  The reference's sampler of that name is
+fatalError (Core/Text/TokenSampler.swift:254-290); the restatement follows openai/whisper's BeamSearchDecoder, which is not in
+this container either, so no golden vector exists - the properties it is checked on are in tests/test_beam_search.py.
 """
 from __future__ import annotations
 
