@@ -632,6 +632,7 @@ def decode_text_beam(new_state: Callable[[], object], initialPrompt: List[int], 
             sj.copy_from(state0)
         nextTokens = [nextToken] * beamSize
         live = True
+        spare = None
         for tokenIndex in range(initialPromptIndex - 1, loopCount):
             rows = []
             for j in range(len(beams)):
@@ -648,10 +649,11 @@ def decode_text_beam(new_state: Callable[[], object], initialPrompt: List[int], 
             if len(beams[0][0]) >= MAX_TOKEN_CONTEXT - 1:
                 break
             beams, sources, completed = beam.update(beams, rows)
-            fresh = [new_state() for _ in beams]
-            for sj, src in zip(fresh, sources):
+            if spare is None:
+                spare = [new_state() for _ in range(beamSize)]       # rearrange_kv_cache: copy into the other pool, swap
+            for sj, src in zip(spare, sources):
                 sj.copy_from(states[src])
-            states = fresh
+            states, spare = spare, states
             nextTokens = [b[0][-1] for b in beams]
             if completed:
                 break

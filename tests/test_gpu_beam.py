@@ -91,7 +91,7 @@ def _compare(got, ores, sampler, what):
 @pytest.mark.parametrize("beam", [5, 2])
 def test_decode_text_beam_vs_oracle(peaky, beam):
     dims, _, model, om, st, langs, ml = peaky
-    kw = dict(**NOFALLBACK, sampleLength=40)
+    kw = dict(**NOFALLBACK, sampleLength=36)
     opts = api.DecodingOptions(**kw)
     n = len(AUDIOS)
     sess = api.Session(model, n * beam)
@@ -104,7 +104,7 @@ def test_decode_text_beam_vs_oracle(peaky, beam):
         so = []
         ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True), prompt, beam, 1.0, _oopts(kw), st, ml, langs, sampler_out=so)
         if _compare(got[a], ores, so[0], f"audio {AUDIOS[a]} beam {beam}"):
-            STATS["early"] += len(ores.tokens) < len(prompt) + 38          # ended through finished (EOT) sequences, not the length cap
+            STATS["early"] += len(ores.tokens) < len(prompt) + 34          # ended through finished (EOT) sequences, not the length cap
             STATS["differs_from_greedy"] += got[a].tokens != greedy[a].tokens
         assert got[a].tokens[-1] == st.endToken and got[a].tokens[0] == prompt[0]
     # exactness: every audio decodes the same alone (1 x beam slots) as in the batch (slots a * beam ...)
@@ -136,7 +136,7 @@ def test_beam_with_patience_and_short_sample_length(peaky):
     """patience 2 -> maxCandidates 4 for beam 2 (more finished sequences are collected before stopping); sampleLength shorter than
     the prompt leaves the pre-filled prompt as the result, like decodeText."""
     dims, _, model, om, st, langs, ml = peaky
-    kw = dict(**NOFALLBACK, sampleLength=40)
+    kw = dict(**NOFALLBACK, sampleLength=36)
     opts = api.DecodingOptions(**kw)
     sess = api.Session(model, 4)
     encs = _encode(sess, AUDIOS[:2])

@@ -8,6 +8,11 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?
 DB=$(ls /tmp/${TAG}_prof/*.db /tmp/${TAG}_prof/*/*.db 2>/dev/null | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats.csv 2> $R/${TAG}_summary.err; head -12 $R/${TAG}_kernel_stats.csv
+# the same command with ONE step in flight: the kernel's own duration (what bench.py's roofline leg times with HIP events on an otherwise
+# idle GPU); with three sessions in flight the streams share the HBM and the per-kernel averages above are stretched
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof1 -o ${TAG}1 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-other-configs --no-roofline > $R/${TAG}_prof_inflight1_bench.json 2> $R/${TAG}_prof_inflight1.err; echo prof1 rc=$?
+DB=$(ls /tmp/${TAG}_prof1/*.db /tmp/${TAG}_prof1/*/*.db 2>/dev/null | head -1)
+python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats_inflight1.csv 2>> $R/${TAG}_summary.err; head -4 $R/${TAG}_kernel_stats_inflight1.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace -d /tmp/${TAG}_pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_run.py large-v3 64 8 > $R/${TAG}_pmc_$C.log 2>&1; echo pmc $C rc=$?
   DB=$(ls /tmp/${TAG}_pmc_$C/*.db /tmp/${TAG}_pmc_$C/*/*.db 2>/dev/null | head -1)
