@@ -17,7 +17,10 @@ namespace wh {
 
 constexpr int AT_LD = 72;  // LDS row stride in halves (64 + 8 pad = 144 B)
 
-__global__ __launch_bounds__(256) void encoder_attention_kernel(const f16* __restrict__ q16, const f16* __restrict__ k16,
+// __launch_bounds__(256, 2): two workgroups per CU = at least two waves per SIMD caps the wave at 256 unified registers, which makes
+// the compiler keep the MFMA accumulators in arch VGPRs.  With one wave per SIMD allowed it placed them in AccVGPRs and moved the
+// 64 score / output registers through 200 v_accvgpr_read / write per key tile - on a kernel that is VALU-bound (softmax) already.
+__global__ __launch_bounds__(256, 2) void encoder_attention_kernel(const f16* __restrict__ q16, const f16* __restrict__ k16,
                                                                 const f16* __restrict__ vt16, f16* __restrict__ out16,
                                                                 int n_head, int d) {
     __shared__ __attribute__((aligned(16))) f16 Ks[64 * AT_LD];

@@ -122,8 +122,11 @@ __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, flo
 // Weights and planes stream in double-buffered chunks of TC k-tiles (tw is a multiple of TC); sched_barriers keep the loads of the
 // next chunk ahead of the current chunk's MFMAs.  Measured and rejected: requesting a wave's whole weight slab (20 tiles, 80 VGPRs) in
 // one burst ahead of the MFMAs - 2-3 % slower at 8 and 32 slots (profiles/r02j_*): the per-launch latency is not the weight round trips.
+// __launch_bounds__(256, 2): capping the wave at 256 unified registers keeps the accumulators in arch VGPRs (with 512 allowed the
+// compiler parked them in AccVGPRs and copied all 32 of them out and back in every loop iteration: 160 v_accvgpr moves per launch);
+// every instantiation fits (88 - 204 VGPRs, no scratch), two workgroups can share a CU.
 template <int MODE, bool HILO, int TC>
-__global__ __launch_bounds__(256) void dec32_proj_kernel(const P32Args a) {
+__global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
     __shared__ float red[4][16][64];                 // the four waves' partial tiles
     __shared__ float st_l[8][32][3];                 // LayerNorm statistics: 8 partial (n, mean, M2) per slot

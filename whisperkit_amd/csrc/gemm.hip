@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
 }
 
 template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {     // (256, 2): accumulators stay in arch VGPRs (no AccVGPR copies)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int CA = BM * 4 / 256, CB = BN * 4 / 256;   // 16-byte chunks per thread per tile
     __shared__ __attribute__((aligned(16))) f16 As[2][BM * LDT];
