@@ -235,6 +235,21 @@ int wh_get_alignment_weights(wh_session* s, int b, float* out_host /* [224][1500
  * CoreML bundles bake it in is not published: default off (z_normalize 0, median_filter_width 0). */
 int wh_session_set_alignment_postprocess(wh_session* s, int z_normalize, int median_filter_width);
 
+/* A device-resident stage output as a plain tensor descriptor (what the MLMultiArray results of the CoreML stages,
+ * Core/Models.swift:848-1107, become behind a C ABI): row-major, `device` = HIP device ordinal (the session's model device). The
+ * memory stays owned by the session and is valid until the stage runs again on that session. */
+enum { WH_DTYPE_F32 = 0, WH_DTYPE_F16 = 1 };
+typedef struct wh_tensor {
+    void* data;
+    int32_t dtype;        /* WH_DTYPE_* */
+    int32_t ndim;
+    int64_t shape[4];
+    int32_t device;
+    int32_t reserved_;
+} wh_tensor;
+int wh_get_mel_tensor(wh_session* s, int b, wh_tensor* out);                          /* f32 [n_mels][3000], the reference layout */
+int wh_get_encoder_output_tensor(wh_session* s, int b, int dtype, wh_tensor* out);    /* f32 or f16 [1500][d] */
+int wh_get_logits_tensor(wh_session* s, wh_tensor* out);                              /* f32 [max_batch][n_vocab], step API / T > 0 */
 /* Device-resident hand-off (MLMultiArray outputs of the CoreML stages stay on the accelerator in the reference too): pointers
  * into the session's HBM buffers of slot b, valid until the session rewrites them; consume them on wh_session_stream(s) or after
  * wh_session_synchronize.  mel [n_mels][3000] f32; encoder output [1500][d] as f32 and as the f16 copy the decoder reads

@@ -206,6 +206,16 @@ def test_device_resident_outputs(micro):
     lg = np.empty((2, dims.n_vocab), np.float32)
     assert hip.hipMemcpy(lg.ctypes.data, sess.getLogitsDevice(), lg.nbytes, 2) == 0
     np.testing.assert_array_equal(lg, got)
+    # the same buffers as wh_tensor descriptors
+    t = sess.getMelTensor(1)
+    assert t == dict(data=sess.getMelDevice(1), dtype=np.float32, shape=(dims.n_mels, 3000), device=0)
+    p32, p16 = sess.getEncoderOutputDevice(1)
+    assert sess.getEncoderOutputTensor(1) == dict(data=p32, dtype=np.float32, shape=(1500, dims.n_audio_state), device=0)
+    assert sess.getEncoderOutputTensor(1, np.float16) == dict(data=p16, dtype=np.float16, shape=(1500, dims.n_audio_state), device=0)
+    assert sess.getLogitsTensor() == dict(data=sess.getLogitsDevice(), dtype=np.float32, shape=(2, dims.n_vocab), device=0)
+    e16 = np.empty((1500, dims.n_audio_state), np.float16)
+    assert hip.hipMemcpy(e16.ctypes.data, sess.getEncoderOutputTensor(0, np.float16)["data"], e16.nbytes, 2) == 0
+    np.testing.assert_array_equal(e16, sess.getEncoderOutput(0).astype(np.float16))
 
 
 def test_sessions_own_their_step_graphs(micro):

@@ -53,6 +53,11 @@ class WhDecodingResult(C.Structure):
     ]
 
 
+class WhTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4), ("device", C.c_int32),
+                ("reserved_", C.c_int32)]
+
+
 class WhSegment(C.Structure):
     _fields_ = [("id", C.c_int32), ("seek", C.c_int32), ("start", C.c_float), ("end", C.c_float),
                 ("token_offset", C.c_int32), ("n_tokens", C.c_int32), ("temperature", C.c_float), ("avg_logprob", C.c_float),
@@ -131,6 +136,9 @@ SYMBOLS = {
     "wh_beam_sampler_update": (I, [VP, I, I, PI32, PF, PF, PF, PI32, I, PI32, PF, PF, PI32, PI32, PI32]),
     "wh_beam_sampler_finalize": (I, [VP, I, I, PI32, PF, PF, I, I, PI32, PF, PI32, PF, PI32]),
     "wh_get_mel_device": (I, [VP, I, PVP]),
+    "wh_get_mel_tensor": (I, [VP, I, C.POINTER(WhTensor)]),
+    "wh_get_encoder_output_tensor": (I, [VP, I, I, C.POINTER(WhTensor)]),
+    "wh_get_logits_tensor": (I, [VP, C.POINTER(WhTensor)]),
     "wh_get_encoder_output_device": (I, [VP, I, PVP, PVP]),
     "wh_get_logits_device": (I, [VP, PVP]),
     "wh_session_set_cancel_flag": (I, [VP, VP]),

@@ -625,6 +625,25 @@ class Session:
         _check(self.lib.wh_get_encoder_output_device(self.handle, slot, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def _tensor(self, t) -> dict:
+        return {"data": t.data, "dtype": {0: np.float32, 1: np.float16}[t.dtype], "shape": tuple(t.shape[i] for i in range(t.ndim)), "device": t.device}
+
+    def getMelTensor(self, slot: int = 0) -> dict:
+        """wh_tensor view of slot's log-mel in HBM: {data (device pointer), dtype, shape, device}"""
+        t = L.WhTensor()
+        _check(self.lib.wh_get_mel_tensor(self.handle, slot, C.byref(t)))
+        return self._tensor(t)
+
+    def getEncoderOutputTensor(self, slot: int = 0, dtype=np.float32) -> dict:
+        t = L.WhTensor()
+        _check(self.lib.wh_get_encoder_output_tensor(self.handle, slot, 1 if np.dtype(dtype) == np.float16 else 0, C.byref(t)))
+        return self._tensor(t)
+
+    def getLogitsTensor(self) -> dict:
+        t = L.WhTensor()
+        _check(self.lib.wh_get_logits_tensor(self.handle, C.byref(t)))
+        return self._tensor(t)
+
     def getLogitsDevice(self) -> int:
         p = C.c_void_p()
         _check(self.lib.wh_get_logits_device(self.handle, C.byref(p)))

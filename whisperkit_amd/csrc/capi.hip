@@ -687,6 +687,35 @@ extern "C" int wh_get_logits_device(wh_session* s, const float** logits_dev) {
     *logits_dev = s->logits;
     return WH_OK;
 }
+static void fill_tensor(wh_tensor* t, const void* data, int dtype, int device, int64_t d0, int64_t d1) {
+    memset(t, 0, sizeof(*t));
+    t->data = const_cast<void*>(data); t->dtype = dtype; t->ndim = 2; t->shape[0] = d0; t->shape[1] = d1; t->device = device;
+}
+extern "C" int wh_get_mel_tensor(wh_session* s, int b, wh_tensor* out) {
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_mel_tensor: null output");
+    const float* p = nullptr;
+    int r = wh_get_mel_device(s, b, &p);
+    if (r) return r;
+    fill_tensor(out, p, WH_DTYPE_F32, s->m->device, s->m->dims.n_mels, kFrames);
+    return WH_OK;
+}
+extern "C" int wh_get_encoder_output_tensor(wh_session* s, int b, int dtype, wh_tensor* out) {
+    if (!out || (dtype != WH_DTYPE_F32 && dtype != WH_DTYPE_F16)) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_encoder_output_tensor: null output or unknown dtype %d", dtype);
+    const float* p32 = nullptr; const void* p16 = nullptr;
+    int r = wh_get_encoder_output_device(s, b, &p32, &p16);
+    if (r) return r;
+    fill_tensor(out, dtype == WH_DTYPE_F32 ? (const void*)p32 : p16, dtype, s->m->device, kCtx, s->m->dims.n_audio_state);
+    return WH_OK;
+}
+extern "C" int wh_get_logits_tensor(wh_session* s, wh_tensor* out) {
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_get_logits_tensor: null output");
+    const float* p = nullptr;
+    int r = wh_get_logits_device(s, &p);
+    if (r) return r;
+    fill_tensor(out, p, WH_DTYPE_F32, s->m->device, s->B, s->m->dims.n_vocab);
+    return WH_OK;
+}
+
 extern "C" int wh_session_set_alignment_postprocess(wh_session* s, int z_normalize, int median_filter_width) {
     if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_alignment_postprocess: null session");
     if (median_filter_width < 0 || median_filter_width > 15 || (median_filter_width > 1 && median_filter_width % 2 == 0))
