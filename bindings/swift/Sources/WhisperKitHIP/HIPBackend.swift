@@ -63,8 +63,8 @@ public final class HIPTextDecoder: TextDecoding {
     let model: HIPModel; let session: OpaquePointer
     public var tokenizer: WhisperTokenizer?
     public var isModelMultilingual: Bool
-    public var logitsFilters: [any LogitsFiltering]?        // user filters run only on the step API (predictLogits); the fused loop
-                                                            // applies the built-in chain of createLogitsFilters (TextDecoder.swift:857-899)
+    public var logitsFilters: [any LogitsFiltering]?        // custom filters (TextDecoder.swift:860-862): when set - or when the sampler is not a
+                                                            // GreedyTokenSampler - decodeText leaves the fused device loop for wh_decode_text_custom
     public var supportsWordTimestamps: Bool { wh_supports_word_timestamps(model.handle) != 0 }
     public var logitsSize: Int? { Int(wh_logits_size(model.handle)) }
     public var kvCacheEmbedDim: Int? { Int(wh_kv_cache_embed_dim(model.handle)) }
@@ -138,8 +138,55 @@ public final class HIPTextDecoder: TextDecoding {
             try check(wh_decode_text_beam(session, 1, Int32(beam.beamSize), beam.patience, &o, &st, prompt, Int32(prompt.count), nil, &res))
             return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
         }
+        let userFilters = logitsFilters ?? []
+        let greedy = tokenSampler as? GreedyTokenSampler
+        if !userFilters.isEmpty || greedy == nil {
+            // User-pluggable LogitsFiltering / TokenSampling (Core/Text/LogitsFilter.swift:8-10, TokenSampler.swift:8-11) run on the host once
+            // per token (TextDecoder.swift:641-652): the library drives the step API and calls back with the host logits.
+            let plug = PluginBox(filters: userFilters, sampler: greedy == nil ? tokenSampler : nil, vocab: logitsSize ?? 0)
+            let ctx = Unmanaged.passUnretained(plug).toOpaque()
+            let filterFn: wh_logits_filter_fn = { user, logits, n, tokens, nTokens in
+                let b = Unmanaged<PluginBox>.fromOpaque(user!).takeUnretainedValue()
+                b.runFilters(logits!, Int(n), (0..<Int(nTokens)).map { Int(tokens![$0]) })
+            }
+            let samplerFn: wh_token_sampler_fn = { user, logits, n, tokens, logprobs, nTokens, tokOut, lpOut in
+                let b = Unmanaged<PluginBox>.fromOpaque(user!).takeUnretainedValue()
+                let r = b.sample(logits!, Int(n), (0..<Int(nTokens)).map { Int(tokens![$0]) }, (0..<Int(nTokens)).map { logprobs![$0] })
+                tokOut!.pointee = Int32(r.token); lpOut!.pointee = r.logProb
+                return r.completed ? 1 : 0
+            }
+            var fns: [wh_logits_filter_fn?] = userFilters.isEmpty ? [] : [filterFn]      // one trampoline runs the whole custom chain in order
+            var users: [UnsafeMutableRawPointer?] = userFilters.isEmpty ? [] : [ctx]
+            try check(wh_decode_text_custom(session, &o, &st, prompt, Int32(prompt.count), temps[0], 0, &fns, &users, Int32(fns.count),
+                                            greedy == nil ? samplerFn : nil, ctx, &res))
+            if let e = plug.error { throw e }
+            return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
+        }
         try check(wh_decode_text(session, 1, &o, &st, prompt, Int32(prompt.count), &temps, nil, 0, &res))
         return decodingResult(res, options: decoderOptions, tokenizer: tokenizer)
+    }
+
+    /// Carrier of the caller's filter / sampler objects across the C callbacks of wh_decode_text_custom: logits travel as Float32
+    /// MLMultiArrays of shape [1, 1, V], the shape TextDecoderOutputType.logits has in the reference (Core/Models.swift:1041).
+    final class PluginBox {
+        let filters: [any LogitsFiltering]; let sampler: TokenSampling?; let vocab: Int
+        var error: Error?
+        init(filters: [any LogitsFiltering], sampler: TokenSampling?, vocab: Int) { self.filters = filters; self.sampler = sampler; self.vocab = vocab }
+        func wrap(_ p: UnsafePointer<Float>, _ n: Int) -> MLMultiArray? {
+            guard let a = try? MLMultiArray(shape: [1, 1, NSNumber(value: n)], dataType: .float32) else { return nil }
+            a.dataPointer.assumingMemoryBound(to: Float.self).update(from: p, count: n)
+            return a
+        }
+        func runFilters(_ logits: UnsafeMutablePointer<Float>, _ n: Int, _ tokens: [Int]) {
+            guard var a = wrap(logits, n) else { return }
+            for f in filters { a = f.filterLogits(a, withTokens: tokens) }
+            for i in 0..<n { logits[i] = a[i].floatValue }
+        }
+        func sample(_ logits: UnsafePointer<Float>, _ n: Int, _ tokens: [Int], _ logProbs: [Float]) -> (token: Int, logProb: Float, completed: Bool) {
+            guard let sampler, let a = wrap(logits, n) else { return (0, 0, true) }
+            let r = sampler.update(tokens: tokens, logits: a, logProbs: logProbs)        // SamplingResult (TokenSampler.swift:13-27)
+            return (r.tokens.last ?? 0, r.logProbs.last ?? 0, r.completed)
+        }
     }
 
     /// detectLanguage (TextDecoder.swift:420-539): one step on <|startoftranscript|>, LanguageLogitsFilter, greedy.

@@ -52,7 +52,8 @@ typedef enum wh_status {
     WH_ERR_DECODING_FAILED = 10,
     WH_ERR_INVALID_ARGUMENT = 100,
     WH_ERR_HIP = 101,
-    WH_ERR_CANCELLED = 102      /* Swift CancellationError thrown by Task.checkCancellation (Core/TranscribeTask.swift:135,144,165) */
+    WH_ERR_CANCELLED = 102,     /* Swift CancellationError thrown by Task.checkCancellation (Core/TranscribeTask.swift:135,144,165) */
+    WH_ERR_OUT_OF_MEMORY = 103  /* a host allocation failed inside the library (std::bad_alloc never crosses the C ABI) */
 } wh_status;
 
 #define WH_WINDOW_SAMPLES 480000 /* Constants.defaultWindowSamples, Core/Models.swift:1457 */
@@ -297,6 +298,25 @@ int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, con
 int wh_decode_text_languages(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,
                              const int32_t* prompt, int n_prompt, const int32_t* language_tokens, const float* temperatures,
                              const int32_t* active, uint64_t seed, wh_decoding_result* out /* [batch] */);
+/* ---- user-pluggable LogitsFiltering / TokenSampling (Core/Text/LogitsFilter.swift:8-10, Core/Text/TokenSampler.swift:8-11) ----
+ * The reference runs `logitsFilters` (custom filters first, Core/TextDecoder.swift:857-899) and the `TokenSampling` object on the
+ * host once per token (:641-652).  The fused device loop of wh_decode_text knows the four built-in filters and the greedy /
+ * top-k sampler only; a caller with its own filter or sampler decodes through this entry point instead: the reference's
+ * decodeText loop (:573-757) on the host over the step API, one slot (slot 0) - per token one wh_predict_logits, the caller's
+ * filters in order on the host logits (in place), the built-in chain of `opt` on the device (wh_filter_logits), then the
+ * caller's sampler or, with sampler == NULL, GreedyTokenSampler(temperature, top_k, seed) exactly as the device loop samples.
+ *   filter:  LogitsFiltering.filterLogits(_:withTokens:) - modify logits[0 .. n_logits) in place; tokens = currentTokens
+ *   sampler: TokenSampling.update(tokens:logits:logProbs:) - write the sampled id and its log-probability; return non-zero
+ *            when decoding is complete (SamplingResult.completed); the loop appends EOT like TokenSampling.finalize if the
+ *            caller's last token is not EOT (GreedyTokenSampler.finalize, TokenSampler.swift:242-251).
+ * Progress callback, cancel flag and alignment rows behave as in wh_decode_text (the callback fires after every token). */
+typedef void (*wh_logits_filter_fn)(void* user, float* logits, int32_t n_logits, const int32_t* tokens, int32_t n_tokens);
+typedef int32_t (*wh_token_sampler_fn)(void* user, const float* logits, int32_t n_logits, const int32_t* tokens, const float* logprobs,
+                                       int32_t n_tokens, int32_t* token_out, float* logprob_out);
+int wh_decode_text_custom(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                          int n_prompt, float temperature, uint64_t seed, const wh_logits_filter_fn* filters,
+                          void* const* filter_users, int n_filters, wh_token_sampler_fn sampler, void* sampler_user,
+                          wh_decoding_result* out /* [1] */);
 /* ---- beam search: NO REFERENCE BEHAVIOUR ------------------------------------------------------------------------------
  * BeamSearchTokenSampler (Core/Text/TokenSampler.swift:254-290) exists in the reference as a class whose update / finalize are
  * fatalError("Not implemented").  These entry points keep its construction parameters (beamSize, eotToken, patience,

@@ -148,6 +148,50 @@ class DecoderState:
                 self.alignment_written[pos + 1] = True
         return logits.numpy()
 
+    def forward_full(self, tokens: Sequence[int], logits_at: Optional[Sequence[int]] = None, want_alignment: bool = True):
+        """Teacher-forced pass over positions 0 .. len(tokens) - 1 in ONE causal forward (openai/whisper TextDecoder.forward with a
+        causal mask, model.py / modeling_whisper.py:431-446): the same function of (tokens, encoder output) as len(tokens) calls of
+        `step`, at the cost of a few of them - what makes full-depth checks (32 layers, 223 positions) affordable on the CPU.
+        Fills the K/V caches and the alignment rows exactly like the stepped calls (a following `step(t, len(tokens))` continues the
+        sequence) and returns {position: logits [V]} for the positions in `logits_at` (default: all).  Pinned against `step` by
+        tests/test_oracle_golden.py (same values to fp32 round-off)."""
+        m, w, dims = self.m, self.m.w, self.m.dims
+        nh = dims.n_text_head
+        n = len(tokens)
+        assert 0 < n <= self.MAX_CTX
+        ids = torch.tensor([int(t) for t in tokens], dtype=torch.long)
+        with torch.no_grad():
+            x = w["decoder.token_embedding.weight"][ids] + w["decoder.positional_embedding"][:n]
+            mask = torch.full((n, n), float("-inf")).triu_(1)
+            align_rows = []
+            for i in range(dims.n_text_layer):
+                p = f"decoder.blocks.{i}"
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".attn_ln.weight"], w[p + ".attn_ln.bias"])
+                q = F.linear(xn, w[p + ".attn.query.weight"], w[p + ".attn.query.bias"])
+                self.k[i][:n] = self._store(F.linear(xn, w[p + ".attn.key.weight"]))
+                self.v[i][:n] = self._store(F.linear(xn, w[p + ".attn.value.weight"], w[p + ".attn.value.bias"]))
+                x = x + m._attend(p + ".attn", q, self.k[i][:n], self.v[i][:n], nh, mask=mask)
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".cross_attn_ln.weight"], w[p + ".cross_attn_ln.bias"])
+                q = F.linear(xn, w[p + ".cross_attn.query.weight"], w[p + ".cross_attn.query.bias"])
+                o, pr = m._attend(p + ".cross_attn", q, self.cross_k[i], self.cross_v[i], nh, return_qk=True)
+                x = x + o
+                for (l, h) in m.alignment_heads:
+                    if l == i:
+                        align_rows.append(pr[h])                       # [n, 1500]
+                xn = F.layer_norm(x, (x.shape[-1],), w[p + ".mlp_ln.weight"], w[p + ".mlp_ln.bias"])
+                hdn = F.gelu(F.linear(xn, w[p + ".mlp.0.weight"], w[p + ".mlp.0.bias"]))
+                x = x + F.linear(hdn, w[p + ".mlp.2.weight"], w[p + ".mlp.2.bias"])
+            x = F.layer_norm(x, (x.shape[-1],), w["decoder.ln.weight"], w["decoder.ln.bias"])
+            pos = list(range(n)) if logits_at is None else [int(p_) for p_ in logits_at]
+            lg = F.linear(x[pos], w["decoder.token_embedding.weight"]).numpy()
+            if want_alignment and align_rows:
+                rows = torch.stack(align_rows)                         # [heads, n, 1500]
+                last = min(n, self.MAX_CTX - 1)                        # row pos + 1 for pos = 0 .. last - 1
+                self.alignment[1:last + 1] = rows.mean(0)[:last].numpy()
+                self.alignment_heads[1:last + 1] = rows.permute(1, 0, 2)[:last].numpy()
+                self.alignment_written[1:last + 1] = True
+        return {p_: lg[i] for i, p_ in enumerate(pos)}
+
     def postprocessed_alignment(self, z_normalize: bool = True, median_filter_width: int = 7) -> np.ndarray:
         """openai/whisper timing.py find_alignment / transformers generation_whisper.py:341-349 on the rows written so far:
         weights [heads, tokens, frames] -> (w - mean over tokens) / std over tokens (unbiased=False) -> median filter along the

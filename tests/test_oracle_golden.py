@@ -70,3 +70,32 @@ def test_weight_blob_roundtrip():
     assert t["enc.conv1.w"].shape == (dims.n_audio_state, 3 * dims.n_mels)
     # conv tap re-ordering [co][kk][ci]
     np.testing.assert_array_equal(t["enc.conv1.w"][5, 1 * dims.n_mels + 7], np.float16(sd["encoder.conv1.weight"][5, 7, 1]))
+
+
+def test_forward_full_equals_stepped_decoder(jfk_pcm):
+    """The one-pass teacher-forced decoder (DecoderState.forward_full, used by the full-depth GPU tests) is the same function as the
+    per-token `step` the reference's call pattern dictates (Core/TextDecoder.swift:573-717) - logits, caches and alignment rows -
+    and therefore pinned to the same HF golden vectors."""
+    g = golden("hf_model_micro.npz")
+    dims = W.MODEL_DIMS["test-micro"]
+    m = OracleWhisper(dims, W.synthetic_state_dict(dims, seed=0))
+    enc = m.encode(omel.log_mel_spectrogram(jfk_pcm, dims.n_mels).astype(np.float32))
+    toks = [int(t) for t in g["tokens"]] + [400, 370, 452, 50364, 13]
+    a, b = m.new_state(enc), m.new_state(enc)
+    stepped = [a.step(t, p) for p, t in enumerate(toks)]
+    full = b.forward_full(toks)
+    ls = int(g["logit_stride"])
+    for p in range(len(toks)):
+        np.testing.assert_allclose(full[p], stepped[p], atol=2e-5, rtol=0)
+        if p < len(g["tokens"]):
+            np.testing.assert_allclose(full[p][::ls], g["logits"][p], atol=2e-4, rtol=0)
+    n = len(toks)
+    np.testing.assert_allclose(b.alignment[: n + 1], a.alignment[: n + 1], atol=1e-6, rtol=0)
+    assert (b.alignment_written == a.alignment_written).all()
+    for i in range(dims.n_text_layer):
+        np.testing.assert_allclose(b.k[i][:n].numpy(), a.k[i][:n].numpy(), atol=1e-5, rtol=0)
+    # a stepped call continues a one-pass prefix; a subset of positions returns the same rows
+    np.testing.assert_allclose(b.step(1029, n), a.step(1029, n), atol=2e-5, rtol=0)
+    sub = m.new_state(enc).forward_full(toks, logits_at=[0, 5, n - 1])
+    assert sorted(sub) == [0, 5, n - 1]
+    np.testing.assert_allclose(sub[5], full[5], atol=1e-6, rtol=0)

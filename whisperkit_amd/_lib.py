@@ -74,6 +74,10 @@ class WhProgress(C.Structure):
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(WhProgress))
+# wh_logits_filter_fn / wh_token_sampler_fn: LogitsFiltering.filterLogits / TokenSampling.update as C callbacks (wh_decode_text_custom)
+LOGITS_FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.c_int32)
+TOKEN_SAMPLER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32,
+                               C.POINTER(C.c_int32), C.POINTER(C.c_float))
 
 
 class WhTimings(C.Structure):
@@ -126,6 +130,8 @@ SYMBOLS = {
     "wh_sample_token": (I, [VP, VP, I, F, I, U64, I, PI32, PF]),
     "wh_decode_text": (I, [VP, I, POPT, PST, PI32, I, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
     "wh_decode_text_languages": (I, [VP, I, POPT, PST, PI32, I, PI32, PF, PI32, U64, C.POINTER(WhDecodingResult)]),
+    "wh_decode_text_custom": (I, [VP, POPT, PST, PI32, I, F, U64, C.POINTER(LOGITS_FILTER_FN), PVP, I, TOKEN_SAMPLER_FN, VP,
+                                  C.POINTER(WhDecodingResult)]),
     "wh_detect_language": (I, [VP, I, PST, PI32, PF]),
     "wh_decode_text_beam": (I, [VP, I, I, F, POPT, PST, PI32, I, PI32, C.POINTER(WhDecodingResult)]),
     "wh_beam_sampler_create": (I, [I, C.c_int32, F, PVP]),

@@ -588,6 +588,52 @@ class Session:
                                                      None if act is None else act.ctypes.data_as(L.PI32), seed, res))
         return [DecodingResult.from_c(r) for r in res]
 
+    def decodeTextCustom(self, prompt: Sequence[int], options: DecodingOptions, logitsFilters: Sequence = (), sampler=None,
+                         temperature: Optional[float] = None, seed: int = 0, specialTokens=None) -> DecodingResult:
+        """TextDecoding.decodeText with the caller's own `LogitsFiltering` / `TokenSampling` objects (Core/Text/LogitsFilter.swift:8-10,
+        Core/Text/TokenSampler.swift:8-11), which the reference runs on the host once per token (Core/TextDecoder.swift:641-652) and
+        the fused device loop cannot: wh_decode_text_custom drives the step API for slot 0 - custom filters first, then the built-in
+        chain of `options`, then the sampler (None: GreedyTokenSampler as the device loop samples).
+          filter:  object with filterLogits(logits: np.ndarray[V] float32, tokens: List[int]) -> np.ndarray[V]  (a new array or the same)
+          sampler: object with update(tokens: List[int], logits: np.ndarray[V], logProbs: List[float]) -> (token, logProb, completed)"""
+        st = specialTokens if specialTokens is not None else self.model.specialTokens
+        o = options.to_c()
+        p = np.ascontiguousarray(list(prompt), dtype=np.int32)
+        errors = []
+
+        def mk_filter(f):
+            def tramp(_user, logits, n, tokens, n_tokens):
+                try:
+                    view = np.ctypeslib.as_array(logits, shape=(n,))
+                    out = f.filterLogits(view.copy(), [tokens[i] for i in range(n_tokens)])
+                    view[:] = np.asarray(out, dtype=np.float32)
+                except Exception as e:        # an exception must not unwind through the C frames
+                    errors.append(e)
+            return L.LOGITS_FILTER_FN(tramp)
+
+        fns = [mk_filter(f) for f in logitsFilters]
+        table = (L.LOGITS_FILTER_FN * max(len(fns), 1))(*fns)
+
+        def samp_tramp(_user, logits, n, tokens, logprobs, n_tokens, tok_out, lp_out):
+            try:
+                tok, lp, done = sampler.update([tokens[i] for i in range(n_tokens)], np.ctypeslib.as_array(logits, shape=(n,)).copy(),
+                                               [logprobs[i] for i in range(n_tokens)])
+                tok_out[0], lp_out[0] = int(tok), float(lp)
+                return int(bool(done))
+            except Exception as e:
+                errors.append(e)
+                tok_out[0], lp_out[0] = int(st.end_token), 0.0
+                return 1
+        samp = L.TOKEN_SAMPLER_FN(samp_tramp) if sampler is not None else L.TOKEN_SAMPLER_FN()
+        res = L.WhDecodingResult()
+        rc = self.lib.wh_decode_text_custom(self.handle, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                                            options.temperature if temperature is None else temperature, seed,
+                                            table if fns else None, None, len(fns), samp, None, C.byref(res))
+        if errors:
+            raise errors[0]
+        _check(rc)
+        return DecodingResult.from_c(res)
+
     def decodeTextBeam(self, prompt: Sequence[int], options: DecodingOptions, nAudio: int = 1, beamSize: int = 5, patience: float = 1.0,
                        specialTokens=None, languageTokens: Optional[Sequence[int]] = None) -> List[DecodingResult]:
         """Beam search at temperature 0 (wh_decode_text_beam) for the windows prepared in slots [0, nAudio); audio a then occupies

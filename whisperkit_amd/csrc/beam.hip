@@ -127,7 +127,7 @@ extern "C" int wh_beam_sampler_create(int beam_size, int32_t eot_token, float pa
     if (beam_size <= 0 || beam_size + 1 > kBeamTopK || max_candidates <= 0)
         return set_error(WH_ERR_INVALID_ARGUMENT, "Invalid beam size %d or patience %g (beam sizes 1..%d)", beam_size, patience, kBeamTopK - 1);   // fatalError in the reference (:273)
     wh_beam_sampler* h = new (std::nothrow) wh_beam_sampler();
-    if (!h) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_beam_sampler_create: out of memory");
+    if (!h) return set_error(WH_ERR_OUT_OF_MEMORY, "wh_beam_sampler_create: out of host memory");
     h->b.beam_size = beam_size; h->b.eot = eot_token; h->b.patience = patience; h->b.max_candidates = max_candidates;
     *out = h;
     return WH_OK;
@@ -147,7 +147,7 @@ static void unpack_beams(int n_beams, int len, const int32_t* tokens, const floa
     }
 }
 
-extern "C" int wh_beam_sampler_update(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
+static int wh_beam_sampler_update_impl(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
                                       const float* topk_logprobs, const int32_t* topk_tokens, int topk_stride, int32_t* new_tokens,
                                       float* new_token_logprobs, float* new_sums, int32_t* sources, int32_t* n_new, int32_t* completed) {
     if (!h || !tokens || !sums || !topk_logprobs || !topk_tokens || !new_tokens || !new_sums || !sources || !n_new || !completed || n_beams < 1 || len < 1 ||
@@ -168,7 +168,7 @@ extern "C" int wh_beam_sampler_update(wh_beam_sampler* h, int n_beams, int len, 
     return WH_OK;
 }
 
-extern "C" int wh_beam_sampler_finalize(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
+static int wh_beam_sampler_finalize_impl(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
                                         int sample_begin, int capacity, int32_t* best_tokens, float* best_token_logprobs, int32_t* best_len,
                                         float* best_sum, int32_t* n_finished) {
     if (!h || !tokens || !sums || !best_tokens || !best_len || n_beams < 1 || len < 1 || sample_begin < 0)
@@ -227,10 +227,10 @@ int copy_pairs(wh_session* s, const std::vector<int>& pairs, bool cross, const f
 }
 }  // namespace
 
-extern "C" int wh_decode_text_beam(wh_session* s, int n_audio, int beam_size, float patience, const wh_decoding_options* opt,
+static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, float patience, const wh_decoding_options* opt,
                                    const wh_special_tokens* st, const int32_t* prompt, int n_prompt, const int32_t* language_tokens,
                                    wh_decoding_result* out) {
-    if (!s || !s->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_decode_text_beam: session/model is null (modelsUnavailable)");
+    CHECK_SESSION(s);       // selects the session's device: the beam buffers below are allocated on first use, from any host thread
     if (!opt || !st || !prompt || !out) return set_error(WH_ERR_DECODING_FAILED, "wh_decode_text_beam: null argument");
     const int max_candidates = (int)((float)beam_size * patience);
     if (beam_size <= 0 || beam_size + 1 > kBeamTopK || max_candidates <= 0)
@@ -378,4 +378,21 @@ extern "C" int wh_decode_text_beam(wh_session* s, int n_audio, int beam_size, fl
         whi::finalize_decoding_result(fin, opt, st, 0.0f, &out[a]);
     }
     return WH_OK;
+}
+
+// ---- C-ABI shims: the bodies above allocate std::vectors (per token inside the beam loop); no exception leaves the library
+extern "C" int wh_beam_sampler_update(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
+                                      const float* topk_logprobs, const int32_t* topk_tokens, int topk_stride, int32_t* new_tokens,
+                                      float* new_token_logprobs, float* new_sums, int32_t* sources, int32_t* n_new, int32_t* completed) {
+    WH_TRY return wh_beam_sampler_update_impl(h, n_beams, len, tokens, token_logprobs, sums, topk_logprobs, topk_tokens, topk_stride, new_tokens, new_token_logprobs, new_sums, sources, n_new, completed); WH_CATCH("wh_beam_sampler_update")
+}
+extern "C" int wh_beam_sampler_finalize(wh_beam_sampler* h, int n_beams, int len, const int32_t* tokens, const float* token_logprobs, const float* sums,
+                                        int sample_begin, int capacity, int32_t* best_tokens, float* best_token_logprobs, int32_t* best_len,
+                                        float* best_sum, int32_t* n_finished) {
+    WH_TRY return wh_beam_sampler_finalize_impl(h, n_beams, len, tokens, token_logprobs, sums, sample_begin, capacity, best_tokens, best_token_logprobs, best_len, best_sum, n_finished); WH_CATCH("wh_beam_sampler_finalize")
+}
+extern "C" int wh_decode_text_beam(wh_session* s, int n_audio, int beam_size, float patience, const wh_decoding_options* opt,
+                                   const wh_special_tokens* st, const int32_t* prompt, int n_prompt, const int32_t* language_tokens,
+                                   wh_decoding_result* out) {
+    WH_TRY return wh_decode_text_beam_impl(s, n_audio, beam_size, patience, opt, st, prompt, n_prompt, language_tokens, out); WH_CATCH("wh_decode_text_beam")
 }

@@ -238,7 +238,7 @@ static int model_create_impl(const void* blob, size_t nbytes, int device, wh_mod
     if (D.n_audio_ctx != kCtx || D.n_audio_state < 64 || D.n_audio_state % 64 || D.n_audio_head < 1 || D.n_text_head < 1 ||
         D.n_audio_state / D.n_audio_head != 64 || D.n_audio_state % D.n_audio_head || D.n_text_state / D.n_text_head != 64 || D.n_text_state % D.n_text_head ||
         D.n_audio_state != D.n_text_state || D.n_audio_state > 1280 || (D.n_mels != 80 && D.n_mels != 128) ||
-        D.n_audio_layer < 1 || D.n_audio_layer > 64 || D.n_text_layer < 1 || D.n_text_layer > 64 || D.n_vocab < 51864 || D.n_vocab > 65536 ||
+        D.n_audio_layer < 1 || D.n_audio_layer > 64 || D.n_text_layer < 1 || D.n_text_layer > 64 || D.n_vocab < 51864 || D.n_vocab > kMaxVocab ||
         D.n_text_ctx < kMaxTok || D.n_text_ctx > 4096 || n_tensors <= 0 || n_tensors > 65536 ||
         56 + (size_t)n_tensors * sizeof(BlobEntry) > nbytes) {
         delete m;
@@ -439,11 +439,6 @@ extern "C" int wh_session_synchronize(wh_session* s) {
 }
 extern "C" void* wh_session_stream(wh_session* s) { return s ? (void*)s->st : nullptr; }
 
-// the HIP current device is per host thread: sessions are driven from worker threads, so every entry point re-selects it
-#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); \
-                              if (hipSetDevice((s)->m->device) != hipSuccess) return set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
-#define CHECK_SLOT(s, b) do { if ((b) < 0 || (b) >= (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: slot %d out of range [0,%d)", __func__, (b), (s)->B); } while (0)
-#define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
 
 // ------------------------------------------------------------------------------------------------ audio / mel
 static int set_audio_common(wh_session* s, int b, const float* pcm, int n, hipMemcpyKind kind) {
@@ -578,6 +573,7 @@ int ensure_align(wh_session* s) {
         drop_session_graphs(s);
         hipFree(s->align);
         s->align = nullptr;
+        s->n_align_alloc = 0;      // nothing is allocated: sizes derived from it (graph keys, align_tmp) must not see the old head count
     }
     if (!s->align && s->m->n_align > 0) {
         size_t n = (size_t)s->B * kMaxTok * s->m->n_align * kCtx;

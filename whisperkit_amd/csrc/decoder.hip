@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
 // ---------------------------------------------------------------------------------------------- sampler
 constexpr int SAMP_T = 1024;
 constexpr int SAMP_E = 51;   // ceil(51866 / 1024)
+static_assert(SAMP_T * SAMP_E >= kMaxVocab, "sampler_kernel keeps the whole logits row in registers");
 
 struct BlockRed {
     float f[32];
@@ -619,11 +620,19 @@ void launch_rules_init(const SamplerCfg* cfg_dev, SeqState* seq, int batch, hipS
 
 // ---------------------------------------------------------------------------------------------- launchers
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static unsigned long long* g_dbg_buf = nullptr;   // [KK_COUNT][4096][8]
+// WH_DBG=1 timeline probe buffer [KK_COUNT][4096][8], allocated once per process (thread-safe function-local static)
 unsigned long long* debug_buffer() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("WH_DBG"); on = (e && e[0] == '1'); if (on) { (void)hipMalloc((void**)&g_dbg_buf, (size_t)KK_COUNT * 4096 * 8 * 8); (void)hipMemset(g_dbg_buf, 0, (size_t)KK_COUNT * 4096 * 8 * 8); } }
-    return g_dbg_buf;
+    static unsigned long long* const buf = [] {
+        unsigned long long* p = nullptr;
+        const char* e = getenv("WH_DBG");
+        if (e && e[0] == '1') {
+            const size_t bytes = (size_t)KK_COUNT * 4096 * 8 * 8;
+            if (hipMalloc((void**)&p, bytes) != hipSuccess) p = nullptr;
+            else (void)hipMemset(p, 0, bytes);
+        }
+        return p;
+    }();
+    return buf;
 }
 
 int cross_attn_splits(int batch, int n_head) {

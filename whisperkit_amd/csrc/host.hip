@@ -27,10 +27,6 @@ int upload_sampler_cfg(wh_session* s, const wh_decoding_options* opt, const wh_s
                        int initial_prompt_index, int language_filter, uint64_t seed);
 }
 
-// the HIP current device is per host thread: sessions are driven from worker threads, so every entry point re-selects it
-#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); \
-                              if (hipSetDevice((s)->m->device) != hipSuccess) return set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
-#define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
 
 // CFAbsoluteTimeGetCurrent(): seconds since 2001-01-01 00:00:00 UTC
 static inline double cf_absolute_time() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - 978307200.0; }
@@ -437,6 +433,81 @@ static int decode_text_impl(wh_session* s, int batch, const wh_decoding_options*
     for (int b = 0; b < batch; ++b) {
         if (!s->seq_host[b].active) { memset(&out[b], 0, sizeof(out[b])); continue; }
         whi::finalize_decoding_result(s->seq_host[b], opt, st, s->seq_host[b].temperature, &out[b]);
+    }
+    return WH_OK;
+}
+
+// decodeText with caller-supplied LogitsFiltering / TokenSampling objects: the reference's host loop (Core/TextDecoder.swift:573-757)
+// over the step API - what the fused device loop cannot run (it knows the built-in filters and the greedy / top-k sampler only).
+extern "C" int wh_decode_text_custom(wh_session* s, const wh_decoding_options* opt, const wh_special_tokens* st, const int32_t* prompt,
+                                     int n_prompt, float temperature, uint64_t seed, const wh_logits_filter_fn* filters,
+                                     void* const* filter_users, int n_filters, wh_token_sampler_fn sampler, void* sampler_user,
+                                     wh_decoding_result* out) {
+    CHECK_SESSION(s);
+    if (!opt || !st || !prompt || !out) return set_error(WH_ERR_DECODING_FAILED, "wh_decode_text_custom: null argument");
+    if (n_prompt < 1 || n_prompt >= kMaxTok) return set_error(WH_ERR_PREFILL_FAILED, "wh_decode_text_custom: prompt length %d out of range [1,%d)", n_prompt, kMaxTok);
+    if (n_filters < 0 || (n_filters > 0 && !filters)) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_decode_text_custom: %d filters but no filter table", n_filters);
+    const int V = s->m->dims.n_vocab;
+    for (int i = 0; i < n_prompt; ++i)
+        if (prompt[i] < 0 || prompt[i] >= V) return set_error(WH_ERR_PREFILL_FAILED, "wh_decode_text_custom: prompt token %d out of vocabulary", prompt[i]);
+    try {
+        int r = wh_reset_decoder_inputs(s, 1);
+        if (r) return r;
+        std::vector<float> logits((size_t)V);
+        SeqState q;                                       // the loop state, in the layout finalize_decoding_result reads
+        memset(&q, 0, sizeof(q));
+        for (int i = 0; i < n_prompt; ++i) q.tokens[i] = prompt[i];
+        q.n_tokens = n_prompt; q.prompt_len = n_prompt; q.active = 1;
+        const float temp = f16_round(temperature);        // GreedyTokenSampler.temperature is FloatType (TokenSampler.swift:30)
+        const int prefilled_index = 0, loop_count = std::min(opt->sample_length, kMaxTok - 1);
+        const bool has_thr = !isnan(opt->first_token_log_prob_threshold);
+        int next = prompt[n_prompt - 1];                  // :566 nextToken = currentTokens.last
+        for (int ti = prefilled_index; ti < loop_count; ++ti) {
+            CHECK_CANCEL(s);
+            const bool is_prefill = ti < n_prompt - 1, is_last_prefill = ti == n_prompt - 1, is_first = ti == prefilled_index;
+            if (ti < n_prompt) {                          // :581-594
+                const bool is_ts = q.tokens[ti] >= st->time_token_begin, pred_ts = next >= st->time_token_begin;
+                if (!(is_last_prefill && is_ts && pred_ts)) next = q.tokens[ti];
+                else q.tokens[ti] = next;
+            }
+            const int32_t tok_in = next, pos_in = ti;
+            r = wh_predict_logits(s, 1, &tok_in, &pos_in, logits.data());                       // :611-633
+            if (r) return r;
+            if (opt->float16_logits) for (auto& v : logits) v = (float)(_Float16)v;             // FloatType logits (Core/Models.swift:1041)
+            q.steps += 1;
+            for (int f = 0; f < n_filters; ++f)                                                 // custom filters come first (:860-862)
+                if (filters[f]) filters[f](filter_users ? filter_users[f] : nullptr, logits.data(), V, q.tokens, q.n_tokens);
+            r = wh_filter_logits(s, opt, st, q.tokens, q.n_tokens, prefilled_index, n_prompt, 0, logits.data(), V);   // :641-643
+            if (r) return r;
+            int32_t tok = 0; float lp = 0.0f; bool completed;
+            if (sampler) {
+                completed = sampler(sampler_user, logits.data(), V, q.tokens, q.logprobs, q.n_tokens, &tok, &lp) != 0;       // :652
+                if (tok < 0 || tok >= V) return set_error(WH_ERR_DECODING_FAILED, "wh_decode_text_custom: the sampler returned token %d (vocabulary %d)", tok, V);
+            } else {
+                r = wh_sample_token(s, logits.data(), V, temp, opt->top_k, seed, ti, &tok, &lp);
+                if (r) return r;
+                completed = tok == st->end_token;
+            }
+            next = tok;
+            const bool too_low = is_first && has_thr && lp < opt->first_token_log_prob_threshold;   // :662-667
+            q.first_token_too_low = too_low ? 1 : 0;
+            if (completed || q.n_tokens >= kMaxTok - 1 || too_low) break;                        // :669-674
+            if (!is_prefill) { q.tokens[q.n_tokens] = tok; q.logprobs[q.n_tokens] = lp; q.n_tokens += 1; }   // :682-686
+            if (s->progress_cb && !is_prefill) {                                                  // :723-755
+                s->seq_host[0] = q;
+                s->skip_special_in_progress = opt->skip_special_tokens != 0;
+                s->special_begin_in_progress = st->special_token_begin;
+                SeqState keep = q;
+                r = report_progress(s, 1);
+                if (r) return r;
+                const bool stop = s->seq_host[0].done != 0;
+                q = keep;
+                if (stop) break;
+            }
+        }
+        whi::finalize_decoding_result(q, opt, st, temp, out);
+    } catch (const std::bad_alloc&) {
+        return set_error(WH_ERR_OUT_OF_MEMORY, "wh_decode_text_custom: out of host memory");
     }
     return WH_OK;
 }

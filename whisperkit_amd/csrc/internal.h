@@ -1,6 +1,8 @@
 // Internal model / session structures behind the opaque C-ABI handles.
 #pragma once
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -103,6 +105,15 @@ int set_error(int code, const char* fmt, ...);
         if (_e != hipSuccess) return whi::set_error(WH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 #define WH_CHECK_LAUNCH() WH_HIP(hipGetLastError())
+// the HIP current device is per host thread: sessions are driven from worker threads, so every session entry point re-selects it
+#define CHECK_SESSION(s) do { if (!(s) || !(s)->m) return whi::set_error(WH_ERR_MODELS_UNAVAILABLE, "%s: session/model is null (modelsUnavailable)", __func__); \
+                              if (hipSetDevice((s)->m->device) != hipSuccess) return whi::set_error(WH_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (s)->m->device); } while (0)
+#define CHECK_SLOT(s, b) do { if ((b) < 0 || (b) >= (s)->B) return whi::set_error(WH_ERR_INVALID_ARGUMENT, "%s: slot %d out of range [0,%d)", __func__, (b), (s)->B); } while (0)
+#define CHECK_BATCH(s, n) do { if ((n) < 1 || (n) > (s)->B) return whi::set_error(WH_ERR_INVALID_ARGUMENT, "%s: batch %d out of range [1,%d]", __func__, (n), (s)->B); } while (0)
+// C++ exceptions never cross the C ABI: entry points that allocate on the host wrap their body in WH_TRY / WH_CATCH
+#define WH_TRY try {
+#define WH_CATCH(name) } catch (const std::bad_alloc&) { return whi::set_error(WH_ERR_OUT_OF_MEMORY, "%s: out of host memory", name); } \
+                         catch (const std::exception& e_) { return whi::set_error(WH_ERR_INVALID_ARGUMENT, "%s: %s", name, e_.what()); }
 
 wh::DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position = wh::kMaxTok - 1);
 void drop_session_graphs(wh_session* s);

@@ -181,6 +181,11 @@ struct DecodeBuffers {
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
 constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
+// Largest vocabulary the sampling kernels cover: sampler_kernel holds SAMP_T x SAMP_E = 1024 x 51 ids in registers, the fused greedy
+// path writes one statistics record per 32 logits rows (kStatBlocks of them).  wh_model_create rejects anything larger (Whisper
+// vocabularies are 51864 / 51865 / 51866, Utilities/ModelUtilities.swift:124-170).
+constexpr int kMaxVocab = 52224;
+static_assert(kMaxVocab <= kStatBlocks * 32, "fused greedy sampler: one statistics record per 32-row logits tile");
 constexpr int kMaxSplit = 24;   // cross-attention key splits (64 keys per workgroup at the finest)
 constexpr int kPartStride = 96; // floats per split partial (m, l, o[64]) padded to 3 x 128 bytes: no cache line is shared between splits
 int cross_attn_splits(int batch, int n_head);
