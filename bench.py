@@ -8,14 +8,20 @@ it - "PCM in host memory -> token ids + segments on host": padOrTrim from host f
 encoder -> cross-K/V projection -> greedy token loop (WhisperKit decodeText semantics, filters + sampler on device) ->
 findSeekPointAndSegments per chunk on the host -> result records (+ all-gather over RCCL when N > 1).
 
-Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step and GPU
-(two 32-slot MFMA batch tiles per decode launch), 3 steps in flight (one session / HIP stream / host thread each: the encoder
+Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step
+(two 32-slot MFMA batch tiles per decode launch), 3 device batches in flight (one session / HIP stream / host thread each: the encoder
 GEMMs and the latency-bound projection kernels of one batch overlap the HBM-bound cross-attention stream of the others), greedy.
 Measured alternatives on one MI355X (profiles/r02n_*, r02o_*): 32 x 3 in flight 1521 audio-s/s, 64 x 2 1621, 64 x 3 1674, 64 x 4 1715,
 96 x 2 1695, 128 x 1 1615, 128 x 2 1735.  Weights are random-init (no checkpoints in
 the image), so EOT is never the argmax and the loop runs to the reference's length cap (sampleLength 224 -> 223 decoder forward
 passes per chunk): the decode length is fixed and comparable across runs.  Round 1's configuration (8 chunks per step, 3 in
 flight) and the other BASELINE configs are measured after the headline and reported under "other_configs".
+
+N > 1 (configs[3]: "64 x 30 s chunks sharded across 8 x MI355X"): STRONG scaling by default - a step is still 64 chunks in total,
+block-partitioned over the ranks (64 / N per GPU, no data-path collective), the per-chunk result records of every step are
+all-gathered through the C-ABI communicator (wh_comm_*: ncclAllGather over xGMI, librccl dlopen'ed by libwhisperhip).  A GPU packs
+its shares of G = N consecutive steps into one full device batch (continuous batching: the 64 slots / 3 batches in flight of the
+1-GPU line, so the kernels run at the batch size they are tuned for); `--scaling weak` is the old mode (64 chunks per step AND GPU).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   `roofline`      the dominant kernel of the step, HIP-event timed on the session stream (wh_measure_kernels), against the
@@ -163,7 +169,11 @@ def get_model(name, local_rank, keep_sd=False):
     return _MODELS[name]
 
 
-def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False):
+def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False,
+               comm=None, scaling="strong"):
+    """B = chunks per step: in total over the ranks (strong scaling, the default) or per rank (weak).  A rank's share of a step is the
+    contiguous block partition_chunks gives it; the shares of G consecutive steps are packed into one device batch of at most the
+    1-GPU batch size (G = 1 at one GPU and in weak mode)."""
     import torch
     import torch.distributed as dist
     from whisperkit_amd import api, parallel
@@ -171,52 +181,65 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
 
     model, dims, sd = get_model(model_name, local_rank, keep_sd=want_cpu)
     F = max(1, F)
-    sessions = [api.Session(model, B) for _ in range(F)]
+    total = B * world if scaling == "weak" else B               # chunks of one step over all ranks
+    first, last = parallel.partition_chunks(total, world, rank)
+    n_local = last - first                                       # this rank's chunks of one step
+    per_rank_max = (total + world - 1) // world
+    cap = max(B, n_local)                                        # device batch capacity = the 1-GPU batch
+    G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch
+    slots = max(1, G * n_local)
+    sessions = [api.Session(model, slots) for _ in range(F)]
     sess = sessions[0]
-    # weak scaling: every rank owns B chunks per step; global chunk index = rank * B + b
-    first, _ = parallel.partition_chunks(world * B, world, rank)
-    chunks = [np.ascontiguousarray(synthetic_chunk(1234 + first + b), dtype=np.float32) for b in range(B)]   # host float32 PCM
+    chunks = [np.ascontiguousarray(synthetic_chunk(1234 + first + b), dtype=np.float32) for b in range(n_local)]   # host float32 PCM
     opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
                                noSpeechThreshold=None, temperatureFallbackCount=0, sampleLength=args.sample_length,
                                wordTimestamps=word_timestamps)
     prompt = sess.prefillPrompt(opts)
     st = model.specialTokens
 
-    def hot_path(ss):
-        for b, x in enumerate(chunks):
-            ss.padOrTrim(x, b)                     # PCM in host memory -> HBM, inside the timed region
-        ss.logMelSpectrogram(B)
-        ss.encodeFeatures(B)
-        ss.prepareDecoderInputs(B)
-        res = ss.decodeText(prompt, opts, batch=B)
+    def hot_path(ss, g=1):
+        """the rank's chunks of g consecutive steps as ONE device batch; returns (results, [records of step 0, step 1, ...], segments)"""
+        nb = g * n_local
+        if nb == 0:
+            return [], [np.zeros((0, parallel.RECORD_INTS), np.int32) for _ in range(g)], 0
+        for k in range(g):
+            for b, x in enumerate(chunks):
+                ss.padOrTrim(x, k * n_local + b)       # PCM in host memory -> HBM, inside the timed region (SURVEY 8d)
+        ss.logMelSpectrogram(nb)
+        ss.encodeFeatures(nb)
+        ss.prepareDecoderInputs(nb)
+        res = ss.decodeText(prompt, opts, batch=nb)
         nseg = 0
         for b, r in enumerate(res):
             if word_timestamps:     # findAlignment (SegmentSeeker.swift:340-408): alignment rows of the result tokens -> DTW
                 api.dynamicTimeWarping(ss.getAlignmentWeights(b)[:len(r.tokens)])
             _, segs = api.findSeekPointAndSegments(r.tokens, r.tokenLogProbs, opts, st, 0, 0, 480000, r.avgLogProb)   # segments on the host
             nseg += len(segs or ())
-        recs = np.stack([parallel.pack_record(first + b, r.tokens, 0, r.steps, r.avgLogProb, r.temperature, r.compressionRatio)
-                         for b, r in enumerate(res)])
+        recs = [np.stack([parallel.pack_record(first + b, res[k * n_local + b].tokens, 0, res[k * n_local + b].steps, res[k * n_local + b].avgLogProb,
+                                               res[k * n_local + b].temperature, res[k * n_local + b].compressionRatio) for b in range(n_local)])
+                for k in range(g)]
         return res, recs, nseg
 
     def run_steps(n):
-        """n steps, F in flight: worker f runs steps f, f + F, ... on its own session / HIP stream (ctypes drops the GIL while
-        the library runs); the per-step result records are gathered over RCCL by the main thread afterwards, in step order."""
-        out = [None] * n
-        dur = [0.0] * n
+        """n steps as ceil(n / G) device batches, F batches in flight: worker f runs batches f, f + F, ... on its own session / HIP
+        stream (ctypes drops the GIL while the library runs); the per-step result records are gathered across the ranks by the main
+        thread afterwards, in step order (wh_comm all-gather behind the C ABI; torch.distributed only when no communicator exists)."""
+        groups = [min(G, n - i) for i in range(0, n, G)]
+        out = [None] * len(groups)
+        dur = [0.0] * len(groups)
         if F == 1:
-            for i in range(n):
-                a = time.perf_counter(); out[i] = hot_path(sess); dur[i] = time.perf_counter() - a
+            for i, g in enumerate(groups):
+                a = time.perf_counter(); out[i] = hot_path(sess, g); dur[i] = time.perf_counter() - a
         else:
             errs = []
 
             def work(f):
                 try:
-                    for i in range(f, n, F):
-                        a = time.perf_counter(); out[i] = hot_path(sessions[f]); dur[i] = time.perf_counter() - a
+                    for i in range(f, len(groups), F):
+                        a = time.perf_counter(); out[i] = hot_path(sessions[f], groups[i]); dur[i] = time.perf_counter() - a
                 except BaseException as e:   # noqa: BLE001
                     errs.append(e)
-            ths = [threading.Thread(target=work, args=(f,)) for f in range(min(F, n))]
+            ths = [threading.Thread(target=work, args=(f,)) for f in range(min(F, len(groups)))]
             for t in ths:
                 t.start()
             for t in ths:
@@ -224,8 +247,10 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
             if errs:
                 raise errs[0]
         gdev = dev if (world > 1 and args.dist_backend == "nccl") else None
-        gathered = [parallel.gather_records(recs, B, device=gdev) for _, recs, _ in out]
-        return out[-1][0], gathered[-1], dur
+        gathered = [parallel.gather_records(recs, per_rank_max, device=gdev, comm=comm) for _, per_step, _ in out for recs in per_step]
+        assert len(gathered) == n
+        step_dur = [(d / g, d) for d, g in zip(dur, groups) for _ in range(g)]      # (a batch's wall time shared by the steps it carries, the step's latency)
+        return out[0][0], gathered[-1], step_dur
 
     def fence():
         for ss in sessions:
@@ -234,9 +259,12 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         if world > 1:
             dist.barrier()
 
-    log(f"{model_name}: model + {F} session(s) of {B} chunks ready; warmup x{warmup}")
+    log(f"{model_name}: model + {F} session(s) of {slots} slots ready ({n_local} chunks per step on this rank, {G} step(s) per device batch); warmup x{warmup}")
     if warmup > 0:
-        run_steps(max(warmup, F))    # every session captures its step graph before the timed region
+        run_steps(max(warmup, F * G))    # every session captures its step graphs before the timed region
+        if steps % G:                    # ... including the graphs of the short last batch of the timed run
+            for ss in sessions:
+                hot_path(ss, steps % G)
     fence()
     t0 = time.perf_counter()
     res, allrecs, durs = run_steps(steps)
@@ -246,47 +274,52 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert len(allrecs) == world * B, (len(allrecs), world, B)
-    log(f"{model_name}: timed region done: {elapsed:.3f} s for {steps} steps of {B} chunks, {F} in flight")
-    dec_steps = [r.steps for r in res]
-    audio_s = world * B * 30.0 * steps
+    assert len(allrecs) == total and [r["chunk_index"] for r in allrecs] == list(range(total)), (len(allrecs), world, total)
+    log(f"{model_name}: timed region done: {elapsed:.3f} s for {steps} steps of {total} chunks ({n_local} on this rank), {F} batches in flight")
+    dec_steps = [r.steps for r in res] if res else [min(args.sample_length, 224) - 1]
+    audio_s = total * 30.0 * steps
     # median step: every step's own wall time (host PCM in -> segments out); with F steps in flight a step's latency is F x the
     # interval at which steps complete, so latency / F is the per-step cost the throughput implies
-    Fe = min(F, steps)
+    Fe = min(F, (steps + G - 1) // G)          # device batches in flight
+    lat = [l for _, l in durs]
+    durs = [d for d, _ in durs]
     out = {"value": audio_s / elapsed, "elapsed": elapsed, "audio_s": audio_s, "dec_steps": dec_steps[0], "B": B, "inflight": F,
-           "median_step_latency_ms": float(np.median(durs)) * 1e3, "median_ms_per_step": float(np.median(durs)) * 1e3 / Fe, "n_median": int(len(durs))}
+           "total": total, "n_local": n_local, "steps_per_batch": G, "slots": slots,
+           "median_step_latency_ms": float(np.median(lat)) * 1e3, "median_ms_per_step": float(np.median(durs)) * 1e3 / Fe, "n_median": int(len(durs))}
     if rank == 0 and F > 1 and args.serial_reference:
         # single-stream reference on rank 0 only: local synchronisation, no collective (the other ranks are not here)
         for ss in sessions:
             ss.synchronize()
         s0 = time.perf_counter()
         for _ in range(2):
-            hot_path(sess)
+            hot_path(sess, G)
         sess.synchronize()
-        out["serial_ms_per_step"] = (time.perf_counter() - s0) / 2 * 1e3
+        out["serial_ms_per_step"] = (time.perf_counter() - s0) / (2 * G) * 1e3
 
-    # ---- stage split (rank 0): mel + encoder milliseconds per chunk, decode tokens/s
+    # ---- stage split (rank 0): mel + encoder milliseconds per chunk, decode tokens/s (one full device batch)
     if rank == 0:
         ts = []
+        nb = slots
         for _ in range(3):
             sess.synchronize(); a0 = time.perf_counter()
-            for b, x in enumerate(chunks):
-                sess.padOrTrim(x, b)
+            for k in range(G):
+                for b, x in enumerate(chunks):
+                    sess.padOrTrim(x, k * n_local + b)
             sess.synchronize(); a = time.perf_counter()
-            sess.logMelSpectrogram(B); sess.synchronize(); b_ = time.perf_counter()
-            sess.encodeFeatures(B); sess.synchronize(); c = time.perf_counter()
-            sess.prepareDecoderInputs(B); sess.synchronize(); d_ = time.perf_counter()
-            r2 = sess.decodeText(prompt, opts, batch=B); e = time.perf_counter()
+            sess.logMelSpectrogram(nb); sess.synchronize(); b_ = time.perf_counter()
+            sess.encodeFeatures(nb); sess.synchronize(); c = time.perf_counter()
+            sess.prepareDecoderInputs(nb); sess.synchronize(); d_ = time.perf_counter()
+            r2 = sess.decodeText(prompt, opts, batch=nb); e = time.perf_counter()
             ts.append((a - a0, b_ - a, c - b_, d_ - c, e - d_))
         med = np.median(np.array(ts), axis=0)
-        out["stages"] = {"batch": B, "pcm_upload_ms_per_chunk": med[0] * 1e3 / B, "logmels_ms_per_chunk": med[1] * 1e3 / B,
-                         "encoder_ms_per_chunk": med[2] * 1e3 / B, "encoder_ms_per_batch": med[2] * 1e3,
-                         "cross_kv_ms_per_chunk": med[3] * 1e3 / B, "decode_ms_per_chunk": med[4] * 1e3 / B,
-                         "decoder_steps": int(r2[0].steps), "tokens_per_s": B * r2[0].steps / med[4],
+        out["stages"] = {"batch": nb, "pcm_upload_ms_per_chunk": med[0] * 1e3 / nb, "logmels_ms_per_chunk": med[1] * 1e3 / nb,
+                         "encoder_ms_per_chunk": med[2] * 1e3 / nb, "encoder_ms_per_batch": med[2] * 1e3,
+                         "cross_kv_ms_per_chunk": med[3] * 1e3 / nb, "decode_ms_per_chunk": med[4] * 1e3 / nb,
+                         "decoder_steps": int(r2[0].steps), "tokens_per_s": nb * r2[0].steps / med[4],
                          "us_per_decoder_step": med[4] * 1e6 / max(r2[0].steps, 1)}
         log(f"{model_name}: stages {json.dumps({k: round(v, 3) for k, v in out['stages'].items()})}")
     if rank == 0 and want_roofline:
-        out["roofline"] = measure_kernels(sess, dims, B, 16, dec_steps[0], model_name)
+        out["roofline"] = measure_kernels(sess, dims, slots, 16, dec_steps[0], model_name)
         log(f"{model_name}: roofline leg done")
 
     # ---- CPU baseline: the oracle (port of the same algorithm) on the host cores, bounded sample
@@ -391,7 +424,12 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="steps (batches of --batch chunks) in flight per GPU, each on its own session / HIP stream")
     ap.add_argument("--serial-reference", action="store_true", default=True)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--batch", type=int, default=64, help="30 s chunks per GPU per step (one decode batch = batch / 32 MFMA batch tiles)")
+    ap.add_argument("--batch", type=int, default=64, help="30 s chunks per step (one decode batch = batch / 32 MFMA batch tiles): in total over the GPUs "
+                    "with --scaling strong (BASELINE configs[3]: 64 chunks sharded across the GPUs), per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: strong = --batch chunks per step in total, block-partitioned "
+                    "over the ranks (SURVEY 8d c4; the default); weak = --batch chunks per step and GPU")
+    ap.add_argument("--gather", choices=["wh_comm", "torch"], default="wh_comm", help="N > 1: result-record all-gather through the C-ABI communicator "
+                    "(RCCL, or the library's TCP transport in a --single-device rehearsal) or through torch.distributed")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")
@@ -423,8 +461,36 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    # ---- the communicator of the result gather, behind the C ABI (wh_comm_*): rank 0's id reaches the others through the process group
+    # the launcher already set up (any out-of-band channel would do: a Swift host would use its own)
+    comm, gather_kind = None, "none (1 GPU)"
+    if world > 1:
+        gather_kind = f"torch.distributed all_gather_into_tensor ({args.dist_backend})"
+        if args.gather == "wh_comm":
+            from whisperkit_amd import parallel
+            try:
+                def exchange(raw):
+                    box = [raw]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+                rccl = args.dist_backend == "nccl" and not args.single_device      # RCCL refuses two ranks on one device: rehearsals use TCP
+                port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+                comm = parallel.Comm(world, rank, transport="rccl" if rccl else "tcp", device=local_rank,
+                                     tcp_address=f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{port}", exchange_id=exchange if rccl else None)
+                comm.barrier()
+                gather_kind = "wh_comm_gather_records (C ABI): " + ("ncclAllGather over RCCL / xGMI" if rccl else "library TCP transport (one-GPU rehearsal)")
+            except Exception as e:   # noqa: BLE001 - every rank takes the same branch only if the failure is symmetric; say what happened
+                log(f"wh_comm unavailable ({e}); falling back to torch.distributed for the gather")
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+                gather_kind = f"torch.distributed all_gather_into_tensor ({args.dist_backend}); wh_comm failed on another rank"
+
     main_cfg = run_config(args, args.model, args.batch, args.inflight, args.steps, args.warmup, world, rank, local_rank, dev,
-                          want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline))
+                          want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline), comm=comm, scaling=args.scaling)
     other = {}
     headline = (args.model, args.batch) == ("large-v3", 64)
     extra = rank == 0 and world == 1 and not args.no_other_configs
@@ -451,29 +517,36 @@ def main():
         other["configs[2] whisper-small, 8 x 30 s chunks, greedy + word-timestamp alignment (DTW), 3 in flight, 1 GPU"] = brief(o, 6)
     if rank == 0:
         B = args.batch
+        total, nl, G = main_cfg["total"], main_cfg["n_local"], main_cfg["steps_per_batch"]
+        scaling = args.scaling if world > 1 else "strong"
+        packed = (f"; each GPU packs its {nl}-chunk shares of {G} consecutive steps into one {main_cfg['slots']}-slot device batch" if G > 1 else "")
         out = {
             "metric": "audio-sec/sec (1/RTF), 30 s chunks: host PCM -> log-mel + encoder + greedy decode -> segments",
             "value": round(main_cfg["value"], 2), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(main_cfg["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(main_cfg["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"whisper-{args.model}, {B} x 30 s 16 kHz chunks per step and GPU, {main_cfg['inflight']} steps in flight "
-                                   f"(= {B * main_cfg['inflight']} chunks resident per GPU), greedy (T=0), {main_cfg['dec_steps']} decoder steps/chunk, "
+            "config": {"workload": f"whisper-{args.model}, {total} x 30 s 16 kHz chunks per step" + (f" over {world} GPUs ({scaling} scaling, {nl} per GPU)" if world > 1 else "")
+                                   + f", {main_cfg['inflight']} device batches in flight per GPU (= {main_cfg['slots'] * main_cfg['inflight']} chunks resident per GPU){packed}, "
+                                   f"greedy (T=0), {main_cfg['dec_steps']} decoder steps/chunk, "
                                    "random-init weights, PCM handed over in host memory, segments built on the host",
-                       "chunks_per_step": B, "chunks_per_gpu": B, "parallelism": f"chunk-dp{world}", "decoder_steps": main_cfg["dec_steps"],
-                       "steps_in_flight": main_cfg["inflight"],
+                       "chunks_per_step": total, "chunks_per_gpu": nl, "steps_per_device_batch": G, "device_batch_slots": main_cfg["slots"],
+                       "parallelism": f"chunk-dp{world}", "decoder_steps": main_cfg["dec_steps"],
+                       "steps_in_flight": main_cfg["inflight"] * G, "device_batches_in_flight": main_cfg["inflight"], "result_gather": gather_kind,
                        "serial_ms_per_step": round(main_cfg.get("serial_ms_per_step", 0.0), 3) or None,
                        "arith": "fp16 operands (decoder activations as f16 hi|lo pairs), fp32 accumulate/residual/softmax; mel fp32"},
             "rtf": round(main_cfg["elapsed"] / main_cfg["audio_s"], 6),
             "median_ms_per_step": round(main_cfg["median_ms_per_step"], 3), "median_step_latency_ms": round(main_cfg["median_step_latency_ms"], 3),
             "n_median": main_cfg["n_median"],
-            "value_from_median_step": round(B * 30.0 * world / (main_cfg["median_ms_per_step"] * 1e-3), 2),
-            "value_single_stream": (round(B * 30.0 * world / (main_cfg["serial_ms_per_step"] * 1e-3), 2)
+            "value_from_median_step": round(total * 30.0 / (main_cfg["median_ms_per_step"] * 1e-3), 2),
+            "value_single_stream": (round(total * 30.0 / (main_cfg["serial_ms_per_step"] * 1e-3), 2)
                                     if main_cfg.get("serial_ms_per_step") else None),
             "encoder_ms_per_chunk": round(main_cfg["stages"]["encoder_ms_per_chunk"], 4),
             "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in main_cfg["stages"].items()},
             "roofline": main_cfg.get("roofline"), "cpu_baseline": main_cfg.get("cpu_baseline"), "other_configs": other,
         }
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -518,6 +518,48 @@ int wh_vad_voice_activity(const float* pcm, int n, int frame_length_samples, int
 int wh_vad_chunk_all(const float* pcm, int n, int max_chunk_length, const wh_decoding_options* opt,
                      int32_t* chunk_start, int32_t* chunk_end, int capacity);
 
+/* ---- multi-GPU: chunk partition + result gather across one-process-per-GPU ranks ------------------------------------
+ * The reference fans independent audio arrays out over a TaskGroup sharing the model objects (Core/WhisperKit.swift:735-812)
+ * and merges per-chunk results in process (Utilities/TranscriptionUtilities.swift:76-157; chunk offsets applied by
+ * AudioChunking.updateSeekOffsetsForResults, Core/Audio/AudioChunker.swift:14-39).  With one process per GPU the chunks are
+ * block-partitioned over the ranks (weights replicated, no data-path collective) and the merge needs ONE all-gather of the
+ * per-chunk results - the only collective of the path.  Transports:
+ *   WH_COMM_RCCL  ncclAllGather over xGMI; librccl is dlopen'ed on first use (a copy already in the process is reused), `id` is
+ *                 RCCL's 128-byte ncclUniqueId made by wh_comm_unique_id on rank 0 and handed to the other ranks by the caller;
+ *   WH_COMM_TCP   a star over host TCP sockets (rank 0 listens at "host:port", carried in `id`): hosts without RCCL, CPU-only
+ *                 tests, several ranks sharing one GPU (RCCL refuses duplicate devices).
+ * Calls on one communicator are collective: every rank makes the same sequence of calls. */
+typedef struct wh_comm wh_comm;
+enum { WH_COMM_RCCL = 0, WH_COMM_TCP = 1 };
+#define WH_COMM_ID_BYTES 128
+#define WH_RECORD_TOKENS 232
+/* what the merge needs of one chunk's DecodingResult: 240 x 4 bytes */
+typedef struct wh_chunk_record {
+    int32_t tokens[WH_RECORD_TOKENS];
+    int32_t n_tokens, chunk_index /* < 0: padding */, seek /* chunk offset in samples */, steps;
+    float avg_logprob, temperature, compression_ratio, no_speech_prob;
+} wh_chunk_record;
+int wh_comm_unique_id(int transport, const char* tcp_address /* "host:port" of rank 0, TCP only */, uint8_t* id /* [WH_COMM_ID_BYTES] */);
+/* `device`: the HIP device of this rank (RCCL staging buffers live there); id may be NULL when world_size == 1 */
+int wh_comm_create(int transport, const uint8_t* id, int world_size, int rank, int device, wh_comm** out);
+void wh_comm_destroy(wh_comm* c);
+int wh_comm_rank(const wh_comm* c);
+int wh_comm_world_size(const wh_comm* c);
+int wh_comm_transport(const wh_comm* c);
+/* rank r owns chunks [start, end) of n_chunks: contiguous blocks, sizes differ by at most one, output order kept */
+int wh_partition_chunks(int n_chunks, int world_size, int rank, int* start, int* end);
+int wh_comm_barrier(wh_comm* c);
+/* nbytes from every rank -> world_size * nbytes on every rank, in rank order (host buffers) */
+int wh_comm_all_gather(wh_comm* c, const void* send, void* recv, size_t nbytes);
+int wh_chunk_record_from_result(const wh_decoding_result* res, int chunk_index, int seek, wh_chunk_record* out);
+/* every rank passes its n_local <= max_per_rank records (same max_per_rank everywhere) and receives all records by chunk index */
+int wh_comm_gather_records(wh_comm* c, const wh_chunk_record* local, int n_local, int max_per_rank, wh_chunk_record* all_out,
+                           int capacity, int* n_out);
+/* whole TranscriptionResults (as their Codable JSON documents): every rank receives every rank's results in chunk order as new
+ * handles it owns; feed them to wh_merge_transcriptions (mergeTranscriptionResults) */
+int wh_comm_gather_transcriptions(wh_comm* c, const wh_transcription* const* local, const int32_t* chunk_indices, int n_local,
+                                  wh_transcription** all_out, int32_t* chunk_indices_out /* may be NULL */, int capacity, int* n_out);
+
 /* ---- measurement (bench.py roofline leg; no reference analogue) --------------------------------------
  * One eager pass of the hot path on the session stream - log-mel, encoder, cross-K/V projection, then n_steps decoder
  * steps - with a HIP event pair around every kernel launch.  avg_us / launches are indexed by kernel kind

@@ -37,8 +37,14 @@ def main():
 
     sess = api.Session(model, B)
     first, _ = parallel.partition_chunks(world * B, world, rank)
-    got = parallel.gather_records(records(sess, first, B), B)
+    mine = records(sess, first, B)
+    got = parallel.gather_records(mine, B)
     assert [r["chunk_index"] for r in got] == list(range(world * B)), got
+    # the same step behind the C ABI (wh_comm_*): partition, record gather, result gather + merge without torch.distributed on the data path
+    # (TCP transport: RCCL refuses two ranks on one device; the RCCL transport of the same calls runs at world size 1 in test_gpu_round3.py)
+    comm = parallel.Comm(world, rank, transport="tcp", tcp_address=f"127.0.0.1:{int(os.environ.get('MASTER_PORT', '29500')) + 23}")
+    assert comm.partition(world * B) == parallel.partition_chunks(world * B, world, rank)
+    assert comm.gather_records(mine, B) == got
     # long audio across ranks
     gap = np.zeros(24000, np.float32)
     audio = np.concatenate([synthetic_chunk(91)[:400000], gap, synthetic_chunk(92)[:350000], gap, synthetic_chunk(93)[:320000], gap, synthetic_chunk(94)[:300000]])
@@ -46,6 +52,9 @@ def main():
                                 temperatureFallbackCount=0, sampleLength=10)
     s4 = api.Session(model, 4)
     ordered, merged = parallel.transcribe_chunked_sharded(s4, audio, topts)
+    ordered_c, merged_c = parallel.transcribe_chunked_sharded(s4, audio, topts, comm=comm)
+    assert [(o, r.tokens) for o, r in ordered_c] == [(o, r.tokens) for o, r in ordered] and merged_c.tokens == merged.tokens
+    assert [(g.start, g.end, g.tokens) for g in merged_c.segments] == [(g.start, g.end, g.tokens) for g in merged.segments]
     if rank == 0:
         s_all = api.Session(model, world * B)
         ref = [parallel.unpack_record(r) for r in records(s_all, 0, world * B)]
@@ -60,6 +69,8 @@ def main():
         m2 = api.mergeTranscriptionResults([r for _, r in single])
         assert merged.tokens == m2.tokens and len(merged.segments) == len(m2.segments)
         print("REHEARSAL OK", world, "ranks,", len(got), "records,", len(ordered), "chunks", flush=True)
+    comm.barrier()
+    comm.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -255,6 +255,10 @@ def test_two_ranks_on_one_gpu_rehearsal():
     import json
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["chunks_per_step"] == 2
+    # strong scaling by default (BASELINE configs[3]: the step's chunks are sharded over the GPUs): 1 chunk per rank and step, two steps
+    # packed into one 2-slot device batch, records gathered through the C-ABI communicator
+    assert line["scaling"] == "strong" and line["config"]["chunks_per_gpu"] == 1 and line["config"]["steps_per_device_batch"] == 2
+    assert line["config"]["result_gather"].startswith("wh_comm_gather_records"), line["config"]["result_gather"]
 
 
 def test_float16_logits_reference_numerics_mode(micro_ml):

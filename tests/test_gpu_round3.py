@@ -199,3 +199,36 @@ def test_custom_path_errors(rig):
     sess.prepareDecoderInputs(1)
     with pytest.raises(ValueError):
         sess.decodeTextCustom(prompt, opts, logitsFilters=[Raises()])
+
+
+# ------------------------------------------------------------------------------------------------ wh_comm on the GPU
+def test_comm_rccl_world_size_one_on_the_gpu(rig):
+    """The RCCL transport of wh_comm_* (librccl dlopen'ed by libwhisperhip, ncclCommInitRank, ncclAllGather on device staging buffers) at
+    world size 1: the records of a real decode go through the collective and come back sorted by chunk index; whole results
+    (TranscriptionResult JSON) likewise.  More than one rank needs more than one GPU (RCCL refuses duplicate devices): the driver's
+    multi-GPU bench run is the first place that happens - stated, not claimed."""
+    from whisperkit_amd import _lib as L
+    from whisperkit_amd import parallel
+    dims, model, sess, om, enc, st, langs = rig
+    comm = parallel.Comm(1, 0, transport="rccl", device=0)
+    assert comm.lib.wh_comm_transport(comm.handle) == L.COMM_RCCL and (comm.world_size, comm.rank) == (1, 0)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=12)
+    sess.padOrTrim(synthetic_chunk(32), 1); sess.logMelSpectrogram(2); sess.encodeFeatures(2); sess.prepareDecoderInputs(2)
+    res = sess.decodeText(sess.prefillPrompt(opts), opts, batch=2)
+    recs = np.stack([parallel.pack_record(5 - b, r.tokens, 480000 * b, r.steps, r.avgLogProb, r.temperature, r.compressionRatio) for b, r in enumerate(res)])
+    for _ in range(3):
+        got = comm.gather_records(recs, 4)
+    assert [g["chunk_index"] for g in got] == [4, 5]
+    assert got[1]["tokens"] == res[0].tokens and got[0]["tokens"] == res[1].tokens and got[0]["seek"] == 480000
+    assert got[1]["avg_logprob"] == np.float32(res[0].avgLogProb)
+    comm.barrier()
+    # raw all-gather of a larger buffer: 1 MB through the device staging buffers
+    import ctypes as C
+    blob = np.random.default_rng(0).integers(0, 255, 1 << 20, dtype=np.uint8)
+    out = np.zeros_like(blob)
+    api._check(comm.lib.wh_comm_all_gather(comm.handle, blob.ctypes.data, out.ctypes.data, C.c_size_t(blob.nbytes)))
+    np.testing.assert_array_equal(out, blob)
+    tr = sess.transcribe([synthetic_chunk(40)[:200000], synthetic_chunk(41)[:160000]], api.DecodingOptions(**NOFALLBACK, sampleLength=10))
+    back = comm.gather_results([(1, tr[1]), (0, tr[0])])
+    assert [i for i, _ in back] == [0, 1] and [r.tokens for _, r in back] == [tr[0].tokens, tr[1].tokens]
+    comm.close()

@@ -80,6 +80,15 @@ TOKEN_SAMPLER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.c_
                                C.POINTER(C.c_int32), C.POINTER(C.c_float))
 
 
+class WhChunkRecord(C.Structure):
+    """wh_chunk_record: what the cross-rank merge needs of one chunk's DecodingResult (960 bytes)"""
+    _fields_ = [("tokens", C.c_int32 * 232), ("n_tokens", C.c_int32), ("chunk_index", C.c_int32), ("seek", C.c_int32), ("steps", C.c_int32),
+                ("avg_logprob", C.c_float), ("temperature", C.c_float), ("compression_ratio", C.c_float), ("no_speech_prob", C.c_float)]
+
+
+COMM_RCCL, COMM_TCP, COMM_ID_BYTES = 0, 1, 128
+
+
 class WhTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "audio_processing", "logmels", "encoding", "decoding_init", "decoding_predictions", "decoding_filtering",
@@ -208,6 +217,16 @@ SYMBOLS = {
     "wh_prepare_seek_clips": (I, [POPT, I, PI32, PI32, I]),
     "wh_vad_voice_activity": (I, [PF, I, I, I, F, PU8, I]),
     "wh_vad_chunk_all": (I, [PF, I, I, POPT, PI32, PI32, I]),
+    "wh_comm_unique_id": (I, [I, C.c_char_p, PU8]),
+    "wh_comm_create": (I, [I, PU8, I, I, I, PVP]),
+    "wh_comm_destroy": (None, [VP]),
+    "wh_comm_rank": (I, [VP]), "wh_comm_world_size": (I, [VP]), "wh_comm_transport": (I, [VP]),
+    "wh_partition_chunks": (I, [I, I, I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "wh_comm_barrier": (I, [VP]),
+    "wh_comm_all_gather": (I, [VP, VP, VP, C.c_size_t]),
+    "wh_chunk_record_from_result": (I, [C.POINTER(WhDecodingResult), I, I, C.POINTER(WhChunkRecord)]),
+    "wh_comm_gather_records": (I, [VP, C.POINTER(WhChunkRecord), I, I, C.POINTER(WhChunkRecord), I, C.POINTER(C.c_int)]),
+    "wh_comm_gather_transcriptions": (I, [VP, PVP, PI32, I, PVP, PI32, I, C.POINTER(C.c_int)]),
     "wh_kernel_kind_count": (I, []),
     "wh_kernel_kind_name": (C.c_char_p, [I]),
     "wh_measure_kernels": (I, [VP, I, I, C.POINTER(C.c_double), PI32]),

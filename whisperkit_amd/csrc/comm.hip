@@ -1,0 +1,361 @@
+// wh_comm_*: the multi-GPU step of the path behind the C ABI - one process per GPU, the chunk list block-partitioned over the
+// ranks, one all-gather of fixed-size result records (or of the ranks' TranscriptionResult JSON documents) at the end.
+//
+// What it replaces: the reference fans independent audio arrays out over a TaskGroup that shares the model objects
+// (Sources/WhisperKit/Core/WhisperKit.swift:735-812) and merges the per-chunk results in process
+// (Utilities/TranscriptionUtilities.swift:76-157, updateSeekOffsetsForResults Core/Audio/AudioChunker.swift:14-39).  With one
+// process per GPU the "merge" needs the other ranks' results: that is the ONLY collective of the path -
+// ~1 KB per chunk, latency-bound.
+//
+// Transports:
+//   WH_COMM_RCCL  ncclAllGather on device staging buffers over xGMI.  librccl is resolved with dlopen at the first communicator
+//                 (an already loaded copy - e.g. the one torch.distributed brought - is reused), so the library has no link-time
+//                 dependency on it and single-GPU hosts never load it.  The 128-byte id is RCCL's ncclUniqueId, created on rank 0
+//                 and handed to the other ranks by the caller (environment, file, socket - as with any NCCL bootstrap).
+//   WH_COMM_TCP   a star over TCP on the host (rank 0 listens; gather then broadcast): for hosts without RCCL, CPU-only tests and
+//                 the two-ranks-on-one-GPU rehearsal, where RCCL refuses duplicate devices.  The id carries "host:port".
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+
+using whi::set_error;
+
+namespace {
+
+// ---- the handful of RCCL entry points this file needs (rccl.h: ncclResult_t 0 = success, ncclUniqueId = 128 bytes by value)
+struct RcclId { char internal[128]; };
+typedef void* RcclComm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
+};
+constexpr int kRcclUint8 = 1;   // ncclUint8
+
+const RcclApi* rccl_api(std::string* why) {
+    static RcclApi api;
+    static std::string err;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) if ((api.handle = dlopen(n, RTLD_LAZY | RTLD_NOLOAD))) break;      // reuse a copy the process already has
+        if (!api.handle) for (const char* n : names) if ((api.handle = dlopen(n, RTLD_LAZY | RTLD_LOCAL))) break;
+        if (!api.handle) { err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return; }
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        if (!api.ok()) err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    });
+    if (!api.ok()) { if (why) *why = err; return nullptr; }
+    return &api;
+}
+
+// ---- TCP helpers (blocking, whole buffers)
+bool send_all(int fd, const void* p, size_t n) {
+    const char* c = static_cast<const char*>(p);
+    while (n) { ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) { if (errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
+    return true;
+}
+bool recv_all(int fd, void* p, size_t n) {
+    char* c = static_cast<char*>(p);
+    while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
+    return true;
+}
+
+}  // namespace
+
+struct wh_comm {
+    int transport = WH_COMM_TCP, world = 1, rank = 0, device = -1;
+    // RCCL
+    RcclComm comm = nullptr;
+    hipStream_t st = nullptr;
+    void *send_dev = nullptr, *recv_dev = nullptr;
+    size_t send_cap = 0, recv_cap = 0;
+    // TCP star: rank 0 holds one socket per peer (index = peer rank), the others one socket to rank 0
+    std::vector<int> socks;
+    int listen_fd = -1;
+};
+
+static int comm_fail(wh_comm* c, int code, const char* what) {
+    int r = set_error(code, "%s", what);
+    wh_comm_destroy(c);
+    return r;
+}
+
+extern "C" int wh_comm_unique_id(int transport, const char* address, uint8_t* id) {
+    if (!id) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: null id");
+    memset(id, 0, WH_COMM_ID_BYTES);
+    if (transport == WH_COMM_RCCL) {
+        std::string why;
+        const RcclApi* api = rccl_api(&why);
+        if (!api) return set_error(WH_ERR_HIP, "wh_comm_unique_id: RCCL unavailable (%s)", why.c_str());
+        RcclId rid;
+        int e = api->GetUniqueId(&rid);
+        if (e) return set_error(WH_ERR_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString ? api->GetErrorString(e) : "?");
+        static_assert(sizeof(rid) == WH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+        memcpy(id, &rid, sizeof(rid));
+        return WH_OK;
+    }
+    if (transport != WH_COMM_TCP) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: unknown transport %d", transport);
+    if (!address || !strchr(address, ':') || strlen(address) >= WH_COMM_ID_BYTES)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: the TCP transport needs \"host:port\" of rank 0");
+    strcpy(reinterpret_cast<char*>(id), address);
+    return WH_OK;
+}
+
+static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
+    std::string addr(reinterpret_cast<const char*>(id), strnlen(reinterpret_cast<const char*>(id), WH_COMM_ID_BYTES));
+    const size_t colon = addr.rfind(':');
+    if (colon == std::string::npos) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: TCP id is not host:port");
+    const std::string host = addr.substr(0, colon), port = addr.substr(colon + 1);
+    const int one = 1;
+    if (c->rank == 0) {
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM; hints.ai_flags = AI_PASSIVE;
+        if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) || !res) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: cannot resolve %s", addr.c_str());
+        c->listen_fd = ::socket(res->ai_family, SOCK_STREAM, 0);
+        setsockopt(c->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        const bool ok = c->listen_fd >= 0 && ::bind(c->listen_fd, res->ai_addr, res->ai_addrlen) == 0 && ::listen(c->listen_fd, c->world) == 0;
+        freeaddrinfo(res);
+        if (!ok) return set_error(WH_ERR_HIP, "wh_comm_create: rank 0 cannot listen on %s: %s", addr.c_str(), strerror(errno));
+        c->socks.assign(c->world, -1);
+        for (int k = 1; k < c->world; ++k) {
+            const int fd = ::accept(c->listen_fd, nullptr, nullptr);
+            int32_t peer = -1;
+            if (fd < 0 || !recv_all(fd, &peer, 4) || peer < 1 || peer >= c->world || c->socks[peer] >= 0) {
+                if (fd >= 0) ::close(fd);
+                return set_error(WH_ERR_HIP, "wh_comm_create: bad hello from a peer (rank %d)", peer);
+            }
+            setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            c->socks[peer] = fd;
+        }
+        return WH_OK;
+    }
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) || !res) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: cannot resolve %s", addr.c_str());
+    int fd = -1;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(60);      // rank 0 may not be listening yet
+    while (true) {
+        fd = ::socket(res->ai_family, SOCK_STREAM, 0);
+        if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+        if (fd >= 0) ::close(fd);
+        fd = -1;
+        if (std::chrono::steady_clock::now() > deadline) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+    freeaddrinfo(res);
+    if (fd < 0) return set_error(WH_ERR_HIP, "wh_comm_create: rank %d cannot reach rank 0 at %s", c->rank, addr.c_str());
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    const int32_t me = c->rank;
+    if (!send_all(fd, &me, 4)) { ::close(fd); return set_error(WH_ERR_HIP, "wh_comm_create: hello to rank 0 failed"); }
+    c->socks.assign(1, fd);
+    return WH_OK;
+}
+
+extern "C" int wh_comm_create(int transport, const uint8_t* id, int world_size, int rank, int device, wh_comm** out) {
+    if (!out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: null output");
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: rank %d of %d", rank, world_size);
+    if (world_size > 1 && !id) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: a communicator of %d ranks needs the id of rank 0", world_size);
+    WH_TRY
+    wh_comm* c = new wh_comm();
+    c->transport = transport; c->world = world_size; c->rank = rank; c->device = device;
+    if (transport == WH_COMM_RCCL) {
+        std::string why;
+        const RcclApi* api = rccl_api(&why);
+        if (!api) { std::string m = "wh_comm_create: RCCL unavailable (" + why + ")"; return comm_fail(c, WH_ERR_HIP, m.c_str()); }
+        if (hipSetDevice(device) != hipSuccess) return comm_fail(c, WH_ERR_HIP, "wh_comm_create: hipSetDevice failed");
+        RcclId rid;
+        if (id) memcpy(&rid, id, sizeof(rid));
+        else if (api->GetUniqueId(&rid)) return comm_fail(c, WH_ERR_HIP, "wh_comm_create: ncclGetUniqueId failed");     // world size 1
+        const int e = api->CommInitRank(&c->comm, world_size, rid, rank);
+        if (e) { std::string m = std::string("ncclCommInitRank failed: ") + (api->GetErrorString ? api->GetErrorString(e) : "?"); c->comm = nullptr; return comm_fail(c, WH_ERR_HIP, m.c_str()); }
+        if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return comm_fail(c, WH_ERR_HIP, "wh_comm_create: hipStreamCreate failed");
+    } else if (transport == WH_COMM_TCP) {
+        if (world_size > 1) { int r = tcp_connect_all(c, id); if (r) { wh_comm_destroy(c); return r; } }
+    } else {
+        delete c;
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: unknown transport %d", transport);
+    }
+    *out = c;
+    return WH_OK;
+    WH_CATCH("wh_comm_create")
+}
+
+extern "C" void wh_comm_destroy(wh_comm* c) {
+    if (!c) return;
+    if (c->comm) { if (const RcclApi* api = rccl_api(nullptr)) api->CommDestroy(c->comm); }
+    if (c->send_dev) hipFree(c->send_dev);
+    if (c->recv_dev) hipFree(c->recv_dev);
+    if (c->st) hipStreamDestroy(c->st);
+    for (int fd : c->socks) if (fd >= 0) ::close(fd);
+    if (c->listen_fd >= 0) ::close(c->listen_fd);
+    delete c;
+}
+extern "C" int wh_comm_rank(const wh_comm* c) { return c ? c->rank : -1; }
+extern "C" int wh_comm_world_size(const wh_comm* c) { return c ? c->world : -1; }
+extern "C" int wh_comm_transport(const wh_comm* c) { return c ? c->transport : -1; }
+
+// contiguous block partition that keeps the output order: rank r owns chunks [start, end)
+extern "C" int wh_partition_chunks(int n_chunks, int world_size, int rank, int* start, int* end) {
+    if (n_chunks < 0 || world_size < 1 || rank < 0 || rank >= world_size || !start || !end)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_partition_chunks: invalid argument");
+    const int base = n_chunks / world_size, rem = n_chunks % world_size;
+    *start = rank * base + std::min(rank, rem);
+    *end = *start + base + (rank < rem ? 1 : 0);
+    return WH_OK;
+}
+
+// all ranks contribute `nbytes` bytes; every rank receives world * nbytes bytes in rank order
+extern "C" int wh_comm_all_gather(wh_comm* c, const void* send, void* recv, size_t nbytes) {
+    if (!c || (!send && nbytes) || (!recv && nbytes)) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_all_gather: null argument");
+    if (nbytes == 0) return WH_OK;
+    if (c->transport == WH_COMM_RCCL) {
+        const RcclApi* api = rccl_api(nullptr);
+        if (!api || !c->comm) return set_error(WH_ERR_HIP, "wh_comm_all_gather: communicator has no RCCL handle");
+        WH_HIP(hipSetDevice(c->device));
+        const size_t total = nbytes * (size_t)c->world;
+        if (c->send_cap < nbytes) { if (c->send_dev) hipFree(c->send_dev); c->send_dev = nullptr; WH_HIP(hipMalloc(&c->send_dev, nbytes)); c->send_cap = nbytes; }
+        if (c->recv_cap < total) { if (c->recv_dev) hipFree(c->recv_dev); c->recv_dev = nullptr; WH_HIP(hipMalloc(&c->recv_dev, total)); c->recv_cap = total; }
+        WH_HIP(hipMemcpyAsync(c->send_dev, send, nbytes, hipMemcpyHostToDevice, c->st));
+        const int e = api->AllGather(c->send_dev, c->recv_dev, nbytes, kRcclUint8, c->comm, c->st);
+        if (e) return set_error(WH_ERR_HIP, "ncclAllGather failed: %s", api->GetErrorString ? api->GetErrorString(e) : "?");
+        WH_HIP(hipMemcpyAsync(recv, c->recv_dev, total, hipMemcpyDeviceToHost, c->st));
+        WH_HIP(hipStreamSynchronize(c->st));
+        return WH_OK;
+    }
+    char* out = static_cast<char*>(recv);
+    if (c->world == 1) { memcpy(out, send, nbytes); return WH_OK; }
+    if (c->rank == 0) {
+        memcpy(out, send, nbytes);
+        for (int k = 1; k < c->world; ++k)
+            if (!recv_all(c->socks[k], out + (size_t)k * nbytes, nbytes)) return set_error(WH_ERR_HIP, "wh_comm_all_gather: receive from rank %d failed", k);
+        for (int k = 1; k < c->world; ++k)
+            if (!send_all(c->socks[k], out, nbytes * (size_t)c->world)) return set_error(WH_ERR_HIP, "wh_comm_all_gather: send to rank %d failed", k);
+        return WH_OK;
+    }
+    if (!send_all(c->socks[0], send, nbytes) || !recv_all(c->socks[0], out, nbytes * (size_t)c->world))
+        return set_error(WH_ERR_HIP, "wh_comm_all_gather: exchange with rank 0 failed");
+    return WH_OK;
+}
+
+extern "C" int wh_comm_barrier(wh_comm* c) {
+    if (!c) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_barrier: null communicator");
+    WH_TRY
+    std::vector<int32_t> all((size_t)c->world);
+    const int32_t me = c->rank;
+    return wh_comm_all_gather(c, &me, all.data(), sizeof(me));
+    WH_CATCH("wh_comm_barrier")
+}
+
+// Fixed-size chunk records: every rank passes its n_local records (n_local <= max_per_rank; the same max_per_rank on every rank),
+// every rank receives all valid records sorted by chunk_index.  ONE all-gather of world x max_per_rank x 960 bytes.
+extern "C" int wh_comm_gather_records(wh_comm* c, const wh_chunk_record* local, int n_local, int max_per_rank, wh_chunk_record* all_out,
+                                      int capacity, int* n_out) {
+    if (!c || (n_local > 0 && !local) || !all_out || !n_out || n_local < 0 || max_per_rank < 1 || n_local > max_per_rank)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_gather_records: invalid argument");
+    WH_TRY
+    std::vector<wh_chunk_record> mine((size_t)max_per_rank), all((size_t)max_per_rank * c->world);
+    for (auto& r : mine) { memset(&r, 0, sizeof(r)); r.chunk_index = -1; }
+    for (int i = 0; i < n_local; ++i) mine[i] = local[i];
+    int r = wh_comm_all_gather(c, mine.data(), all.data(), mine.size() * sizeof(wh_chunk_record));
+    if (r) return r;
+    std::vector<wh_chunk_record> valid;
+    for (const auto& q : all) if (q.chunk_index >= 0) valid.push_back(q);
+    std::stable_sort(valid.begin(), valid.end(), [](const wh_chunk_record& a, const wh_chunk_record& b) { return a.chunk_index < b.chunk_index; });
+    if ((int)valid.size() > capacity) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_gather_records: %zu records, capacity %d", valid.size(), capacity);
+    std::copy(valid.begin(), valid.end(), all_out);
+    *n_out = (int)valid.size();
+    return WH_OK;
+    WH_CATCH("wh_comm_gather_records")
+}
+
+// DecodingResult of chunk `chunk_index` -> record (the fields the merge needs; TranscriptionUtilities.swift:76-157)
+extern "C" int wh_chunk_record_from_result(const wh_decoding_result* res, int chunk_index, int seek, wh_chunk_record* out) {
+    if (!res || !out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_chunk_record_from_result: null argument");
+    memset(out, 0, sizeof(*out));
+    const int n = std::min<int>(res->n_tokens, WH_RECORD_TOKENS);
+    for (int i = 0; i < n; ++i) out->tokens[i] = res->tokens[i];
+    out->n_tokens = n; out->chunk_index = chunk_index; out->seek = seek; out->steps = res->steps;
+    out->avg_logprob = res->avg_logprob; out->temperature = res->temperature; out->compression_ratio = res->compression_ratio;
+    out->no_speech_prob = res->no_speech_prob;
+    return WH_OK;
+}
+
+// Whole results across ranks: this rank's transcriptions (handles, with the index of the chunk each belongs to) travel as the
+// reference's Codable JSON documents; two all-gathers (payload sizes, padded payloads).  Every rank receives every transcription
+// in chunk order; the caller owns the returned handles (wh_transcription_free) and typically hands them to wh_merge_transcriptions.
+extern "C" int wh_comm_gather_transcriptions(wh_comm* c, const wh_transcription* const* local, const int32_t* chunk_indices, int n_local,
+                                             wh_transcription** all_out, int32_t* chunk_indices_out, int capacity, int* n_out) {
+    if (!c || (n_local > 0 && (!local || !chunk_indices)) || !all_out || !n_out || n_local < 0)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_gather_transcriptions: invalid argument");
+    WH_TRY
+    // payload = n x [int32 chunk index, int32 json bytes, json]
+    std::string payload;
+    for (int i = 0; i < n_local; ++i) {
+        const int need = wh_transcription_to_json(local[i], nullptr, 0);
+        if (need < 0) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: result %d cannot be serialised", i);
+        std::string js((size_t)need + 1, '\0');
+        const int got = wh_transcription_to_json(local[i], js.data(), need + 1);
+        if (got < 0) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: result %d cannot be serialised", i);
+        js.resize((size_t)need);
+        const int32_t head[2] = {chunk_indices[i], (int32_t)js.size()};
+        payload.append(reinterpret_cast<const char*>(head), sizeof(head));
+        payload += js;
+    }
+    std::vector<int64_t> sizes((size_t)c->world);
+    const int64_t mine = (int64_t)payload.size();
+    int r = wh_comm_all_gather(c, &mine, sizes.data(), sizeof(mine));
+    if (r) return r;
+    const size_t cap = (size_t)std::max<int64_t>(*std::max_element(sizes.begin(), sizes.end()), 1);
+    payload.resize(cap, '\0');
+    std::string all(cap * (size_t)c->world, '\0');
+    r = wh_comm_all_gather(c, payload.data(), all.data(), cap);
+    if (r) return r;
+    std::vector<std::pair<int32_t, wh_transcription*>> got;
+    auto drop = [&]() { for (auto& g : got) wh_transcription_free(g.second); };
+    for (int k = 0; k < c->world; ++k) {
+        const char* p = all.data() + (size_t)k * cap;
+        const char* end = p + sizes[k];
+        while (p + 8 <= end) {
+            int32_t head[2];
+            memcpy(head, p, 8);
+            p += 8;
+            if (head[1] < 0 || p + head[1] > end) { drop(); return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: malformed payload from rank %d", k); }
+            wh_transcription* t = nullptr;
+            r = wh_transcription_from_json(p, head[1], &t);
+            if (r) { drop(); return r; }
+            got.emplace_back(head[0], t);
+            p += head[1];
+        }
+    }
+    std::stable_sort(got.begin(), got.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    if ((int)got.size() > capacity) { drop(); return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_gather_transcriptions: %zu results, capacity %d", got.size(), capacity); }
+    for (size_t i = 0; i < got.size(); ++i) { all_out[i] = got[i].second; if (chunk_indices_out) chunk_indices_out[i] = got[i].first; }
+    *n_out = (int)got.size();
+    return WH_OK;
+    WH_CATCH("wh_comm_gather_transcriptions")
+}
