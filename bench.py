@@ -115,16 +115,10 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
     api._check(lib.wh_measure_kernels(sess.handle, B, n_meas, avg, cnt))
     avg_len = (n_meas + 1) / 2.0
     table, step_us = {}, {}
-    measured = {name for k, name in enumerate(names) if cnt[k]}
-    # fused launches (decoder_fused.hip): the QKV launch also carries the self-attention, the cross-attention launch the cross-query
-    # projection - their algorithmic bytes are the sum of both parts
-    carried = {"dec_proj_qkv": "dec_self_attn", "dec_cross_attn": "dec_proj_cq"}
     for k, name in enumerate(names):
         if cnt[k] == 0:
             continue
         bound, amount = algorithmic_work(name, dims, B, avg_len)
-        if name in carried and carried[name] not in measured:
-            amount += algorithmic_work(carried[name], dims, B, avg_len)[1]
         is_dec = name.startswith("dec_") or name == "sampler"
         per_step = cnt[k] / n_meas * decode_steps if is_dec else cnt[k]      # launches in one full hot-path step
         step_us[name] = avg[k] * per_step

@@ -19,9 +19,10 @@ Per configuration and checked slot:
                        filtered logits (tests/neartie.py), after which the oracle follows the device's token;
   3. end to end      - the oracle runs its OWN fp64 mel + fp32 encoder from the same PCM: max |delta| of the encoder output and of the
                        logits is MEASURED, written to gpurun_out/r03_fulldepth_errors.json (committed copy: profiles/), and asserted
-                       at <= 2 x the value measured when the test was written (E2E_MEASURED below).  The contract's 1e-3 is quoted
-                       for fp32 arithmetic; fp16 operands over 32 encoder layers exceed it - DESIGN.md section 6 states the measured
-                       deviation and its cause;
+                       at <= 2 x the value measured when the test was written (E2E_MEASURED below).  Measured on MI355X (profiles/
+                       r03b_fulldepth_errors.json): the encoder output differs from the fp32 oracle by <= 2.6e-3 (mean 3.3e-4; fp16 GEMM
+                       operands over 32 layers) and the logits END TO END by 9.7e-4 at large-v3 - inside the contract's 1e-3 with a
+                       3 % margin; the report carries `within_contract` so that a change which tips it over is seen, not hidden;
   4. batch invariance - the last slot decodes to the same ids / log-probs alone (1-slot session) as among the others.
 """
 import json
@@ -61,12 +62,12 @@ ALIGNMENT_HEADS = {
 }
 # end-to-end errors measured on MI355X when this test was written (profiles/r03_fulldepth_errors.json); asserted at 2 x
 E2E_MEASURED = {
-    "large-v3": dict(encoder_max=None, encoder_mean=None, logits_max=None),
-    "small": dict(encoder_max=None, encoder_mean=None, logits_max=None),
-    "tiny.en": dict(encoder_max=None, encoder_mean=None, logits_max=None),
+    "large-v3": dict(encoder_max=2.55e-3, encoder_mean=3.28e-4, logits_max=9.67e-4),
+    "small": dict(encoder_max=1.87e-3, encoder_mean=2.71e-4, logits_max=8.47e-4),
+    "tiny.en": dict(encoder_max=1.28e-3, encoder_mean=1.42e-4, logits_max=5.51e-4),
 }
 # stage-isolated logits error against the fp32-K/V oracle (the Float16 rounding of the cached keys / values included), same rule
-STAGE_MEASURED = {"large-v3": None, "small": None, "tiny.en": None}
+STAGE_MEASURED = {"large-v3": 9.68e-4, "small": 8.46e-4, "tiny.en": 5.47e-4}
 # provisional ceilings used while a configuration has no measured value yet
 E2E_CEILING = dict(encoder_max=1e-1, encoder_mean=1e-2, logits_max=2e-2)
 
@@ -231,7 +232,8 @@ def test_fulldepth_end_to_end_from_pcm(rig):
         enc_max, enc_mean, logit_max = max(enc_max, float(err.max())), max(enc_mean, float(err.mean())), max(logit_max, le)
     got = dict(encoder_max=enc_max, encoder_mean=enc_mean, logits_max=logit_max)
     rig.report["end_to_end"] = {"encoder_max_abs_err": enc_max, "encoder_mean_abs_err": enc_mean, "logits_max_abs_err": logit_max,
-                                "per_slot": per_slot, "contract_logits_tolerance": 1e-3, "positions": POSITIONS}
+                                "per_slot": per_slot, "contract_logits_tolerance": 1e-3, "within_contract": bool(logit_max <= 1e-3),
+                                "positions": POSITIONS}
     _write_report()
     for k, v in got.items():
         m = E2E_MEASURED[rig.name][k]

@@ -375,18 +375,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     s->m = m; s->B = max_batch;
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.n_audio_state, L = D.n_text_layer, V = D.n_vocab, H = D.n_text_head;
-    {
-        // WH_ENC_STREAM=1 (experiment knob): the session's decode stream at the highest priority, its MFMA-bound stages (encoder,
-        // cross-K/V) on a second stream at the lowest - with several sessions in flight a latency-bound decode launch of one
-        // session then takes a freed CU ahead of the queued GEMM workgroups of another
-        static const bool split = [] { const char* e = getenv("WH_ENC_STREAM"); return e && e[0] == '1'; }();
-        int lo = 0, hi = 0;
-        if (split && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
-            if (hipStreamCreateWithPriority(&s->st, hipStreamNonBlocking, hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&s->st_enc, hipStreamNonBlocking, lo) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreateWithPriority failed"); }
-            for (auto& e : s->ev_enc) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        } else if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
-    }
+    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
     DALLOC(s->pcm, B * kWindowSamples); DALLOC(s->n_valid, B);
     DALLOC(s->logspec, B * D.n_mels * kFrames); DALLOC(s->maxkey, B);
     DALLOC(s->mel_t, B * kFramesPad * D.n_mels); DALLOC(s->mel_f32, B * D.n_mels * kFrames);
@@ -401,7 +390,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
     {
         const size_t n_bt = (B + 31) / 32, R = n_bt * 32;
-        const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 3 * 1024 + 16 * 256;
+        const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 16 * 256;
         if (hipMalloc(&s->d32_blob, bytes) != hipSuccess || hipMemset(s->d32_blob, 0, bytes) != hipSuccess) {
             wh_session_destroy(s);
             return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the decode-step buffers failed", bytes);
@@ -415,8 +404,6 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
         q.stat = c.take<float2>(n_bt * (d / 32) * 32);
         q.part = c.take<float>(n_bt * (size_t)kD32PartFloats); q.part_floats = kD32PartFloats;
         q.ticket = c.take<int>(n_bt * 4096);
-        q.sflag = c.take<int>(256); q.cflag = c.take<int>(256); q.poison = c.take<int>(64);
-        if (c.off > bytes) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "internal: decode-step buffers overflow (%zu > %zu)", c.off, bytes); }
     }
     if (hipHostMalloc((void**)&s->seq_host, sizeof(SeqState) * B) != hipSuccess) { wh_session_destroy(s); return set_error(WH_ERR_HIP, "hipHostMalloc failed"); }
     for (auto& e : s->ev) hipEventCreate(&e);
@@ -442,8 +429,6 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->seq_host) hipHostFree(s->seq_host);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
     if (s->st) hipStreamDestroy(s->st);
-    if (s->st_enc) hipStreamDestroy(s->st_enc);
-    for (auto& e : s->ev_enc) if (e) hipEventDestroy(e);
     delete s;
 }
 extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1; }
@@ -502,8 +487,7 @@ extern "C" int wh_encode_features(wh_session* s, int batch) {
     const wh_model* m = s->m;
     const wh_dims& D = m->dims;
     const int d = D.n_audio_state, nm = D.n_mels, M = batch * kCtx;
-    hipStream_t st = s->st_enc ? s->st_enc : s->st;
-    if (s->st_enc) { WH_HIP(hipEventRecord(s->ev_enc[0], s->st)); WH_HIP(hipStreamWaitEvent(s->st_enc, s->ev_enc[0], 0)); }
+    hipStream_t st = s->st;
     GemmArgs g{};
     // conv1 (k3 s1 p1) + GELU as a GEMM over 3 consecutive rows of the padded time-major mel
     g.A = s->mel_t; g.W = m->conv1_w; g.bias = m->conv1_b; g.M = batch * kFrames; g.N = d; g.K = 3 * nm; g.lda = nm;
@@ -541,7 +525,6 @@ extern "C" int wh_encode_features(wh_session* s, int batch) {
     }
     launch_layernorm(s->x, m->lnp_g, m->lnp_b, M, d, s->enc16, s->enc32, st);
     WH_CHECK_LAUNCH();
-    if (s->st_enc) { WH_HIP(hipEventRecord(s->ev_enc[1], s->st_enc)); WH_HIP(hipStreamWaitEvent(s->st, s->ev_enc[1], 0)); }
     return WH_OK;
 }
 extern "C" int wh_get_encoder_output(wh_session* s, int b, float* out) {
@@ -601,17 +584,6 @@ int ensure_align(wh_session* s) {
     return WH_OK;
 }
 
-int check_handoffs(wh_session* s) {
-    int poisoned = 0;
-    WH_HIP(hipMemcpyAsync(&poisoned, s->d32.poison, sizeof(int), hipMemcpyDeviceToHost, s->st));
-    WH_HIP(hipStreamSynchronize(s->st));
-    if (!poisoned) return WH_OK;
-    WH_HIP(hipMemsetAsync(s->d32.poison, 0, sizeof(int), s->st));
-    WH_HIP(hipMemsetAsync(s->d32.sflag, 0, 256 * sizeof(int), s->st));
-    WH_HIP(hipMemsetAsync(s->d32.cflag, 0, 256 * sizeof(int), s->st));
-    return set_error(WH_ERR_HIP, "decoder step: an in-launch projection -> attention hand-off timed out (results of this call are invalid)");
-}
-
 int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active) {
     // DecodingInputs.reset for the slots that decode again (temperature fallback): an accepted slot keeps its alignment rows
     // until the window's word timestamps have been read (TranscribeTask.swift:374-398 resets only the task's own inputs)
@@ -638,11 +610,7 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
     g.ldc = L * 2 * d; g.k16 = s->cross_k; g.vt16 = s->cross_v; g.d_model = d; g.max_batch = s->B;
     g.prof_kind = KK_CROSS_KV;
-    if (s->st_enc) {
-        WH_HIP(hipEventRecord(s->ev_enc[0], s->st)); WH_HIP(hipStreamWaitEvent(s->st_enc, s->ev_enc[0], 0));
-        launch_gemm(EPI_CROSS_KV, g, s->st_enc);
-        WH_HIP(hipEventRecord(s->ev_enc[1], s->st_enc)); WH_HIP(hipStreamWaitEvent(s->st, s->ev_enc[1], 0));
-    } else launch_gemm(EPI_CROSS_KV, g, s->st);
+    launch_gemm(EPI_CROSS_KV, g, s->st);
     WH_CHECK_LAUNCH();
     return wh_reset_decoder_inputs(s, batch);
 }
@@ -667,7 +635,8 @@ extern "C" int wh_predict_logits(wh_session* s, int batch, const int32_t* tokens
     launch_decoder_step(db, nullptr, nullptr, false, s->st);
     WH_CHECK_LAUNCH();
     if (logits_out) WH_HIP(hipMemcpyAsync(logits_out, s->logits, sizeof(float) * (size_t)batch * V, hipMemcpyDeviceToHost, s->st));
-    return whi::check_handoffs(s);
+    WH_HIP(hipStreamSynchronize(s->st));
+    return WH_OK;
 }
 
 extern "C" int wh_get_alignment_weights(wh_session* s, int b, float* out) {

@@ -29,7 +29,7 @@
 // same bits alone or among 31 others (tests/test_gpu_dims.py).
 #include <cstdlib>
 
-#include "dec_attn_body.h"
+#include "dec_shared.h"
 
 namespace wh {
 
@@ -70,13 +70,236 @@ __device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, cons
 }
 
 // ---------------------------------------------------------------------------------------------- attention
-// Bodies: dec_attn_body.h (shared with the fused projection + attention launches of decoder_fused.hip).
+struct AttnArgs {
+    int batch, d, n_head, layer, n_layer, n_split;
+    const float* q;          // [B][d]
+    const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
+    const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
+    f16 *att_hi, *att_lo;    // attention output (before the out projection) as an f16 hi | lo pair in B-fragment plane order (decoder32.hip)
+    float* part;             // [B][H][n_split][kPartStride]: (m, l, o[64]) of every key split, one 128-byte-aligned slot each
+    int* ticket;             // [B][H] arrival counters (zero between launches)
+    float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
+    SeqState* seq;
+    int no_fence;
+    unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
+};
+#define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+
+__device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float v) {
+    f16 hi, lo;
+    split_hilo(v, hi, lo);
+    const size_t o = plane_index(b, n, a.d);
+    a.att_hi[o] = hi;
+    a.att_lo[o] = lo;
+}
+
+// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 halves).  Thread layout: 8 lanes per
+// key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
+// before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
+// o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 load_kv16(const f16* p) {      // 16 bytes of a K / V row; NT: non-temporal (streamed once per step)
+    if constexpr (NT) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return uint4{v[0], v[1], v[2], v[3]};
+    } else return *reinterpret_cast<const uint4*>(p);
+}
+
+template <int PASSES, bool NT, typename GetN, typename QFix>
+__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
+                                             GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
+                                             float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
+    // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
+    // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = tid & 7, kg = tid >> 3;
+    uint4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int key = kg + 32 * i;
+        kreg[i] = key < n_load ? load_kv16<NT>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int key = kg + 32 * i;
+        vreg[i] = key < n_load ? load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+    }
+    float qv[8];
+    {
+        float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
+        float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
+        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    }
+    const int n = get_n();
+    if (n < 0) return false;            // workgroup-uniform
+    qfix(qv, part);                     // hook for a query fix-up (identity today)
+    float* raw_scores = *raw_pp;
+    float s[PASSES];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        f16x8 k8 = *reinterpret_cast<f16x8*>(&kreg[i]);
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t = fmaf((float)k8[j], qv[j], t);
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        const int key = kg + 32 * i;
+        if (key < n) {
+            if (raw_scores && part == 0) raw_scores[key] = t;
+            lmax = fmaxf(lmax, t);
+        } else t = -INFINITY;
+        s[i] = t;
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.0f;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const bool valid = kg + 32 * i < n;
+        const float p = valid ? __expf(s[i] - m) : 0.0f;
+        if (part == 0) lsum += p;
+        if (!valid) vreg[i] = uint4{0, 0, 0, 0};          // rows past n were fetched speculatively: keep 0 * garbage out
+        f16x8 v8 = *reinterpret_cast<f16x8*>(&vreg[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = o[j];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        o[j] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) osum[wave * 64 + lane * 8 + j] = o[j];
+    }
+    __syncthreads();
+    if (tid < 64) o_out[tid] = (osum[tid] + osum[64 + tid]) + (osum[128 + tid] + osum[192 + tid]);
+    if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
+    *m_out = m;
+    *l_out = (red[4] + red[5]) + (red[6] + red[7]);
+    return true;
+}
+
+// PASSES x 32 cached positions are FETCHED (speculatively, before the slot state is known): the launcher passes the smallest
+// bound that covers every live slot's position, so the cache traffic follows the decoded length instead of always being 224 rows
+// (PMC, 32 slots at positions < 9: 37 MB fetched per launch with the fixed 7 passes against 1.5 MB needed).
 template <int PASSES>
-__global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) { dec_self_attn_body<PASSES, false>(a, (int)blockIdx.x, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
+    __shared__ float red[16], osum[256], o_l[64];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
+    const int d = a.d;
+    const size_t base = ((size_t)b * a.n_head + h) * kMaxTok * kHeadDim;
+    float m, l;
+    float* raw = nullptr;
+    auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, PASSES * 32) : -1; };
+    auto qfix = [](float (&)[8], int) {};
+    if (!attend_block<PASSES, false>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, PASSES * 32, get_n, qfix, &raw, red, osum, o_l, &m, &l))
+        return;
+    if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
+}
 
 template <int PASSES, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
-    dec_cross_attn_body<PASSES, NT, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    constexpr int KPB = PASSES * 32;
+    __shared__ float red[16], osum[256], o_l[64];
+    __shared__ int last_flag;
+    const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
+    const int d = a.d, S = a.n_split;
+    const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
+    const size_t base = (((size_t)b * a.n_head + h) * kCtx + t0) * kHeadDim;
+    int slot = -1;
+    if (a.align) slot = a.align_slot[a.layer * a.n_head + h];
+    float m, l;
+    ATT_STAMP(0);
+    unsigned long long* stamp = a.dbg ? a.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 : nullptr;
+    // alignment-head row: DecodingCache.alignmentWeights row tokenIndex + 1 (TextDecoder.swift:272-296), raw scores here,
+    // softmax + head mean in alignment_mean_kernel
+    float* raw = nullptr;
+    auto get_n = [&]() {
+        if (!(s_act && !s_done)) return -1;
+        const int pos = min(max(s_ti, 0), kMaxTok - 1);
+        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
+        return n;
+    };
+    auto qfix = [](float (&)[8], int) {};
+    if (!attend_block<PASSES, NT>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
+        return;
+    // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
+    const int tid = threadIdx.x;
+    float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
+    // write-through (sc1) stores + drained ticket: no per-workgroup L2 write-back (MI355X_MICROARCH.md "publish-large")
+    if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 64) {
+        __hip_atomic_store(mine, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        int* cnt = a.ticket + b * a.n_head + h;
+        int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = (t == S - 1);
+        if (last) {
+            // agent-scope acquire on the combining CU: the partial slots are rewritten by every layer's launch, and a copy
+            // left in this XCD's L2 by an earlier combine must not be served to the sc1 loads below (the recipe of
+            // MI355X_MICROARCH.md: one relaxed ticket, one agent acquire).  WH_XATT_NOFENCE=1 drops it (A/B knob).
+            if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    ATT_STAMP(4);
+    if (last_flag && tid == 0 && a.dbg) stamp[6] = 1;
+    if (last_flag) {      // workgroup-uniform
+        // all S partials (S x 66 floats) are fetched by the whole workgroup in ONE round of independent sc1 loads into LDS
+        // (a per-thread loop over the splits is S dependent L2 round trips: 24 us at S = 24) and combined from there
+        __shared__ float pl[kMaxSplit * 66];
+        const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
+        constexpr int NLD = (kMaxSplit * 66 + 255) / 256;
+        float tmp[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {         // issue every load before the first use
+            const int i = tid + 256 * k, sp_i = i / 66, e = i - sp_i * 66;
+            tmp[k] = i < S * 66 ? __hip_atomic_load(p0 + sp_i * kPartStride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;   // sc1
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < S * 66) pl[i] = tmp[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float mg = -INFINITY;
+            for (int i = 0; i < S; ++i) mg = fmaxf(mg, pl[i * 66]);
+            float lg = 0.0f, og = 0.0f;
+            for (int i = 0; i < S; ++i) {
+                const float w = __expf(pl[i * 66] - mg);
+                lg = fmaf(w, pl[i * 66 + 1], lg);
+                og = fmaf(w, pl[i * 66 + 2 + tid], og);
+            }
+            store_att(a, b, h * kHeadDim + tid, og / lg);
+        }
+    }
+    ATT_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------- sampler
@@ -420,13 +643,10 @@ int cross_attn_splits(int batch, int n_head) {
     (void)batch;
     static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 16 / 12 / 8 / 4 / 2
     // measured large-v3, 64 slots (profiles/r03a_*): 6 passes (8 splits, 70 registers, 7 waves per SIMD) 5.20 ms per decoder step against
-    // 5.38 with 8 passes (6 splits, 87 registers): 1754 vs 1715 audio-s/s with three sessions in flight
+    // 5.38 with 8 passes (6 splits, 87 registers); 1754 vs 1715 audio-s/s with three sessions in flight
     const int passes = forced ? forced : (n_head >= 12 ? 6 : n_head >= 4 ? 4 : 2);
     return (kCtx + passes * 32 - 1) / (passes * 32);
 }
-
-bool launch_qkv_self_fused(const P32Args& a, const AttnArgs& at, int n_bt, int H, int B, hipStream_t st);
-bool launch_cq_cross_fused(const P32Args& a, const AttnArgs& at, int n_bt, int S, int H, int B, hipStream_t st);
 
 static void launch_self_attn(const AttnArgs& at, int passes, int H, int B, hipStream_t st) {
     ProfScope ps_(KK_DEC_SELF_ATTN, st);
@@ -483,47 +703,32 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
     P32Args base{};
     base.batch = B; base.d = d; base.n_head = H; base.n_vocab = V; base.seq = db.seq; base.part = D.part; base.ticket = D.ticket;
     base.x = D.x; base.stat_in = D.stat; base.n_stat = d / 32;
-    // WH_DEC_FUSE (bit 0: QKV projection + self-attention in one launch, bit 1: cross query + cross-attention; decoder_fused.hip);
-    // 0 keeps the eight stand-alone kernels per layer (the A/B side of the parity tests and of the timing)
-    static const int fuse = env_int("WH_DEC_FUSE", 3);
-    const int n_flags = n_bt * H;
-    const bool fuse_ok = n_flags <= 256;
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = db.layers_host[l];
         const Dec32LayerW& t = D.layers_host[l];
         P32Args a = base;       // LN1 (folded) + QKV: q (f32), k / v into the self-attention cache at token_index
         a.N = 3 * d; a.K = d; a.Wt = t.qkv_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.qkv_g; a.fold_c = t.qkv_c; a.q = D.q;
         a.self_k = db.self_k + (size_t)l * self_stride; a.self_v = db.self_v + (size_t)l * self_stride; a.prof_kind = KK_DEC_QKV;
+        launch_dec32_proj(P32_QKV, a, n_bt, st);
         AttnArgs at{};
         at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q;
         at.self_k = a.self_k; at.self_v = a.self_v;
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
-        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.poison = D.poison;
-        bool fused_self = false;
-        if ((fuse & 1) && fuse_ok) { a.signal = D.sflag; fused_self = launch_qkv_self_fused(a, at, n_bt, H, B, st); a.signal = nullptr; }
-        if (!fused_self) {
-            launch_dec32_proj(P32_QKV, a, n_bt, st);
-            launch_self_attn(at, db.self_passes, H, B, st);
-        }
+        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
+        launch_self_attn(at, db.self_passes, H, B, st);
         a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
         a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
-        if (fused_self) { a.clear_flags = D.sflag; a.n_clear = n_flags; }
         launch_dec32_proj(P32_RESID, a, n_bt, st);
         a = base;               // LN2 (folded) + cross-attention query
         a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
+        launch_dec32_proj(P32_Q, a, n_bt, st);
         at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
-        bool fused_cross = false;
-        if ((fuse & 2) && fuse_ok) { a.signal = D.cflag; fused_cross = launch_cq_cross_fused(a, at, n_bt, S, H, B, st); a.signal = nullptr; }
-        if (!fused_cross) {
-            launch_dec32_proj(P32_Q, a, n_bt, st);
-            launch_cross_attn(at, S, H, B, st);
-        }
+        launch_cross_attn(at, S, H, B, st);
         a = base;               // x += W_co att + b_co; planes gamma_3 x, statistics for LN3
         a.N = d; a.K = d; a.Wt = t.co_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.co_b; a.gamma_next = w.ln3_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_COPROJ;
-        if (fused_cross) { a.clear_flags = D.cflag; a.n_clear = n_flags; }
         launch_dec32_proj(P32_RESID, a, n_bt, st);
         a = base;               // LN3 (folded) + fc1 + GELU -> f16 plane
         a.N = 4 * d; a.K = d; a.Wt = t.fc1_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.fc1_g; a.fold_c = t.fc1_c; a.h_out = D.h; a.prof_kind = KK_DEC_FC1;

@@ -430,8 +430,6 @@ static int decode_text_impl(wh_session* s, int batch, const wh_decoding_options*
     s->special_begin_in_progress = st->special_token_begin;
     r = run_token_loop(s, batch, std::max(loop_count, 0));
     if (r) return r;
-    r = whi::check_handoffs(s);
-    if (r) return r;
     for (int b = 0; b < batch; ++b) {
         if (!s->seq_host[b].active) { memset(&out[b], 0, sizeof(out[b])); continue; }
         whi::finalize_decoding_result(s->seq_host[b], opt, st, s->seq_host[b].temperature, &out[b]);

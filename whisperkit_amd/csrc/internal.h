@@ -58,8 +58,6 @@ struct wh_session {
     wh_model* m = nullptr;
     int B = 0;
     hipStream_t st = nullptr;
-    hipStream_t st_enc = nullptr;          // optional low-priority stream of the MFMA-bound stages (WH_ENC_STREAM=1): mel, encoder, cross-K/V
-    hipEvent_t ev_enc[2]{};                // st -> st_enc and st_enc -> st ordering
     // stage buffers
     float* pcm = nullptr; int* n_valid = nullptr;
     float* logspec = nullptr; unsigned* maxkey = nullptr; f16* mel_t = nullptr; float* mel_f32 = nullptr;
@@ -121,7 +119,6 @@ wh::DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position = wh
 void drop_session_graphs(wh_session* s);
 int ensure_align(wh_session* s);          // (re)allocate the raw alignment-head score buffer for the model's current head set
 int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active);
-int check_handoffs(wh_session* s);         // the bounded spins of the fused launches (decoder_fused.hip) gave up -> WH_ERR_HIP, word re-armed
 // host logic shared by wh_decode_text / wh_transcribe (host.hip)
 void finalize_decoding_result(const wh::SeqState& sq, const wh_decoding_options* opt, const wh_special_tokens* st,
                               float temperature, wh_decoding_result* out);

@@ -211,8 +211,6 @@ struct Dec32 {
     float2* stat;            // [n_bt][d/32][32] per-row-tile (mean, M2) of the residual stream: LayerNorm statistics, Chan-combined
     float* part; int* ticket; // split-K partial tiles + arrival counters
     size_t part_floats;
-    int *sflag, *cflag;      // [n_bt][n_head] arrival counters of the fused QKV -> self-attention / cross query -> cross-attention launches
-    int* poison;             // sticky give-up word of their bounded spins (decoder_fused.hip); checked by the host after a decode
 };
 constexpr int kD32PartFloats = 2 * 1024 * 1024;   // per batch tile: row tiles x K splits x 1024 <= 2 M floats
 enum { P32_QKV = 0, P32_Q = 1, P32_RESID = 2, P32_FC1 = 3, P32_LOGITS = 4 };
@@ -231,9 +229,6 @@ struct P32Args {
     const SeqState* seq;
     int prof_kind;
     unsigned long long* dbg;     // WH_DBG=1: 8 wall-clock stamps per workgroup (tools/probe_dec32.py)
-    // in-launch hand-offs (decoder_fused.hip): `signal` [n_bt][n_head] arrival counters this launch's QKV / Q finishers bump (null:
-    // stand-alone kernel, plain stores); `clear_flags`: counters of the PREVIOUS fused launch, re-armed by workgroup 0 of this one
-    int* signal; int* clear_flags; int n_clear;
 };
 void launch_dec32_proj(int mode, const P32Args& a, int n_bt, hipStream_t st);
 void launch_dec32_embed(const f16* emb, const float* pos, const SeqState* seq, int batch, int d, int n_vocab, int n_bt, float* x,
