@@ -93,10 +93,10 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
         return "hbm", d * d * 2 + 2 * act
     if kind == "dec_cross_attn":  # 1500 K and V rows per slot, q in, att planes out
         return "hbm", B * 2 * T * d * 2 + 2 * act
-    if kind == "dec_proj_fc1":   # W[4d][d] + planes in, f16 hidden plane out
-        return "hbm", 4 * d * d * 2 + act + B * 4 * d * 2
-    if kind == "dec_proj_fc2":   # W[d][4d] + hidden plane in, x read + written, planes out
-        return "hbm", 4 * d * d * 2 + B * 4 * d * 2 + 3 * act
+    if kind == "dec_proj_fc1":   # W[4d][d] + planes in, hidden hi|lo plane pair out
+        return "hbm", 4 * d * d * 2 + act + B * 4 * d * 4
+    if kind == "dec_proj_fc2":   # W[d][4d] + hidden plane pair in, x read + written, planes out
+        return "hbm", 4 * d * d * 2 + B * 4 * d * 4 + 3 * act
     if kind == "dec_proj_logits":  # tied embedding [V][d] + planes in; per-tile sampler records (fused greedy) or the logits out
         return "hbm", V * d * 2 + act + (B * ((V + 31) // 32) * 32 if fused_sampler else B * V * 4)
     if kind == "sampler":        # merge of the per-tile records

@@ -293,15 +293,14 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
             any_live = true;
         }
     }
-    // ---- 2. every audio's cross K/V and pre-filled cache rows into its beam slots (audio a -> slots a * beam .. + beam - 1).  Descending,
-    // one launch group per audio: a destination slot is never a source that is still needed
+    // ---- 2. every audio's pre-filled cache rows into its beam slots (audio a -> slots a * beam .. + beam - 1).  Descending, one launch group
+    // per audio: a destination slot is never a source that is still needed.  The cross K / V is NOT replicated: the beams of audio a read
+    // the one copy in slot a (DecodeBuffers.cross_div = beam_size; round 2 copied 245 MB per beam at large-v3 and streamed it 5 x per step)
     const int n_slots = n_audio * beam_size;
     if (any_live && beam_size > 1) {
         for (int a = n_audio - 1; a >= 0; --a) {
             std::vector<int> pairs;
             for (int j = beam_size - 1; j >= 0; --j) if (a * beam_size + j != a) { pairs.push_back(a); pairs.push_back(a * beam_size + j); }
-            r = copy_pairs(s, pairs, true, s->cross_k, s->cross_k, s->cross_v, s->cross_v, 0);
-            if (r) return r;
             r = copy_pairs(s, pairs, false, s->self_k, s->self_k, s->self_v, s->self_v, n_prompt);
             if (r) return r;
         }
@@ -322,6 +321,7 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
             }
         WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * n_slots, hipMemcpyHostToDevice, s->st));
         DecodeBuffers db = whi::decode_buffers(s, n_slots, token_index);
+        db.cross_div = beam_size;
         launch_decoder_step(db, nullptr, nullptr, false, s->st);
         launch_filter_batch(s->cfg_dev, s->suppress_dev, s->seq, s->logits, n_slots, s->st);
         launch_beam_topk(s->logits, s->seq, n_slots, V, beam_size + 1, s->beam_lp, s->beam_tok, s->st);

@@ -390,7 +390,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->tok_out_dev, B); DALLOC(s->lp_out_dev, B); DALLOC(s->scratch_logits, V);
     {
         const size_t n_bt = (B + 31) / 32, R = n_bt * 32;
-        const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 16 * 256;
+        const size_t bytes = 2 * R * d * 4 + 4 * R * d * 2 + 2 * R * 4 * d * 2 + n_bt * (d / 32) * 32 * 8 + n_bt * (size_t)kD32PartFloats * 4 + n_bt * 4096 * 4 + 16 * 256;
         if (hipMalloc(&s->d32_blob, bytes) != hipSuccess || hipMemset(s->d32_blob, 0, bytes) != hipSuccess) {
             wh_session_destroy(s);
             return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the decode-step buffers failed", bytes);
@@ -400,7 +400,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
         q.layers_host = m->dec32.data(); q.emb_t = m->emb_t; q.lg_g = m->lg_g; q.lg_c = m->lg_c; q.n_bt = (int)n_bt;
         q.x = c.take<float>(R * d); q.q = c.take<float>(R * d);
         q.za_hi = c.take<f16>(R * d); q.za_lo = c.take<f16>(R * d); q.zb_hi = c.take<f16>(R * d); q.zb_lo = c.take<f16>(R * d);
-        q.h = c.take<f16>(R * 4 * d);
+        q.h = c.take<f16>(R * 4 * d); q.h_lo = c.take<f16>(R * 4 * d);
         q.stat = c.take<float2>(n_bt * (d / 32) * 32);
         q.part = c.take<float>(n_bt * (size_t)kD32PartFloats); q.part_floats = kD32PartFloats;
         q.ticket = c.take<int>(n_bt * 4096);
@@ -552,6 +552,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     // max_position: the largest token_index any live slot can have during the launches built from this description
     const wh_model* m = s->m;
     DecodeBuffers db{};
+    db.cross_div = 1;
     db.self_passes = std::min(7, std::max(1, (std::min(std::max(max_position, 0), kMaxTok - 1) + 32) / 32));
     db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;

@@ -72,6 +72,7 @@ __device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, cons
 // ---------------------------------------------------------------------------------------------- attention
 struct AttnArgs {
     int batch, d, n_head, layer, n_layer, n_split;
+    int cross_div;           // > 1: slot b attends over the cross K / V of slot b / cross_div (beams of one audio share one copy)
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
     const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
     const int d = a.d, S = a.n_split;
     const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
-    const size_t base = (((size_t)b * a.n_head + h) * kCtx + t0) * kHeadDim;
+    const int bc = a.cross_div > 1 ? b / a.cross_div : b;       // the slot whose cross K / V this slot reads
+    const size_t base = (((size_t)bc * a.n_head + h) * kCtx + t0) * kHeadDim;
     int slot = -1;
     if (a.align) slot = a.align_slot[a.layer * a.n_head + h];
     float m, l;
@@ -672,7 +674,7 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     // non-temporal K / V loads (each row is read once per step; measured large-v3, 32 slots: 51.9 -> 49.7 us per launch, 3 sessions in
     // flight 13.4 k -> 14.2 k sequence-steps/s, profiles/r02i_*); WH_XATT_NT=0 is the A/B side
     static const int nt = env_int("WH_XATT_NT", 1);
-    if (nt) {
+    if (nt && at.cross_div <= 1) {      // shared K / V (beam search): cacheable loads, the L2 of the XCD serves the other beams of the audio
         if (S == 3) dec_cross_attn_kernel<16, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 4) dec_cross_attn_kernel<12, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 6) dec_cross_attn_kernel<8, true><<<grid, 256, xlds, st>>>(at);
@@ -711,7 +713,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a.self_k = db.self_k + (size_t)l * self_stride; a.self_v = db.self_v + (size_t)l * self_stride; a.prof_kind = KK_DEC_QKV;
         launch_dec32_proj(P32_QKV, a, n_bt, st);
         AttnArgs at{};
-        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q;
+        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div;
         at.self_k = a.self_k; at.self_v = a.self_v;
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
@@ -731,10 +733,10 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_COPROJ;
         launch_dec32_proj(P32_RESID, a, n_bt, st);
         a = base;               // LN3 (folded) + fc1 + GELU -> f16 plane
-        a.N = 4 * d; a.K = d; a.Wt = t.fc1_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.fc1_g; a.fold_c = t.fc1_c; a.h_out = D.h; a.prof_kind = KK_DEC_FC1;
+        a.N = 4 * d; a.K = d; a.Wt = t.fc1_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.fc1_g; a.fold_c = t.fc1_c; a.h_out = D.h; a.h_out_lo = D.h_lo; a.prof_kind = KK_DEC_FC1;
         launch_dec32_proj(P32_FC1, a, n_bt, st);
         a = base;               // x += W_2 h + b_2; planes of the next layer's LN1 (or the final LayerNorm)
-        a.N = d; a.K = 4 * d; a.Wt = t.fc2_t; a.zhi = D.h; a.zlo = nullptr; a.bias = w.fc2_b;
+        a.N = d; a.K = 4 * d; a.Wt = t.fc2_t; a.zhi = D.h; a.zlo = D.h_lo; a.bias = w.fc2_b;
         a.gamma_next = (l + 1 < L) ? db.layers_host[l + 1].ln1_g : db.lnf_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_FC2;
         launch_dec32_proj(P32_RESID, a, n_bt, st);

@@ -177,6 +177,7 @@ struct DecodeBuffers {
     const int* align_slot;   // [L*H] -> slot index or -1
     int n_align;
     SeqState* seq;           // [B]
+    int cross_div;           // > 1: slot b reads the cross K / V of slot b / cross_div (beam search: the beams of an audio share ONE copy)
     int self_passes;         // self-attention fetch bound: ceil((largest live token_index + 1) / 32), 1..7 (0 = 7: the whole cache)
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
@@ -207,7 +208,7 @@ struct Dec32 {
     float* q;                // [n_bt*32][d] query of the attention kernels
     f16 *za_hi, *za_lo;      // [n_bt][d/16][2][32][8] gamma * x of the next LayerNorm consumer
     f16 *zb_hi, *zb_lo;      // attention output (input of the out projections)
-    f16* h;                  // [n_bt][4d/16][2][32][8] GELU(fc1), single plane
+    f16 *h, *h_lo;           // [n_bt][4d/16][2][32][8] GELU(fc1) as an f16 hi | lo plane pair (a single f16 plane moved the large-v3 logits by 1e-3)
     float2* stat;            // [n_bt][d/32][32] per-row-tile (mean, M2) of the residual stream: LayerNorm statistics, Chan-combined
     float* part; int* ticket; // split-K partial tiles + arrival counters
     size_t part_floats;
@@ -223,7 +224,7 @@ struct P32Args {
     const float2* stat_in; int n_stat; const float *fold_g, *fold_c;           // LayerNorm fold (QKV, Q, FC1, LOGITS)
     const float* bias; float* x; const float* gamma_next; f16 *zhi_out, *zlo_out; float2* stat_out;   // RESID
     float* q; f16 *self_k, *self_v;                                            // QKV / Q
-    f16* h_out;                                                                // FC1
+    f16 *h_out, *h_out_lo;                                                     // FC1
     float* logits; float* stats; const unsigned char* sup_mask; const SamplerCfg* cfg;   // LOGITS (+ fused greedy statistics)
     float* part; int* ticket;
     const SeqState* seq;
