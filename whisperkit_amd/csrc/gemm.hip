@@ -395,148 +395,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- 256 x 128 x 32 tile, two workgroups per CU
-// Round 3.  Where the 256 x 256 kernel loses its time (profiles/r02r_gemm256_pingpong_ablation.log, fc1 at 64 chunks): 0.58 ms of a
-// 1.63 ms launch is the epilogue - GELU on the VALU and 983 MB of stores with the matrix cores idle, because ONE workgroup owns the
-// whole register file and 128 of the CU's 160 KB of LDS: nothing else can run on the CU under its epilogue.  This kernel halves the
-// tile: 4 waves (2 x 2, wave tile 128 x 64 = the same 4 x 2 MFMA tiles and 128 accumulator registers as before), one wave per SIMD,
-// 72 KB of LDS (three 24 KB stages of a K-slice of 32) - TWO workgroups share a CU, and the hardware runs one workgroup's K loop under
-// the other's epilogue (and under its barriers and waits: the hand-placed ping-pong of the 256-tile kernel becomes the scheduler's job).
-//   * operands by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring: 6 one-KB pieces per wave and stage, requested two stages
-//     ahead; an LDS row is the 64-byte K-slice of one operand row, 16-byte chunk c of row r stored at c ^ ((r >> 2) & 3) (applied to the
-//     SOURCE address: the DMA image is lane-linear) - conflict-free ds_read_b128 for every lane group;
-//   * a wave double-buffers its fragments: the 6 ds_read_b128 of the next k-step are issued before the 8 MFMAs of the current one;
-//   * ONE s_barrier per K-slice: before it a wave has finished reading slice t (lgkmcnt(0)) and has seen its own pieces of slice
-//     t + 1 land (vmcnt); after it slice t + 1 may be read by everyone and the stage of slice t be refilled (slice t + 3).
-// K order, operand order and accumulator layout are those of the other two kernels: the same bits (tests/test_gpu_dims.py compares a
-// chunk encoded alone - 64-tile kernel - with the same chunk in a batch).  Costs 1.5 x the L2 -> LDS bytes per FLOP of the 256 x 256 tile.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs a) {
-    constexpr int TM = 4, TN = 2, STAGE = 24576, NSTAGE = 3;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [3 stages][A 16 KB | B 8 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int tiles_n = (a.N + 127) >> 7, tiles_m = (a.M + 255) >> 8;
-    constexpr int GM = 8;
-    const int gsz = GM * tiles_n, grp = wg / gsz, first_m = grp * GM;
-    const int gm = min(tiles_m - first_m, GM), in_g = wg - grp * gsz;
-    const int m0 = (first_m + in_g % gm) << 8, n0 = (in_g / gm) << 7;
-
-    // LDS-DMA pieces of this wave: 4 of A (rows wave * 64 + p * 16 ...), 2 of W (rows wave * 32 + p * 16 ...); lane -> (row, chunk)
-    const int prow = lane >> 2, pch = lane & 3;
-    const f16* src[6];
-    int dst_off[6];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int rl = wave * 64 + p * 16 + prow;                     // row inside the A region
-        const int m = min(m0 + rl, a.M - 1);
-        src[p] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + ((pch ^ ((rl >> 2) & 3)) << 3);
-        dst_off[p] = (wave * 64 + p * 16) * 64;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int rl = wave * 32 + p * 16 + prow;
-        const int n = min(n0 + rl, a.N - 1);
-        src[4 + p] = a.W + (long long)n * a.K + ((pch ^ ((rl >> 2) & 3)) << 3);
-        dst_off[4 + p] = 16384 + (wave * 32 + p * 16) * 64;
-    }
-    auto dma = [&](int kt) {
-        unsigned char* sb = smem + (kt % NSTAGE) * STAGE;
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * 32),
-                                             (__attribute__((address_space(3))) void*)(sb + dst_off[p]), 16, 0, 0);
-    };
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int nk = a.K >> 5;
-    // fragment addresses: row (wm * 128 + i * 32 + fr) of A, (wn * 64 + j * 32 + fr) of W; rows of one lane differ by multiples of 32,
-    // so the swizzle term (row >> 2) & 3 = (fr >> 2) & 3 is the same for all of them
-    const int swz = (fr >> 2) & 3;
-    const int a_row_off = (wm * 128 + fr) * 64, b_row_off = 16384 + (wn * 64 + fr) * 64;
-    auto body = [&](auto swap_tag) {
-        constexpr bool SWAP = decltype(swap_tag)::value;
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        f16x8 af[2][TM], bf[2][TN];
-        auto frag = [&](int buf, int kt, int ks) {      // the fragments of k-step ks of K-slice kt
-            const unsigned char* sb = smem + (kt % NSTAGE) * STAGE;
-            const int slot = ((2 * ks + fh) ^ swz) << 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 2048 + slot);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 2048 + slot);
-        };
-        auto mm = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][i], bf[buf][j], acc[i][j], 0, 0, 0);
-                }
-        };
-        dma(0);
-        if (nk > 1) dma(1);
-        if (nk > 2) dma(2);
-        // slice 0 landed (this wave's pieces: all but the 12 younger ones), visible to the workgroup after the barrier
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        frag(0, 0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            // ---- k-step 0: request the fragments of k-step 1, multiply k-step 0
-            frag(1, kt, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(0);
-            __builtin_amdgcn_sched_barrier(0);
-            // this wave is done reading slice kt once its LDS reads have returned; its pieces of slice kt + 1 must have landed:
-            // outstanding DMA = slices kt + 1 (oldest), kt + 2 -> wait until only kt + 2's 6 pieces remain
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- k-step 1: refill the stage of slice kt (slice kt + 3), request the first fragments of slice kt + 1, multiply
-            if (kt + 3 < nk) dma(kt + 3);
-            if (kt + 1 < nk) frag(0, kt + 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
-        else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
-    };
-    if constexpr (EPI == EPI_QKV_ENC) {
-        if (n0 + wn * 64 >= 2 * a.d_model) body(std::false_type{});
-        else body(std::true_type{});
-    } else {
-        body(std::true_type{});
-    }
-}
-
 template <int EPI>
 static void launch_epi(const GemmArgs& a, hipStream_t st) {
     // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
-    static const bool use2 = [] { const char* e = getenv("WH_GEMM2"); return e && e[0] == '1'; }();     // 256 x 128 tile, two workgroups per CU
-    if (!no256 && use2 && tiles256 >= 64 && a.K % 32 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
-        static PerDeviceOnce raised2;
-        raised2.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 73728); });
-        const long long tiles = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-        gemm2_kernel<EPI><<<(unsigned)tiles, 256, 73728, st>>>(a);
-        return;
-    }
     if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
         static PerDeviceOnce raised;
         raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
