@@ -20,9 +20,10 @@ Per configuration and checked slot:
   3. end to end      - the oracle runs its OWN fp64 mel + fp32 encoder from the same PCM: max |delta| of the encoder output and of the
                        logits is MEASURED, written to gpurun_out/r03_fulldepth_errors.json (committed copy: profiles/), and asserted
                        at <= 2 x the value measured when the test was written (E2E_MEASURED below).  Measured on MI355X (profiles/
-                       r03b_fulldepth_errors.json): the encoder output differs from the fp32 oracle by <= 2.6e-3 (mean 3.3e-4; fp16 GEMM
-                       operands over 32 layers) and the logits END TO END by 9.7e-4 at large-v3 - inside the contract's 1e-3 with a
-                       3 % margin; the report carries `within_contract` so that a change which tips it over is seen, not hidden;
+                       r03d_fulldepth_errors.json): the encoder output differs from the fp32 oracle by <= 2.4e-3 (mean 3.3e-4; fp16 GEMM
+                       operands over 32 layers) and the logits END TO END by 7.3e-4 at large-v3 - inside the contract's 1e-3, which is
+                       also asserted as such.  (With the fc1 -> fc2 activations in ONE f16 plane, as in round 2, the same measurement
+                       was 1.1e-3: the first run of this test found that, profiles/r03b_*, r03c; they travel as an f16 hi|lo pair now.)
   4. batch invariance - the last slot decodes to the same ids / log-probs alone (1-slot session) as among the others.
 """
 import json
@@ -62,12 +63,12 @@ ALIGNMENT_HEADS = {
 }
 # end-to-end errors measured on MI355X when this test was written (profiles/r03_fulldepth_errors.json); asserted at 2 x
 E2E_MEASURED = {
-    "large-v3": dict(encoder_max=2.55e-3, encoder_mean=3.28e-4, logits_max=9.67e-4),
-    "small": dict(encoder_max=1.87e-3, encoder_mean=2.71e-4, logits_max=8.47e-4),
-    "tiny.en": dict(encoder_max=1.28e-3, encoder_mean=1.42e-4, logits_max=5.51e-4),
+    "large-v3": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),
+    "small": dict(encoder_max=2.08e-3, encoder_mean=2.71e-4, logits_max=5.10e-4),
+    "tiny.en": dict(encoder_max=1.43e-3, encoder_mean=1.42e-4, logits_max=4.47e-4),
 }
 # stage-isolated logits error against the fp32-K/V oracle (the Float16 rounding of the cached keys / values included), same rule
-STAGE_MEASURED = {"large-v3": 9.68e-4, "small": 8.46e-4, "tiny.en": 5.47e-4}
+STAGE_MEASURED = {"large-v3": 7.54e-4, "small": 5.17e-4, "tiny.en": 4.49e-4}
 # provisional ceilings used while a configuration has no measured value yet
 E2E_CEILING = dict(encoder_max=1e-1, encoder_mean=1e-2, logits_max=2e-2)
 
@@ -212,7 +213,7 @@ def test_fulldepth_stage_isolated_logits_greedy_tokens_and_alignment(rig):
     _write_report()
     assert worst16 <= 1e-3, (rig.name, worst16)
     m = STAGE_MEASURED[rig.name]
-    assert worst32 <= (2.0 * m if m is not None else 5e-3), (rig.name, worst32)
+    assert worst32 <= min(2.0 * m, 1e-3), (rig.name, worst32)        # ... and never beyond the contract
     assert worst_align <= 1e-4, (rig.name, worst_align)
     assert worst_lp <= 2e-3, (rig.name, worst_lp)
     assert all(len(v) <= 4 for v in ties.values()), (rig.name, ties)
@@ -239,6 +240,7 @@ def test_fulldepth_end_to_end_from_pcm(rig):
         m = E2E_MEASURED[rig.name][k]
         limit = 2.0 * m if m is not None else E2E_CEILING[k]
         assert v <= limit, (rig.name, k, v, limit)
+    assert logit_max <= 1e-3, (rig.name, logit_max)      # the contract itself, end to end from PCM, at the depth the benchmark runs
 
 
 def test_fulldepth_batch_invariance(rig):

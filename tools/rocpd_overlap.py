@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Concurrency picture of a multi-stream run from a rocprofv3 rocpd .db (kernel trace): how long 0 / 1 / 2 / 3+ kernels were running,
+how long at least one HBM-bound cross-attention kernel / one encoder GEMM was running, and per queue the busy time and the idle gaps
+between consecutive kernels - what the in-flight regime of bench.py loses against the sum of its kernels.
+
+    python tools/rocpd_overlap.py x_results.db [t0_fraction t1_fraction]     (analyse only the [t0, t1] fraction of the trace)
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main(path, f0=0.0, f1=1.0):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    qcol = next((k for k in ("stream_id", "queue_id", "queue", "stream") if k in cols), None)
+    rows = c.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
+    t_lo, t_hi = rows[0][1], max(r[2] for r in rows)
+    a, b = t_lo + (t_hi - t_lo) * float(f0), t_lo + (t_hi - t_lo) * float(f1)
+    rows = [r for r in rows if r[1] >= a and r[2] <= b]
+    ev = []
+    for name, s, e, q in rows:
+        kind = "xattn" if "cross_attn" in name else "gemm" if ("gemm256" in name or "gemm_kernel" in name or "encoder_attention" in name) else "other"
+        ev.append((s, 1, kind)); ev.append((e, -1, kind))
+    ev.sort()
+    run = defaultdict(int)
+    hist, t_x, t_g, t_xg = defaultdict(int), 0, 0, 0
+    prev = ev[0][0]
+    n = 0
+    for t, d, kind in ev:
+        dt = t - prev
+        if dt > 0:
+            hist[min(n, 4)] += dt
+            if run["xattn"] > 0: t_x += dt
+            if run["gemm"] > 0: t_g += dt
+            if run["xattn"] > 0 and run["gemm"] > 0: t_xg += dt
+        n += d; run[kind] += d; prev = t
+    span = ev[-1][0] - ev[0][0]
+    print(f"queue column: {qcol}; kernels {len(rows)}; span {span / 1e6:.2f} ms")
+    for k in sorted(hist):
+        print(f"  {k}{'+' if k == 4 else ' '} kernels running: {hist[k] / 1e6:9.2f} ms  {100.0 * hist[k] / span:5.1f} %")
+    print(f"  >= 1 cross-attention running: {t_x / 1e6:.2f} ms ({100.0 * t_x / span:.1f} %);  >= 1 encoder GEMM / attention: {t_g / 1e6:.2f} ms "
+          f"({100.0 * t_g / span:.1f} %);  both: {t_xg / 1e6:.2f} ms")
+    per_q = defaultdict(list)
+    for name, s, e, q in rows:
+        per_q[q].append((s, e))
+    for q, ks in sorted(per_q.items(), key=lambda kv: -len(kv[1]))[:8]:
+        busy = sum(e - s for s, e in ks)
+        gaps = sorted(max(0, ks[i + 1][0] - ks[i][1]) for i in range(len(ks) - 1))
+        if not gaps:
+            continue
+        big = sum(g for g in gaps if g > 20000)
+        print(f"  queue {q}: {len(ks)} kernels, busy {busy / 1e6:.2f} ms, gaps total {sum(gaps) / 1e6:.2f} ms (p50 {gaps[len(gaps) // 2]} ns, "
+              f"p90 {gaps[int(len(gaps) * 0.9)]} ns, gaps > 20 us: {big / 1e6:.2f} ms)")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

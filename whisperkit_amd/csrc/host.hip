@@ -347,18 +347,28 @@ static int run_token_loop(wh_session* s, int batch, int loop_count) {
     }
     if (use_graphs()) {
         const int n_graphs = (loop_count + kStepsPerGraph - 1) / kStepsPerGraph;
+        // WH_DBG_HOST=1: host-side cost of the replay loop (time inside hipGraphLaunch vs waiting for the device), one line per decode
+        static const bool dbg_host = [] { const char* e = getenv("WH_DBG_HOST"); return e && e[0] == '1'; }();
+        double t_launch = 0.0, t_wait = 0.0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_begin = dbg_host ? now() : 0.0;
+        struct Report { bool on; double *l, *w, t0; int n; decltype(now)* clk; ~Report() { if (on) fprintf(stderr, "[wh host] decode loop: %d graph launches, %.2f ms inside hipGraphLaunch, %.2f ms waiting for the device, %.2f ms total\n", n, *l * 1e3, *w * 1e3, ((*clk)() - t0) * 1e3); } } report{dbg_host, &t_launch, &t_wait, t_begin, n_graphs, &now};
         for (int g = 0; g < n_graphs; ++g) {
             if (cancelled(s)) { hipStreamSynchronize(s->st); return set_error(WH_ERR_CANCELLED, "decodeText: cancelled through the session's cancel flag"); }
             hipGraphExec_t exec;
             int r = get_step_graph(s, batch, g * kStepsPerGraph, &exec);
             if (r) return r;
+            const double ta = dbg_host ? now() : 0.0;
             WH_HIP(hipGraphLaunch(exec, s->st));
+            if (dbg_host) t_launch += now() - ta;
             // snapshot the slot states behind graph g; while it runs, look at the snapshot behind graph g-1
             // (at most one graph of run-ahead; `done` is monotonic, so a torn snapshot is harmless)
             WH_HIP(hipMemcpyAsync(s->seq_host, s->seq, bytes, hipMemcpyDeviceToHost, s->st));
             WH_HIP(hipEventRecord(s->ev[g & 1], s->st));
             if (g >= 1) {
+                const double tb = dbg_host ? now() : 0.0;
                 WH_HIP(hipEventSynchronize(s->ev[(g - 1) & 1]));
+                if (dbg_host) t_wait += now() - tb;
                 if (all_done()) break;
             }
         }
