@@ -422,7 +422,8 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--inflight", type=int, default=3, help="steps (batches of --batch chunks) in flight per GPU, each on its own session / HIP stream")
-    ap.add_argument("--serial-reference", action="store_true", default=True)
+    ap.add_argument("--serial-reference", action=argparse.BooleanOptionalAction, default=True,
+                    help="after the timed region, time the same workload with one step in flight (value_single_stream); --no-serial-reference skips it")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=64, help="30 s chunks per step (one decode batch = batch / 32 MFMA batch tiles): in total over the GPUs "
                     "with --scaling strong (BASELINE configs[3]: 64 chunks sharded across the GPUs), per GPU with --scaling weak")

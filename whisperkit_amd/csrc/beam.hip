@@ -306,6 +306,8 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
         }
     }
     // ---- 3. the beam loop (decoding.py _main_loop with the reference's loop bounds)
+    const char* bk_env = getenv("WH_XATT_BEAM_SHARED");       // A/B knob, read per call: 0 = per-slot cross-attention workgroups
+    const int beam_kernel = !(bk_env && bk_env[0] == '0');
     std::vector<float> h_lp((size_t)n_slots * kBeamTopK);
     std::vector<int> h_tok((size_t)n_slots * kBeamTopK);
     for (int token_index = n_prompt - 1; any_live && token_index < loop_count; ++token_index) {
@@ -322,6 +324,7 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
         WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * n_slots, hipMemcpyHostToDevice, s->st));
         DecodeBuffers db = whi::decode_buffers(s, n_slots, token_index);
         db.cross_div = beam_size;
+        db.cross_beam_kernel = beam_kernel;
         launch_decoder_step(db, nullptr, nullptr, false, s->st);
         launch_filter_batch(s->cfg_dev, s->suppress_dev, s->seq, s->logits, n_slots, s->st);
         launch_beam_topk(s->logits, s->seq, n_slots, V, beam_size + 1, s->beam_lp, s->beam_tok, s->st);

@@ -279,6 +279,10 @@ static int model_create_impl(const void* blob, size_t nbytes, int device, wh_mod
         r = set_alignment_heads(m, pairs.data(), (int)pairs.size() / 2);
     }
     if (r) { wh_model_destroy(m); return r; }
+    if (hipMalloc((void**)&m->xattn_gate, 256) != hipSuccess || hipMemset(m->xattn_gate, 0, 256) != hipSuccess) {      // its own cache lines
+        wh_model_destroy(m);
+        return set_error(WH_ERR_HIP, "hipMalloc of the cross-attention gate word failed");
+    }
     *out = m;
     return WH_OK;
 }
@@ -308,6 +312,7 @@ extern "C" void wh_model_destroy(wh_model* m) {
     if (m->dec32_blob) hipFree(m->dec32_blob);
     if (m->mel_tables_dev) hipFree(m->mel_tables_dev);
     if (m->align_slot_dev) hipFree(m->align_slot_dev);
+    if (m->xattn_gate) hipFree(m->xattn_gate);
     delete m;
 }
 
@@ -373,6 +378,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     WH_HIP(hipSetDevice(m->device));
     wh_session* s = new wh_session();
     s->m = m; s->B = max_batch;
+    m->n_sessions.fetch_add(1);
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.n_audio_state, L = D.n_text_layer, V = D.n_vocab, H = D.n_text_head;
     if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
@@ -417,6 +423,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
 
 extern "C" void wh_session_destroy(wh_session* s) {
     if (!s) return;
+    if (s->m) s->m->n_sessions.fetch_sub(1);
     if (s->st) hipStreamSynchronize(s->st);
     whi::drop_session_graphs(s);
     if (s->d32_blob) hipFree(s->d32_blob);
@@ -547,6 +554,7 @@ extern "C" int wh_set_encoder_output(wh_session* s, int b, const float* enc) {
 }
 
 // ------------------------------------------------------------------------------------------------ decoder
+constexpr bool kXattnGateDefault = false;     // flipped once measured (profiles/r03h_*)
 namespace whi {
 DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     // max_position: the largest token_index any live slot can have during the launches built from this description
@@ -561,6 +569,10 @@ DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = s->n_align_alloc;
     db.d32 = &s->d32; db.x = s->d32.x; db.q = s->d32.q;
+    // cross-attention gate: WH_XATT_GATE=0 never, 1 always, unset: while the model carries more than one session (dec_shared.h)
+    static const int gate_mode = [] { const char* e = getenv("WH_XATT_GATE"); return e ? atoi(e) : -1; }();
+    const bool gate_on = gate_mode < 0 ? kXattnGateDefault && m->n_sessions.load() > 1 : gate_mode != 0;
+    db.xattn_gate = gate_on ? m->xattn_gate : nullptr;
     return db;
 }
 }  // namespace whi

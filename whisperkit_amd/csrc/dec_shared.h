@@ -45,4 +45,25 @@ __device__ __forceinline__ void split_hilo(float z, f16& hi, f16& lo) {
     lo = (f16)((z - (float)hi) * 2048.0f);
 }
 
+
+// Cross-attention gate (scheduling only, never correctness): sessions of one model that decode concurrently take turns at the ONE
+// kernel of a decoder layer that saturates the HBM.  Free-running streams fall into convoys - their cross-attention launches overlap
+// (each then takes twice as long), finish together, and then all of them run their latency-bound projection chains with the HBM idle
+// (kernel trace of three sessions in flight, profiles/r03g_inflight_overlap.txt: no cross-attention kernel running 34 - 39 % of the
+// time).  The cross-query projection's workgroup 0 takes the gate before it exits (so the session's cross-attention launch starts
+// behind it), the LAST workgroup of the cross-attention grid gives it back when it is dispatched (the grid is draining from there:
+// the next session's launch ramps up under the tail).  A bounded wait: streams that share a hardware queue cannot deadlock, they
+// only lose the staggering.
+constexpr unsigned long long kGateTimeoutTicks = 50000;     // 500 us of the 100 MHz wall clock
+__device__ __forceinline__ void xattn_gate_acquire(int* g) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        int expected = 0;
+        if (__hip_atomic_compare_exchange_strong(g, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (wall_clock64() - t0 > kGateTimeoutTicks) { __hip_atomic_fetch_add(g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+__device__ __forceinline__ void xattn_gate_release(int* g) { __hip_atomic_fetch_add(g, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 }  // namespace wh

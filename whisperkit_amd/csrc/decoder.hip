@@ -27,6 +27,7 @@
 //
 // All results are bit-deterministic (fixed summation orders, no float atomics) and batch-invariant: a slot decodes to the
 // same bits alone or among 31 others (tests/test_gpu_dims.py).
+#include <algorithm>
 #include <cstdlib>
 
 #include "dec_shared.h"
@@ -73,6 +74,7 @@ __device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, cons
 struct AttnArgs {
     int batch, d, n_head, layer, n_layer, n_split;
     int cross_div;           // > 1: slot b attends over the cross K / V of slot b / cross_div (beams of one audio share one copy)
+    int beam_kernel;         // cross_div > 1: one workgroup per (split, head, audio) serves all the beams (dec_cross_attn_beams_kernel)
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
     const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
@@ -82,8 +84,12 @@ struct AttnArgs {
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
     int no_fence;
+    int* gate; int gate_wg;    // cross-attention gate (dec_shared.h): the workgroup with linear id gate_wg gives it back at entry
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
+__device__ __forceinline__ void gate_release_if_mine(const AttnArgs& a) {
+    if (a.gate && threadIdx.x == 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) == a.gate_wg) xattn_gate_release(a.gate);
+}
 #define ATT_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 4096 * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float v) {
@@ -107,15 +113,10 @@ __device__ __forceinline__ uint4 load_kv16(const f16* p) {      // 16 bytes of a
     } else return *reinterpret_cast<const uint4*>(p);
 }
 
-template <int PASSES, bool NT, typename GetN, typename QFix>
-__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
-                                             GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
-                                             float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
-    // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
-    // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int part = tid & 7, kg = tid >> 3;
-    uint4 kreg[PASSES], vreg[PASSES];
+// attend_fetch: every K and V row of the block is requested before anything is used.
+template <int PASSES, bool NT>
+__device__ __forceinline__ void attend_fetch(const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load, uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES]) {
+    const int part = threadIdx.x & 7, kg = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = kg + 32 * i;
@@ -126,16 +127,21 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
         const int key = kg + 32 * i;
         vreg[i] = key < n_load ? load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
     }
-    float qv[8];
-    {
-        float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
-        float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
-        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
-    }
-    const int n = get_n();
-    if (n < 0) return false;            // workgroup-uniform
-    qfix(qv, part);                     // hook for a query fix-up (identity today)
-    float* raw_scores = *raw_pp;
+}
+__device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, float (&qv)[8]) {
+    const int part = threadIdx.x & 7;
+    float4 q0 = *reinterpret_cast<const float4*>(qg + part * 8);
+    float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
+    qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+}
+// attend_compute: the fetched rows against ONE query; n of them count.  The K / V registers survive (rows past n are zeroed, which is
+// the same for every query), so the beam-search kernel runs several queries against one fetch.
+template <int PASSES>
+__device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES], int n, float* raw_scores,
+                                               float* red /* [16] */, float* osum /* [4][64] */, float* o_out /* [64] */, float* m_out, float* l_out,
+                                               unsigned long long* stamp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = tid & 7, kg = tid >> 3;
     float s[PASSES];
     float lmax = -INFINITY;
 #pragma unroll
@@ -192,6 +198,22 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
     if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();
     *m_out = m;
     *l_out = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
+template <int PASSES, bool NT, typename GetN, typename QFix>
+__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
+                                             GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
+                                             float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
+    // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
+    // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
+    uint4 kreg[PASSES], vreg[PASSES];
+    attend_fetch<PASSES, NT>(kb, vb, n_load, kreg, vreg);
+    float qv[8];
+    attend_load_q(qg, qv);
+    const int n = get_n();
+    if (n < 0) return false;            // workgroup-uniform
+    qfix(qv, threadIdx.x & 7);          // hook for a query fix-up (identity today)
+    attend_compute<PASSES>(qv, kreg, vreg, n, *raw_pp, red, osum, o_out, m_out, l_out, stamp);
     return true;
 }
 
@@ -215,12 +237,45 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
 
+// The last arriver of a (slot, head): all S partials (S x 66 floats) are fetched by the whole workgroup in ONE round of independent sc1
+// loads into LDS (a per-thread loop over the splits is S dependent L2 round trips: 24 us at S = 24) and combined from there in index order.
+__device__ __forceinline__ void combine_splits(const AttnArgs& a, int b, int h, int S) {
+    __shared__ float pl[kMaxSplit * 66];
+    const int tid = threadIdx.x;
+    const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
+    constexpr int NLD = (kMaxSplit * 66 + 255) / 256;
+    float tmp[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {         // issue every load before the first use
+        const int i = tid + 256 * k, sp_i = i / 66, e = i - sp_i * 66;
+        tmp[k] = i < S * 66 ? __hip_atomic_load(p0 + sp_i * kPartStride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;   // sc1
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < S * 66) pl[i] = tmp[k];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float mg = -INFINITY;
+        for (int i = 0; i < S; ++i) mg = fmaxf(mg, pl[i * 66]);
+        float lg = 0.0f, og = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            const float w = __expf(pl[i * 66] - mg);
+            lg = fmaf(w, pl[i * 66 + 1], lg);
+            og = fmaf(w, pl[i * 66 + 2 + tid], og);
+        }
+        store_att(a, b, h * kHeadDim + tid, og / lg);
+    }
+}
+
 template <int PASSES, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     constexpr int KPB = PASSES * 32;
     __shared__ float red[16], osum[256], o_l[64];
     __shared__ int last_flag;
     const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    gate_release_if_mine(a);
     const SeqState* sq = a.seq + b;
     const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
     const int d = a.d, S = a.n_split;
@@ -271,37 +326,83 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     __syncthreads();
     ATT_STAMP(4);
     if (last_flag && tid == 0 && a.dbg) stamp[6] = 1;
-    if (last_flag) {      // workgroup-uniform
-        // all S partials (S x 66 floats) are fetched by the whole workgroup in ONE round of independent sc1 loads into LDS
-        // (a per-thread loop over the splits is S dependent L2 round trips: 24 us at S = 24) and combined from there
-        __shared__ float pl[kMaxSplit * 66];
-        const float* p0 = a.part + ((size_t)b * a.n_head + h) * S * kPartStride;
-        constexpr int NLD = (kMaxSplit * 66 + 255) / 256;
-        float tmp[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {         // issue every load before the first use
-            const int i = tid + 256 * k, sp_i = i / 66, e = i - sp_i * 66;
-            tmp[k] = i < S * 66 ? __hip_atomic_load(p0 + sp_i * kPartStride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;   // sc1
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + 256 * k;
-            if (i < S * 66) pl[i] = tmp[k];
-        }
-        __syncthreads();
-        if (tid < 64) {
-            float mg = -INFINITY;
-            for (int i = 0; i < S; ++i) mg = fmaxf(mg, pl[i * 66]);
-            float lg = 0.0f, og = 0.0f;
-            for (int i = 0; i < S; ++i) {
-                const float w = __expf(pl[i * 66] - mg);
-                lg = fmaf(w, pl[i * 66 + 1], lg);
-                og = fmaf(w, pl[i * 66 + 2 + tid], og);
-            }
-            store_att(a, b, h * kHeadDim + tid, og / lg);
+    if (last_flag) combine_splits(a, b, h, S);      // workgroup-uniform
+    ATT_STAMP(5);
+}
+
+
+// Beam search (cross_div = beam size > 1): the beams of an audio attend over ONE cross K / V copy.  One workgroup per (key split, head,
+// AUDIO) fetches the split's K / V rows ONCE into registers and runs the query of every live beam against them, so the traffic of the
+// launch is that of `n_audio` slots, not of n_audio x beam (per-slot workgroups re-read the rows through L2 / MALL: 100 slots of 20
+// audios cost what 100 independent slots cost in request slots, large-v3: ~100 us per launch).  Per beam the arithmetic is that of
+// dec_cross_attn_kernel - same partials, same combine order, the same bits (tests/test_gpu_beam.py compares the two paths).  The
+// partials of all beams are published with ONE drain and one round of tickets.  No reference behaviour (the reference has no beam search).
+constexpr int kMaxBeamShare = 8;
+template <int PASSES>
+__global__ __launch_bounds__(256) void dec_cross_attn_beams_kernel(const AttnArgs a) {
+    constexpr int KPB = PASSES * 32;
+    __shared__ float red[16], osum[256], o_all[kMaxBeamShare][64], ml_all[kMaxBeamShare][2];
+    __shared__ int last_flags[kMaxBeamShare];
+    const int sp = blockIdx.x, h = blockIdx.y, au = blockIdx.z, NB = a.cross_div;
+    const int tid = threadIdx.x;
+    gate_release_if_mine(a);
+    const int d = a.d, S = a.n_split;
+    const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
+    const size_t base = (((size_t)au * a.n_head + h) * kCtx + t0) * kHeadDim;
+    uint4 kreg[PASSES], vreg[PASSES];
+    attend_fetch<PASSES, true>(a.cross_k + base, a.cross_v + base, n, kreg, vreg);
+    int slot = -1;
+    if (a.align) slot = a.align_slot[a.layer * a.n_head + h];
+    unsigned live_mask = 0;
+    for (int j = 0; j < NB; ++j) {
+        const int b = au * NB + j;
+        if (b >= a.batch) break;
+        const SeqState* sq = a.seq + b;
+        if (!(sq->active && !sq->done)) continue;       // workgroup-uniform
+        live_mask |= 1u << j;
+        float qv[8];
+        attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
+        float* raw = nullptr;
+        const int pos = min(max(sq->token_index, 0), kMaxTok - 1);
+        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
+        float m, l;
+        attend_compute<PASSES>(qv, kreg, vreg, n, raw, red, osum, o_all[j], &m, &l, nullptr);
+        if (tid == 0) { ml_all[j][0] = m; ml_all[j][1] = l; }
+    }
+    if (!live_mask) return;
+    __syncthreads();
+    // ---- publish every live beam's partial (write-through stores), ONE drain, one ticket per beam
+    for (int j = 0; j < NB; ++j) {
+        if (!((live_mask >> j) & 1)) continue;
+        const int b = au * NB + j;
+        float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
+        if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_all[j][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 64) {
+            __hip_atomic_store(mine, ml_all[j][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, ml_all[j][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    ATT_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < NB) {
+        int last = 0;
+        if ((live_mask >> tid) & 1) {
+            int* cnt = a.ticket + (au * NB + tid) * a.n_head + h;
+            const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t == S - 1);
+            if (last) {
+                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            }
+        }
+        last_flags[tid] = last;
+    }
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        if (!last_flags[j]) continue;                   // workgroup-uniform
+        combine_splits(a, au * NB + j, h, S);
+        __syncthreads();                                // the combine's LDS staging is reused by the next beam
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- sampler
@@ -670,11 +771,28 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     at.no_fence = nofence;
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
     const dim3 grid(S, H, B);
+    // the gate goes back when workgroup (last - lead) is dispatched; WH_XATT_GATE_LEAD = workgroups before the end (tuning knob)
+    static const int gate_lead = env_int("WH_XATT_GATE_LEAD", 0);
+    at.gate_wg = std::max(0, S * H * B - 1 - gate_lead);
     static const int xlds = env_int("WH_XATT_LDS", 0);   // tuning knob: extra LDS per workgroup caps the residency
     // non-temporal K / V loads (each row is read once per step; measured large-v3, 32 slots: 51.9 -> 49.7 us per launch, 3 sessions in
     // flight 13.4 k -> 14.2 k sequence-steps/s, profiles/r02i_*); WH_XATT_NT=0 is the A/B side
     static const int nt = env_int("WH_XATT_NT", 1);
-    if (nt && at.cross_div <= 1) {      // shared K / V (beam search): cacheable loads, the L2 of the XCD serves the other beams of the audio
+    // beam search: one workgroup per (split, head, AUDIO) runs all the beams' queries against one fetch; WH_XATT_BEAM_SHARED=0 (read per
+    // wh_decode_text_beam call) is the A/B side: per-slot workgroups with cacheable loads, the L2 / MALL serves the other beams of the
+    // audio - same bits either way (tests/test_gpu_beam.py)
+    if (at.beam_kernel && at.cross_div > 1 && at.cross_div <= kMaxBeamShare && B % at.cross_div == 0) {
+        const dim3 gb(S, H, B / at.cross_div);
+        at.gate_wg = std::max(0, S * H * (B / at.cross_div) - 1 - gate_lead);
+        if (S == 3) dec_cross_attn_beams_kernel<16><<<gb, 256, 0, st>>>(at);
+        else if (S == 4) dec_cross_attn_beams_kernel<12><<<gb, 256, 0, st>>>(at);
+        else if (S == 6) dec_cross_attn_beams_kernel<8><<<gb, 256, 0, st>>>(at);
+        else if (S == 8) dec_cross_attn_beams_kernel<6><<<gb, 256, 0, st>>>(at);
+        else if (S == 12) dec_cross_attn_beams_kernel<4><<<gb, 256, 0, st>>>(at);
+        else dec_cross_attn_beams_kernel<2><<<gb, 256, 0, st>>>(at);
+        return;
+    }
+    if (nt && at.cross_div <= 1) {      // shared K / V without the beam kernel: cacheable loads
         if (S == 3) dec_cross_attn_kernel<16, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 4) dec_cross_attn_kernel<12, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 6) dec_cross_attn_kernel<8, true><<<grid, 256, xlds, st>>>(at);
@@ -713,18 +831,18 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a.self_k = db.self_k + (size_t)l * self_stride; a.self_v = db.self_v + (size_t)l * self_stride; a.prof_kind = KK_DEC_QKV;
         launch_dec32_proj(P32_QKV, a, n_bt, st);
         AttnArgs at{};
-        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div;
+        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div; at.beam_kernel = db.cross_beam_kernel;
         at.self_k = a.self_k; at.self_v = a.self_v;
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
-        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align;
+        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate;
         launch_self_attn(at, db.self_passes, H, B, st);
         a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
         a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
         launch_dec32_proj(P32_RESID, a, n_bt, st);
         a = base;               // LN2 (folded) + cross-attention query
-        a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
+        a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ; a.gate = db.xattn_gate;
         launch_dec32_proj(P32_Q, a, n_bt, st);
         at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
         launch_cross_attn(at, S, H, B, st);

@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             last_flag = last;
         }
         __syncthreads();
-        if (!last_flag) return;             // workgroup-uniform
+        if (!last_flag) {                   // workgroup-uniform
+            if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }
+            return;
+        }
         float pv[8][4];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {       // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
         }
     }
     D32_STAMP(6);
+    if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }    // dec_shared.h
 }
 
 // ---------------------------------------------------------------------------------------------- embedding

@@ -266,7 +266,7 @@ static bool use_graphs() {
 // 32-position band (7 per key at most).
 static int get_step_graph(wh_session* s, int batch, int first_step, hipGraphExec_t* out) {
     DecodeBuffers db = whi::decode_buffers(s, batch, first_step + kStepsPerGraph - 1);
-    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_passes};
+    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_passes, db.xattn_gate ? 1 : 0};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WH_OK; }
     hipGraph_t graph;

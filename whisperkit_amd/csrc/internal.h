@@ -44,13 +44,17 @@ struct wh_model {
     std::vector<int> align_slot;   // [L*H] -> slot or -1
     int n_align = 0;
     int* align_slot_dev = nullptr;
+    // cross-attention gate (dec_shared.h): one device word per model; used by the step launches of a session while the model carries
+    // more than one session (WH_XATT_GATE=0 never, =1 always)
+    int* xattn_gate = nullptr;
+    std::atomic<int> n_sessions{0};
 };
 
 // step graphs are keyed by everything their captured launches bake in
 struct WhGraphKey {
-    int batch, align, fused, n_align, self_passes;
+    int batch, align, fused, n_align, self_passes, gate;
     bool operator<(const WhGraphKey& o) const {
-        return std::tie(batch, align, fused, n_align, self_passes) < std::tie(o.batch, o.align, o.fused, o.n_align, o.self_passes);
+        return std::tie(batch, align, fused, n_align, self_passes, gate) < std::tie(o.batch, o.align, o.fused, o.n_align, o.self_passes, o.gate);
     }
 };
 

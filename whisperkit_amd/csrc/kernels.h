@@ -178,6 +178,8 @@ struct DecodeBuffers {
     int n_align;
     SeqState* seq;           // [B]
     int cross_div;           // > 1: slot b reads the cross K / V of slot b / cross_div (beam search: the beams of an audio share ONE copy)
+    int cross_beam_kernel;   // cross_div > 1: the beams of an audio are served by ONE workgroup per (split, head) - one K / V fetch for all of them
+    int* xattn_gate;         // null, or the model's cross-attention gate word (dec_shared.h): concurrent sessions take turns at the HBM
     int self_passes;         // self-attention fetch bound: ceil((largest live token_index + 1) / 32), 1..7 (0 = 7: the whole cache)
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
@@ -228,6 +230,7 @@ struct P32Args {
     float* logits; float* stats; const unsigned char* sup_mask; const SamplerCfg* cfg;   // LOGITS (+ fused greedy statistics)
     float* part; int* ticket;
     const SeqState* seq;
+    int* gate;                   // P32_Q only: workgroup 0 takes the cross-attention gate before it exits (or null)
     int prof_kind;
     unsigned long long* dbg;     // WH_DBG=1: 8 wall-clock stamps per workgroup (tools/probe_dec32.py)
 };
