@@ -3,6 +3,8 @@
 several batch sizes.   python tools/time_decode.py large-v3 8,32 [inflight]"""
 import ctypes, json, os, sys, threading, time
 import numpy as np
+if os.environ.get("WH_TOOL_NO_TORCH") != "1":
+    import torch  # noqa: F401  (bench.py's process set-up: torch's HIP runtime is the one in the process; rocprofv3 bisect in profiles/r03j_*)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whisperkit_amd import api, weights
 from whisperkit_amd.synth import synthetic_chunk
@@ -23,8 +25,13 @@ for B in batches:
             s.padOrTrim(synthetic_chunk(1234 + b), b)
         s.logMelSpectrogram(B); s.encodeFeatures(B); s.prepareDecoderInputs(B)
     prompt = sessions[0].prefillPrompt(opts)
-    for s in sessions:
-        s.decodeText(prompt, opts, batch=B)          # graph capture + warm-up
+    def warm():
+        for s in sessions:
+            s.decodeText(prompt, opts, batch=B)          # graph capture + warm-up
+    if os.environ.get("WH_TOOL_MAIN_THREAD") == "1":
+        warm()
+    else:
+        th = threading.Thread(target=warm); th.start(); th.join()     # bench.py captures on worker threads (profiles/r03j_*)
     def run(s, out, i):
         a = time.perf_counter(); r = s.decodeText(prompt, opts, batch=B); s.synchronize(); out[i] = (time.perf_counter() - a, r[0].steps)
     ts = []

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwhisperhip.so")
+LIB_PATH = os.environ.get("WHISPERHIP_LIB") or os.path.join(HERE, "libwhisperhip.so")      # WHISPERHIP_LIB: another build of the SAME ABI (A/B probes)
 
 WH_MAX_RESULT_TOKENS = 232
 WINDOW_SAMPLES = 480000

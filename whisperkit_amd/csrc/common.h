@@ -37,6 +37,55 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Cross-lane sums / maxima without the LDS crossbar (`__shfl_xor` is ds_bpermute_b32: an LDS-pipe instruction with its latency and an
+// address VGPR): DPP modifiers fold the exchanges inside a row of 16 lanes into the VALU instruction itself, the two exchanges
+// across rows are gfx950's v_permlane16_swap / v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;            // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141, kDppMirror = 0x140;  // lane i <-> 7 - i inside 8 lanes / i <-> 15 - i inside a row
+constexpr int kDppRor8 = 0x128;                            // lane i <- lane (i + 8) % 16 of its row = lane i ^ 8
+// sum / max over the 8 lanes of an aligned group, result in every lane of the group
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);       // the quads are uniform by now: any lane of the other quad will do
+    return v;
+}
+// after the 8-lane groups are uniform: rows, then the four rows of the wave (the swap of a register with itself leaves
+// {rows 0 0 2 2, rows 1 1 3 3} resp. {lanes 0-31 twice, lanes 32-63 twice}: their sum / max is the butterfly step)
+__device__ __forceinline__ float rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = group8_sum(v);
+    v += dpp_mov<kDppMirror>(v);
+    return rows_sum(v);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    return rows_max(v);
+}
+// sum over the 8 lanes that share (lane & 7): l, l ^ 8, l ^ 16, ... - result in all of them
+__device__ __forceinline__ float stride8_sum(float v) {
+    v += dpp_mov<kDppRor8>(v);
+    return rows_sum(v);
+}
+
 // erf-form GELU (activation_function="gelu" in Whisper): x * Phi(x) with erfc(|x|) from Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7 on erf; measured |gelu error| <= 4e-7 over [-8, 8], i.e. far below the fp16 rounding of the result).
 // libdevice erff costs ~3x the instructions and is the dominant VALU cost of the fc1 epilogues.

@@ -84,6 +84,7 @@ struct AttnArgs {
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
     int no_fence;
+    int* xp_counters;          // persistent form: claim counter [0] and exit counter [32] of this session (zero between launches)
     int* gate; int gate_wg;    // cross-attention gate (dec_shared.h): the workgroup with linear id gate_wg gives it back at entry
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
@@ -113,19 +114,20 @@ __device__ __forceinline__ uint4 load_kv16(const f16* p) {      // 16 bytes of a
     } else return *reinterpret_cast<const uint4*>(p);
 }
 
-// attend_fetch: every K and V row of the block is requested before anything is used.
+// attend_fetch: every K and V row of the block is requested before anything is used.  Rows past n_load are not skipped but
+// re-read row n_load - 1 (clamped address): straight-line loads, no exec-mask branches; attend_compute ignores them (key >= n).
 template <int PASSES, bool NT>
 __device__ __forceinline__ void attend_fetch(const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load, uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES]) {
     const int part = threadIdx.x & 7, kg = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        const int key = kg + 32 * i;
-        kreg[i] = key < n_load ? load_kv16<NT>(kb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        const int key = min(kg + 32 * i, n_load - 1);
+        kreg[i] = load_kv16<NT>(kb + (size_t)key * kHeadDim + part * 8);
     }
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        const int key = kg + 32 * i;
-        vreg[i] = key < n_load ? load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8) : uint4{0, 0, 0, 0};
+        const int key = min(kg + 32 * i, n_load - 1);
+        vreg[i] = load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8);
     }
 }
 __device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, float (&qv)[8]) {
@@ -150,17 +152,15 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kre
         float t = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t = fmaf((float)k8[j], qv[j], t);
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
+        t = group8_sum(t);
         const int key = kg + 32 * i;
-        if (key < n) {
-            if (raw_scores && part == 0) raw_scores[key] = t;
-            lmax = fmaxf(lmax, t);
-        } else t = -INFINITY;
+        const bool in = key < n;
+        if (raw_scores && part == 0 && in) raw_scores[key] = t;
+        t = in ? t : -INFINITY;
+        lmax = fmaxf(lmax, t);
         s[i] = t;
     }
-    lmax = wave_max(lmax);
+    lmax = wave_max_dpp(lmax);
     if (lane == 0) red[wave] = lmax;
     if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
     __syncthreads();
@@ -179,16 +179,10 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kre
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
     }
-    lsum = wave_sum(lsum);
+    lsum = wave_sum_dpp(lsum);
     if (lane == 0) red[4 + wave] = lsum;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = o[j];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        o[j] = v;
-    }
+    for (int j = 0; j < 8; ++j) o[j] = stride8_sum(o[j]);
     if (lane < 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) osum[wave * 64 + lane * 8 + j] = o[j];
@@ -330,6 +324,119 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     ATT_STAMP(5);
 }
 
+
+// ---------------------------------------------------------------------------------------------- persistent, software-pipelined form
+// The same work items (key split, head, slot), the same per-item arithmetic (attend_compute), the same partial slots / tickets /
+// combine - so the same bits as dec_cross_attn_kernel - but a FIXED set of workgroups (a few per CU) that claim items from a counter and
+// keep the NEXT item's K / V rows in flight while they compute the current one.
+// Why (kernel traces of three sessions in flight, profiles/r03i_*): the one-item-per-workgroup kernel needs 7 waves per SIMD and
+// ~86 MB of loads in flight to reach its rate, because a workgroup is loading for only part of its life (load -> compute -> publish
+// -> ticket).  That queue depth is also the latency every OTHER kernel's memory access pays: the projection kernels of the other
+// sessions take 22 - 28 us beside it instead of 10 - 14 us, and 69 VGPRs x 7 waves leave a SIMD no room for their 204-VGPR waves.
+// Capping the residency of the one-item kernel (3 workgroups per CU) brings them back to 13 - 18 us - and halves its own rate.  Here a
+// workgroup always has one item's loads (48 KB) in flight, two workgroups per CU cover the bandwidth-latency product, and the queue
+// stays short.
+// Per item: [the claim of the item after next is already in flight] compute -> publish (write-through) -> drain (by now the next
+// item's rows have landed too: memory returns are in order) -> ticket (asynchronous) -> barrier -> fetch of the newly claimed item
+// into the registers just freed -> ticket result -> combine if last.  Claims: one agent-scope counter per session, items handed out
+// in index order (the splits of a (slot, head) are computed close together); the workgroup that exits last re-arms the counters.
+template <int PASSES>
+struct XItemRegs { uint4 k[PASSES], v[PASSES]; float q[8]; int live, ti; };
+
+template <int PASSES>
+__global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const AttnArgs a, const int n_items) {
+    constexpr int KPB = PASSES * 32;
+    __shared__ float red[16], osum[256], o_l[64];
+    __shared__ int last_flag, next_item;
+    const int tid = threadIdx.x;
+    const int S = a.n_split, H = a.n_head, d = a.d;
+    int* const claim_cnt = a.xp_counters;
+    int* const exit_cnt = a.xp_counters + 32;      // its own cache line
+
+    auto fetch = [&](int it, XItemRegs<PASSES>& x) {
+        const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
+        const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
+        const int bc = a.cross_div > 1 ? b / a.cross_div : b;
+        const size_t base = (((size_t)bc * H + h) * kCtx + t0) * kHeadDim;
+        attend_fetch<PASSES, true>(a.cross_k + base, a.cross_v + base, n, x.k, x.v);
+        attend_load_q(a.q + (size_t)b * d + h * kHeadDim, x.q);
+        const SeqState* sq = a.seq + b;
+        x.live = sq->active && !sq->done;
+        x.ti = sq->token_index;
+    };
+    // one item: returns the item now loading into x (or -1)
+    auto step = [&](int it, XItemRegs<PASSES>& x) -> int {
+        const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
+        const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
+        int claim = 0;
+        if (tid == 0) claim = __hip_atomic_fetch_add(claim_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the compute
+        if (a.gate && tid == 0 && it == n_items - 1) xattn_gate_release(a.gate);
+        const bool live = x.live != 0;          // workgroup-uniform
+        float m = 0.0f, l = 0.0f;
+        if (live) {
+            float* raw = nullptr;
+            if (a.align) {
+                const int slot = a.align_slot[a.layer * H + h];
+                const int pos = min(max(x.ti, 0), kMaxTok - 1);
+                if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
+            }
+            attend_compute<PASSES>(x.q, x.k, x.v, n, raw, red, osum, o_l, &m, &l, nullptr);
+            float* mine = a.part + (((size_t)b * H + h) * S + sp) * kPartStride;
+            if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 64) {
+                __hip_atomic_store(mine, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial is out; the other buffer's rows and the claim are in
+        int ticket = 0;
+        int* cnt = a.ticket + b * H + h;
+        if (tid == 0) {
+            if (live) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // result looked at after the fetch
+            next_item = claim < n_items ? claim : -1;
+        }
+        __syncthreads();
+        const int nn = next_item;
+        if (nn >= 0) fetch(nn, x);
+        if (tid == 0) {
+            const int last = live && ticket == S - 1;
+            if (last) {
+                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            }
+            last_flag = last;
+        }
+        __syncthreads();
+        if (last_flag) combine_splits(a, b, h, S);      // workgroup-uniform
+        __syncthreads();                                // last_flag / next_item / the combine's staging are rewritten by the next item
+        return nn;
+    };
+
+    if (tid == 0) {
+        const int c = __hip_atomic_fetch_add(claim_cnt, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next_item = c;
+    }
+    __syncthreads();
+    const int c0 = next_item;
+    __syncthreads();
+    int itX = c0 < n_items ? c0 : -1, itY = c0 + 1 < n_items ? c0 + 1 : -1;
+    XItemRegs<PASSES> X, Y;
+    if (itX >= 0) fetch(itX, X);
+    if (itY >= 0) fetch(itY, Y);
+    for (;;) {
+        if (itX < 0) break;
+        itX = step(itX, X);
+        if (itY < 0) break;
+        itY = step(itY, Y);
+    }
+    if (tid == 0) {     // the workgroup that leaves last re-arms the counters for the next launch of this session
+        const int gone = __hip_atomic_fetch_add(exit_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)gridDim.x - 1) {
+            __hip_atomic_store(claim_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(exit_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // Beam search (cross_div = beam size > 1): the beams of an audio attend over ONE cross K / V copy.  One workgroup per (key split, head,
 // AUDIO) fetches the split's K / V rows ONCE into registers and runs the query of every live beam against them, so the traffic of the
@@ -765,6 +872,7 @@ static void launch_self_attn(const AttnArgs& at, int passes, int H, int B, hipSt
     }
 }
 
+constexpr int kXattPersistDefault = 0;      // flipped once measured (profiles/r03l_*)
 static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStream_t st) {
     static const int nofence = env_int("WH_XATT_NOFENCE", 1);   // sc1 stores + sc1 loads need no acquire (MI355X_MICROARCH.md R1); 0 restores it (A/B)
     AttnArgs at = at_in;
@@ -790,6 +898,14 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
         else if (S == 8) dec_cross_attn_beams_kernel<6><<<gb, 256, 0, st>>>(at);
         else if (S == 12) dec_cross_attn_beams_kernel<4><<<gb, 256, 0, st>>>(at);
         else dec_cross_attn_beams_kernel<2><<<gb, 256, 0, st>>>(at);
+        return;
+    }
+    // persistent, software-pipelined form (same bits): WH_XATT_PERSIST = workgroups per CU (0 = the one-item-per-workgroup kernel);
+    // only where every workgroup gets >= 8 items - below that the launch is latency, not bandwidth (8 slots of large-v3: 1280 items)
+    static const int persist_k = env_int("WH_XATT_PERSIST", kXattPersistDefault);
+    static const int n_cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    if (persist_k > 0 && nt && at.cross_div <= 1 && at.xp_counters && S == 8 && S * H * B >= 8 * persist_k * n_cus) {
+        dec_cross_attn_persist_kernel<6><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
         return;
     }
     if (nt && at.cross_div <= 1) {      // shared K / V without the beam kernel: cacheable loads
@@ -835,7 +951,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         at.self_k = a.self_k; at.self_v = a.self_v;
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
-        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate;
+        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate; at.xp_counters = db.ticket + (size_t)db.max_batch * H;
         launch_self_attn(at, db.self_passes, H, B, st);
         a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
         a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
