@@ -389,7 +389,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
-    DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H + 64);      // + the claim / exit counters of the persistent cross-attention kernel
+    DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H + 512);      // + the claim / exit counters of the persistent cross-attention kernel
     DALLOC(s->logits, B * V);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
     DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress); DALLOC(s->sup_mask_dev, V); DALLOC(s->stats, B * kStatBlocks * 8);

@@ -84,7 +84,7 @@ struct AttnArgs {
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
     int no_fence;
-    int* xp_counters;          // persistent form: claim counter [0] and exit counter [32] of this session (zero between launches)
+    int* xp_counters;          // persistent form: per-XCD claim counters [32 x] and the exit counter [256] of this session (zero between launches)
     int* gate; int gate_wg;    // cross-attention gate (dec_shared.h): the workgroup with linear id gate_wg gives it back at entry
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
@@ -336,22 +336,24 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
 // Capping the residency of the one-item kernel (3 workgroups per CU) brings them back to 13 - 18 us - and halves its own rate.  Here a
 // workgroup always has one item's loads (48 KB) in flight, two workgroups per CU cover the bandwidth-latency product, and the queue
 // stays short.
-// Per item: [the claim of the item after next is already in flight] compute -> publish (write-through) -> drain (by now the next
-// item's rows have landed too: memory returns are in order) -> ticket (asynchronous) -> barrier -> fetch of the newly claimed item
-// into the registers just freed -> ticket result -> combine if last.  Claims: one agent-scope counter per session, items handed out
-// in index order (the splits of a (slot, head) are computed close together); the workgroup that exits last re-arms the counters.
+// First form (profiles/r03l_*, r03m_*: 135 us per launch against 90): compute -> publish -> drain -> ticket -> fetch, i.e. two dependent
+// memory round trips per item with nothing else of the workgroup in flight (6.7 us per item and workgroup).  This form defers them.
 template <int PASSES>
 struct XItemRegs { uint4 k[PASSES], v[PASSES]; float q[8]; int live, ti; };
 
-template <int PASSES>
+template <int PASSES, bool DYNAMIC>
 __global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const AttnArgs a, const int n_items) {
     constexpr int KPB = PASSES * 32;
     __shared__ float red[16], osum[256], o_l[64];
     __shared__ int last_flag, next_item;
     const int tid = threadIdx.x;
     const int S = a.n_split, H = a.n_head, d = a.d;
-    int* const claim_cnt = a.xp_counters;
-    int* const exit_cnt = a.xp_counters + 32;      // its own cache line
+    // claims: DYNAMIC = one counter per XCD (a single word hands out ~88 items per us: 10240 items would take longer than the kernel),
+    // workgroup w pulls from shard w % 8 (the XCD it runs on), item = claim * 8 + shard; static = items w, w + G, w + 2 G, ...
+    const int shard = blockIdx.x & 7;
+    int* const claim_cnt = a.xp_counters + 32 * shard;      // a cache line each
+    int* const exit_cnt = a.xp_counters + 32 * 8;
+    int next_static = blockIdx.x + 2 * (int)gridDim.x;
 
     auto fetch = [&](int it, XItemRegs<PASSES>& x) {
         const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
@@ -364,12 +366,40 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const At
         x.live = sq->active && !sq->done;
         x.ti = sq->token_index;
     };
+    // The publish of an item trails its compute by one iteration and its ticket by two, so that no wait is ever for something just issued:
+    // iteration i computes item n_i, then drains (what is outstanding - the rows of n_i+1, the partial of n_i-1, the ticket of n_i-2 -
+    // was issued an iteration ago), reads the ticket of n_i-2, issues the ticket of n_i-1 and the partial stores of n_i, combines
+    // n_i-2 if it arrived last, and only then requests the rows of n_i+2 into the registers n_i occupied.
+    struct Pend { int b, h, live; };
+    Pend p1{0, 0, 0}, p2{0, 0, 0};     // p1: partial stores in flight, no ticket yet; p2: ticket in flight
+    int tk1 = 0, tk2 = 0;              // thread 0: ticket values of p1 / p2
+    auto retire = [&](bool live_now, const float* o_src, float m, float l, float* mine) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const int last = p2.live && tk2 == S - 1;
+            if (last) {
+                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(a.ticket + p2.b * H + p2.h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            }
+            last_flag = last;
+            if (p1.live) tk1 = __hip_atomic_fetch_add(a.ticket + p1.b * H + p1.h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (live_now && tid < 64) {     // the whole partial leaves from WAVE 0: the drain that precedes its ticket (thread 0, next iteration) is that wave's own
+            __hip_atomic_store(mine + 2 + tid, o_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 2) __hip_atomic_store(mine + tid, tid == 0 ? m : l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (last_flag) combine_splits(a, p2.b, p2.h, S);      // workgroup-uniform; one barrier inside
+        __syncthreads();                                      // last_flag / next_item / the combine's staging are rewritten by the next item
+    };
     // one item: returns the item now loading into x (or -1)
     auto step = [&](int it, XItemRegs<PASSES>& x) -> int {
         const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
         const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
         int claim = 0;
-        if (tid == 0) claim = __hip_atomic_fetch_add(claim_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // in flight under the compute
+        if (DYNAMIC) {      // in flight under the compute; item = claim * 8 + shard
+            if (tid == 0) claim = __hip_atomic_fetch_add(claim_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + shard;
+        } else { claim = next_static; next_static += (int)gridDim.x; }
         if (a.gate && tid == 0 && it == n_items - 1) xattn_gate_release(a.gate);
         const bool live = x.live != 0;          // workgroup-uniform
         float m = 0.0f, l = 0.0f;
@@ -381,45 +411,23 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const At
                 if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
             }
             attend_compute<PASSES>(x.q, x.k, x.v, n, raw, red, osum, o_l, &m, &l, nullptr);
-            float* mine = a.part + (((size_t)b * H + h) * S + sp) * kPartStride;
-            if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_l[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 64) {
-                __hip_atomic_store(mine, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial is out; the other buffer's rows and the claim are in
-        int ticket = 0;
-        int* cnt = a.ticket + b * H + h;
-        if (tid == 0) {
-            if (live) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // result looked at after the fetch
-            next_item = claim < n_items ? claim : -1;
-        }
-        __syncthreads();
-        const int nn = next_item;
+        if (DYNAMIC && tid == 0) next_item = claim < n_items ? claim : -1;     // read after retire's barrier
+        retire(live, o_l, m, l, a.part + (((size_t)b * H + h) * S + sp) * kPartStride);
+        const int nn = DYNAMIC ? next_item : (claim < n_items ? claim : -1);
         if (nn >= 0) fetch(nn, x);
-        if (tid == 0) {
-            const int last = live && ticket == S - 1;
-            if (last) {
-                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            }
-            last_flag = last;
-        }
-        __syncthreads();
-        if (last_flag) combine_splits(a, b, h, S);      // workgroup-uniform
-        __syncthreads();                                // last_flag / next_item / the combine's staging are rewritten by the next item
+        p2 = p1; tk2 = tk1; p1 = Pend{b, h, live ? 1 : 0};
         return nn;
     };
 
-    if (tid == 0) {
-        const int c = __hip_atomic_fetch_add(claim_cnt, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        next_item = c;
+    int c0 = blockIdx.x, c1 = blockIdx.x + (int)gridDim.x;
+    if (DYNAMIC) {
+        if (tid == 0) next_item = __hip_atomic_fetch_add(claim_cnt, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        c0 = next_item * 8 + shard; c1 = c0 + 8;
+        __syncthreads();
     }
-    __syncthreads();
-    const int c0 = next_item;
-    __syncthreads();
-    int itX = c0 < n_items ? c0 : -1, itY = c0 + 1 < n_items ? c0 + 1 : -1;
+    int itX = c0 < n_items ? c0 : -1, itY = c1 < n_items ? c1 : -1;
     XItemRegs<PASSES> X, Y;
     if (itX >= 0) fetch(itX, X);
     if (itY >= 0) fetch(itY, Y);
@@ -429,10 +437,14 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const At
         if (itY < 0) break;
         itY = step(itY, Y);
     }
-    if (tid == 0) {     // the workgroup that leaves last re-arms the counters for the next launch of this session
+    for (int r = 0; r < 2; ++r) {       // the two items still on their way out
+        retire(false, o_l, 0.0f, 0.0f, nullptr);
+        p2 = p1; tk2 = tk1; p1 = Pend{0, 0, 0};
+    }
+    if (DYNAMIC && tid == 0) {     // the workgroup that leaves last re-arms the counters for the next launch of this session
         const int gone = __hip_atomic_fetch_add(exit_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == (int)gridDim.x - 1) {
-            __hip_atomic_store(claim_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int x = 0; x < 8; ++x) __hip_atomic_store(a.xp_counters + 32 * x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(exit_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -905,7 +917,9 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     static const int persist_k = env_int("WH_XATT_PERSIST", kXattPersistDefault);
     static const int n_cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     if (persist_k > 0 && nt && at.cross_div <= 1 && at.xp_counters && S == 8 && S * H * B >= 8 * persist_k * n_cus) {
-        dec_cross_attn_persist_kernel<6><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
+        static const int dyn = env_int("WH_XATT_CLAIM", 0);     // 1: items claimed from per-XCD counters; 0: static stride
+        if (dyn) dec_cross_attn_persist_kernel<6, true><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
+        else dec_cross_attn_persist_kernel<6, false><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
         return;
     }
     if (nt && at.cross_div <= 1) {      // shared K / V without the beam kernel: cacheable loads
