@@ -208,26 +208,6 @@ def test_transcribe_with_beam_and_temperature_fallback_vs_oracle(peaky):
             assert res.timings["total_decoding_fallbacks"] == 0
 
 
-def test_beam_cross_attention_shared_fetch_equals_per_slot_kernel(peaky, monkeypatch):
-    """dec_cross_attn_beams_kernel (one workgroup per (split, head, AUDIO): the K / V rows fetched once, every beam's query run against
-    them) against the per-slot cross-attention kernel (WH_XATT_BEAM_SHARED=0, read per call): the same partials combined in the same
-    order, so the decode must agree bit for bit - tokens, log-probabilities, steps - including a dead audio slot in the batch."""
-    dims, _, model, om, st, langs, ml = peaky
-    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=36)
-    n = len(AUDIOS)
-    for beam in (5, 3):
-        res = []
-        for flag in ("1", "0"):
-            monkeypatch.setenv("WH_XATT_BEAM_SHARED", flag)
-            sess = api.Session(model, n * beam)
-            _encode(sess, AUDIOS)
-            prompt = sess.prefillPrompt(opts)
-            res.append(sess.decodeTextBeam(prompt, opts, nAudio=n, beamSize=beam))
-            sess.close()
-        for x, y in zip(*res):
-            assert x.tokens == y.tokens and x.tokenLogProbs == y.tokenLogProbs and x.steps == y.steps and x.avgLogProb == y.avgLogProb
-
-
 def test_fixture_coverage():
     """Runs last: how much of the above was decisive.  Most comparisons must have been made on decisive rankings, some decodes must
     have ended through finished (EOT) sequences, and beam search must have left the greedy path at least once."""

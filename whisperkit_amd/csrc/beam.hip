@@ -198,31 +198,9 @@ struct AudioBeams {
 };
 
 int ensure_beam_buffers(wh_session* s) {
-    const wh_model* m = s->m;
-    const size_t n = (size_t)m->dims.n_text_layer * s->B * kMaxTok * m->dims.n_text_state;
-    if (!s->beam_k) WH_HIP(hipMalloc((void**)&s->beam_k, n * sizeof(f16)));
-    if (!s->beam_v) WH_HIP(hipMalloc((void**)&s->beam_v, n * sizeof(f16)));
-    if (!s->beam_pairs) WH_HIP(hipMalloc((void**)&s->beam_pairs, sizeof(int) * 2 * (size_t)s->B));
+    if (!s->beam_owner) WH_HIP(hipMalloc((void**)&s->beam_owner, sizeof(int) * kMaxTok * (size_t)s->B));
     if (!s->beam_lp) WH_HIP(hipMalloc((void**)&s->beam_lp, sizeof(float) * kBeamTopK * (size_t)s->B));
     if (!s->beam_tok) WH_HIP(hipMalloc((void**)&s->beam_tok, sizeof(int) * kBeamTopK * (size_t)s->B));
-    return WH_OK;
-}
-
-// copy slot pairs (from, to) inside the self (first n_pos positions of every head) or the cross K/V buffers
-int copy_pairs(wh_session* s, const std::vector<int>& pairs, bool cross, const f16* src_k, f16* dst_k, const f16* src_v, f16* dst_v, int n_pos) {
-    if (pairs.empty()) return WH_OK;
-    const wh_model* m = s->m;
-    const int L = m->dims.n_text_layer, H = m->dims.n_text_head;
-    const int rows = cross ? kCtx : kMaxTok;
-    const size_t slot = (size_t)H * rows * kHeadDim, layer = slot * s->B;
-    WH_HIP(hipMemcpyAsync(s->beam_pairs, pairs.data(), sizeof(int) * pairs.size(), hipMemcpyHostToDevice, s->st));
-    const int n_pairs = (int)pairs.size() / 2;
-    const int n_seg = cross ? 1 : H, seg_stride = cross ? 0 : rows * kHeadDim;
-    const int seg_copy = cross ? (int)slot : std::min(n_pos, rows) * kHeadDim;
-    launch_copy_slots(src_k, dst_k, L, layer, slot, n_seg, seg_stride, seg_copy, s->beam_pairs, n_pairs, s->st);
-    launch_copy_slots(src_v, dst_v, L, layer, slot, n_seg, seg_stride, seg_copy, s->beam_pairs, n_pairs, s->st);
-    WH_HIP(hipGetLastError());
-    WH_HIP(hipStreamSynchronize(s->st));      // `pairs` is reused by the caller; the copies are small next to a decoder step
     return WH_OK;
 }
 }  // namespace
@@ -293,21 +271,17 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
             any_live = true;
         }
     }
-    // ---- 2. every audio's pre-filled cache rows into its beam slots (audio a -> slots a * beam .. + beam - 1).  Descending, one launch group
-    // per audio: a destination slot is never a source that is still needed.  The cross K / V is NOT replicated: the beams of audio a read
-    // the one copy in slot a (DecodeBuffers.cross_div = beam_size; round 2 copied 245 MB per beam at large-v3 and streamed it 5 x per step)
+    // ---- 2. nothing is replicated.  Audio a owns slots a * beam .. a * beam + beam - 1; the cross K / V is read from the one copy in slot a
+    // (DecodeBuffers.cross_div = beam_size; round 2 copied 245 MB per beam at large-v3 and streamed it 5 x per step), and the self-attention
+    // cache is read through a row -> owner table (DecodeBuffers.self_owner): the pre-filled rows 0 .. n_prompt - 2 of audio a live in slot a
+    // (where the pre-fill wrote them; the beam that occupies slot a only ever writes rows >= n_prompt - 1), row r of a beam's history lives
+    // in the slot of the beam that computed it.  Re-parenting a beam copies ints on the host (round 2 / early round 3: openai's
+    // rearrange_kv_cache as slot copies through a scratch cache - 18 % of the beam pass at large-v3, profiles/r03i_beam_*).
     const int n_slots = n_audio * beam_size;
-    if (any_live && beam_size > 1) {
-        for (int a = n_audio - 1; a >= 0; --a) {
-            std::vector<int> pairs;
-            for (int j = beam_size - 1; j >= 0; --j) if (a * beam_size + j != a) { pairs.push_back(a); pairs.push_back(a * beam_size + j); }
-            r = copy_pairs(s, pairs, false, s->self_k, s->self_k, s->self_v, s->self_v, n_prompt);
-            if (r) return r;
-        }
-    }
+    std::vector<int> owner((size_t)n_slots * kMaxTok), owner_next;
+    for (int j = 0; j < n_slots; ++j)
+        for (int r_ = 0; r_ < kMaxTok; ++r_) owner[(size_t)j * kMaxTok + r_] = r_ < n_prompt - 1 ? j / beam_size : j;
     // ---- 3. the beam loop (decoding.py _main_loop with the reference's loop bounds)
-    const char* bk_env = getenv("WH_XATT_BEAM_SHARED");       // A/B knob, read per call: 0 = per-slot cross-attention workgroups
-    const int beam_kernel = !(bk_env && bk_env[0] == '0');
     std::vector<float> h_lp((size_t)n_slots * kBeamTopK);
     std::vector<int> h_tok((size_t)n_slots * kBeamTopK);
     for (int token_index = n_prompt - 1; any_live && token_index < loop_count; ++token_index) {
@@ -322,16 +296,17 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
                 q.n_tokens = (int)bq.tok.size(); q.token_index = token_index; q.next_token = bq.tok.back(); q.prompt_len = n_prompt; q.active = 1;
             }
         WH_HIP(hipMemcpyAsync(s->seq, s->seq_host, sizeof(SeqState) * n_slots, hipMemcpyHostToDevice, s->st));
+        for (int j = 0; j < n_slots; ++j) owner[(size_t)j * kMaxTok + token_index] = j;      // the row this step writes is the slot's own
+        WH_HIP(hipMemcpyAsync(s->beam_owner, owner.data(), sizeof(int) * owner.size(), hipMemcpyHostToDevice, s->st));
         DecodeBuffers db = whi::decode_buffers(s, n_slots, token_index);
         db.cross_div = beam_size;
-        db.cross_beam_kernel = beam_kernel;
+        db.self_owner = s->beam_owner;
         launch_decoder_step(db, nullptr, nullptr, false, s->st);
-        launch_filter_batch(s->cfg_dev, s->suppress_dev, s->seq, s->logits, n_slots, s->st);
-        launch_beam_topk(s->logits, s->seq, n_slots, V, beam_size + 1, s->beam_lp, s->beam_tok, s->st);
+        launch_beam_filter_topk(s->cfg_dev, s->suppress_dev, s->seq, s->logits, n_slots, beam_size + 1, s->beam_lp, s->beam_tok, s->st);
         WH_CHECK_LAUNCH();
         WH_HIP(hipMemcpyAsync(h_lp.data(), s->beam_lp, sizeof(float) * h_lp.size(), hipMemcpyDeviceToHost, s->st));
         WH_HIP(hipMemcpyAsync(h_tok.data(), s->beam_tok, sizeof(int) * h_tok.size(), hipMemcpyDeviceToHost, s->st));
-        WH_HIP(hipStreamSynchronize(s->st));
+        WH_HIP(hipStreamSynchronize(s->st));      // (also: `owner` / seq_host may be rewritten now)
         std::vector<int> pairs;
         any_live = false;
         for (int a = 0; a < n_audio; ++a) {
@@ -354,14 +329,13 @@ static int wh_decode_text_beam_impl(wh_session* s, int n_audio, int beam_size, f
             if (completed) ab.live = false;
             any_live |= ab.live;
         }
-        if (any_live && !pairs.empty() && token_index + 1 < loop_count) {
-            // rearrange_kv_cache: new beam j continues the cache of its source beam - through the scratch copy, then back
-            std::vector<int> to_scratch, back;
-            for (size_t p = 0; p < pairs.size(); p += 2) { to_scratch.push_back(pairs[p]); to_scratch.push_back(pairs[p + 1]); back.push_back(pairs[p + 1]); back.push_back(pairs[p + 1]); }
-            r = copy_pairs(s, to_scratch, false, s->self_k, s->beam_k, s->self_v, s->beam_v, token_index + 1);
-            if (r) return r;
-            r = copy_pairs(s, back, false, s->beam_k, s->self_k, s->beam_v, s->self_v, token_index + 1);
-            if (r) return r;
+        if (any_live && !pairs.empty()) {
+            // rearrange_kv_cache without moving a byte: new beam `to` continues the history of old beam `from` (rows 0 .. token_index)
+            owner_next = owner;
+            for (size_t p = 0; p < pairs.size(); p += 2)
+                std::copy(owner.begin() + (size_t)pairs[p] * kMaxTok, owner.begin() + (size_t)pairs[p] * kMaxTok + token_index + 1,
+                          owner_next.begin() + (size_t)pairs[p + 1] * kMaxTok);
+            owner.swap(owner_next);
         }
     }
     // ---- 4. finalize, rank, results in the reference's DecodingResult conventions (TextDecoder.swift:776-854)

@@ -389,7 +389,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
-    DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H + 512);      // + the claim / exit counters of the persistent cross-attention kernel
+    DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
     DALLOC(s->logits, B * V);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
     DALLOC(s->seq, B); DALLOC(s->cfg_dev, 1); DALLOC(s->suppress_dev, kMaxSuppress); DALLOC(s->sup_mask_dev, V); DALLOC(s->stats, B * kStatBlocks * 8);
@@ -431,7 +431,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits,
-                    s->beam_k, s->beam_v, s->beam_pairs, s->beam_tok, s->beam_lp};
+                    s->beam_owner, s->beam_tok, s->beam_lp};
     for (void* p : ptrs) if (p) hipFree(p);
     if (s->seq_host) hipHostFree(s->seq_host);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
@@ -561,7 +561,8 @@ DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     const wh_model* m = s->m;
     DecodeBuffers db{};
     db.cross_div = 1;
-    db.self_passes = std::min(7, std::max(1, (std::min(std::max(max_position, 0), kMaxTok - 1) + 32) / 32));
+    db.self_rows = std::min(std::max(max_position, 0), kMaxTok - 1) + 1;
+    db.self_owner = nullptr;
     db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
     db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v;

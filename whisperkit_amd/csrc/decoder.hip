@@ -74,7 +74,6 @@ __device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, cons
 struct AttnArgs {
     int batch, d, n_head, layer, n_layer, n_split;
     int cross_div;           // > 1: slot b attends over the cross K / V of slot b / cross_div (beams of one audio share one copy)
-    int beam_kernel;         // cross_div > 1: one workgroup per (split, head, audio) serves all the beams (dec_cross_attn_beams_kernel)
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
     const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
@@ -84,7 +83,8 @@ struct AttnArgs {
     float* align; const int* align_slot; int n_align;   // [B][224][n_align][1500] raw score rows of the alignment heads
     SeqState* seq;
     int no_fence;
-    int* xp_counters;          // persistent form: per-XCD claim counters [32 x] and the exit counter [256] of this session (zero between launches)
+    int self_rows;             // self-attention: cache rows fetched (DecodeBuffers.self_rows)
+    const int* self_owner;     // self-attention: row -> owning slot table of beam search, or null
     int* gate; int gate_wg;    // cross-attention gate (dec_shared.h): the workgroup with linear id gate_wg gives it back at entry
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
 };
@@ -211,9 +211,10 @@ __device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const
     return true;
 }
 
-// PASSES x 32 cached positions are FETCHED (speculatively, before the slot state is known): the launcher passes the smallest
-// bound that covers every live slot's position, so the cache traffic follows the decoded length instead of always being 224 rows
-// (PMC, 32 slots at positions < 9: 37 MB fetched per launch with the fixed 7 passes against 1.5 MB needed).
+// self_rows cached positions are FETCHED (speculatively, before the slot state is known): the launcher passes the smallest bound that
+// covers every live slot's position in its launches (the host replays one step graph per 8 positions), so the cache traffic follows
+// the decoded length (PMC: 37 MB per launch at 32 slots for 1.5 MB needed with a fixed 224-row fetch, 3.4 x the needed bytes with a
+// bound per 32-row band; rows past the bound re-read the last row: cache hits).
 template <int PASSES>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     __shared__ float red[16], osum[256], o_l[64];
@@ -221,13 +222,48 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     const SeqState* sq = a.seq + b;
     const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;     // looked at after the K/V loads are issued
     const int d = a.d;
+    const int n_load = min(PASSES * 32, a.self_rows > 0 ? a.self_rows : PASSES * 32);
     const size_t base = ((size_t)b * a.n_head + h) * kMaxTok * kHeadDim;
     float m, l;
     float* raw = nullptr;
-    auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, PASSES * 32) : -1; };
+    auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, n_load) : -1; };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<PASSES, false>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, PASSES * 32, get_n, qfix, &raw, red, osum, o_l, &m, &l))
+    if (!attend_block<PASSES, false>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, n_load, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
+    if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
+}
+
+// Beam search: row r of slot b's history lives in the cache of slot owner[b][r] (the beam that computed it, or the audio's pre-fill slot);
+// a new beam that continues another beam's sequence inherits that beam's owner row on the host - nothing is copied on the device
+// (openai/whisper's rearrange_kv_cache moved ~8 MB per re-parented beam and position at large-v3: 18 % of the beam pass, profiles/r03i_*).
+// One dependent load more than dec_self_attn_kernel (the owners), the same arithmetic.  No reference behaviour (there is no beam search).
+template <int PASSES>
+__global__ __launch_bounds__(256) void dec_self_attn_owner_kernel(const AttnArgs a) {
+    __shared__ float red[16], osum[256], o_l[64];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
+    const int d = a.d, H = a.n_head;
+    const int n_load = min(PASSES * 32, a.self_rows > 0 ? a.self_rows : PASSES * 32);
+    const int part = threadIdx.x & 7, kg = threadIdx.x >> 3;
+    size_t off[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int key = min(kg + 32 * i, n_load - 1);
+        const int own = min(max(a.self_owner[(size_t)b * kMaxTok + key], 0), a.batch - 1);
+        off[i] = (((size_t)own * H + h) * kMaxTok + key) * kHeadDim + part * 8;
+    }
+    uint4 kreg[PASSES], vreg[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) kreg[i] = load_kv16<false>(a.self_k + off[i]);
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) vreg[i] = load_kv16<false>(a.self_v + off[i]);
+    float qv[8];
+    attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
+    if (!(s_act && !s_done)) return;            // workgroup-uniform
+    const int n = min(min(max(s_ti, 0), kMaxTok - 1) + 1, n_load);
+    float m, l;
+    attend_compute<PASSES>(qv, kreg, vreg, n, nullptr, red, osum, o_l, &m, &l, nullptr);
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
 
@@ -325,204 +361,6 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------- persistent, software-pipelined form
-// The same work items (key split, head, slot), the same per-item arithmetic (attend_compute), the same partial slots / tickets /
-// combine - so the same bits as dec_cross_attn_kernel - but a FIXED set of workgroups (a few per CU) that claim items from a counter and
-// keep the NEXT item's K / V rows in flight while they compute the current one.
-// Why (kernel traces of three sessions in flight, profiles/r03i_*): the one-item-per-workgroup kernel needs 7 waves per SIMD and
-// ~86 MB of loads in flight to reach its rate, because a workgroup is loading for only part of its life (load -> compute -> publish
-// -> ticket).  That queue depth is also the latency every OTHER kernel's memory access pays: the projection kernels of the other
-// sessions take 22 - 28 us beside it instead of 10 - 14 us, and 69 VGPRs x 7 waves leave a SIMD no room for their 204-VGPR waves.
-// Capping the residency of the one-item kernel (3 workgroups per CU) brings them back to 13 - 18 us - and halves its own rate.  Here a
-// workgroup always has one item's loads (48 KB) in flight, two workgroups per CU cover the bandwidth-latency product, and the queue
-// stays short.
-// First form (profiles/r03l_*, r03m_*: 135 us per launch against 90): compute -> publish -> drain -> ticket -> fetch, i.e. two dependent
-// memory round trips per item with nothing else of the workgroup in flight (6.7 us per item and workgroup).  This form defers them.
-template <int PASSES>
-struct XItemRegs { uint4 k[PASSES], v[PASSES]; float q[8]; int live, ti; };
-
-template <int PASSES, bool DYNAMIC>
-__global__ __launch_bounds__(256, 2) void dec_cross_attn_persist_kernel(const AttnArgs a, const int n_items) {
-    constexpr int KPB = PASSES * 32;
-    __shared__ float red[16], osum[256], o_l[64];
-    __shared__ int last_flag, next_item;
-    const int tid = threadIdx.x;
-    const int S = a.n_split, H = a.n_head, d = a.d;
-    // claims: DYNAMIC = one counter per XCD (a single word hands out ~88 items per us: 10240 items would take longer than the kernel),
-    // workgroup w pulls from shard w % 8 (the XCD it runs on), item = claim * 8 + shard; static = items w, w + G, w + 2 G, ...
-    const int shard = blockIdx.x & 7;
-    int* const claim_cnt = a.xp_counters + 32 * shard;      // a cache line each
-    int* const exit_cnt = a.xp_counters + 32 * 8;
-    int next_static = blockIdx.x + 2 * (int)gridDim.x;
-
-    auto fetch = [&](int it, XItemRegs<PASSES>& x) {
-        const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
-        const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
-        const int bc = a.cross_div > 1 ? b / a.cross_div : b;
-        const size_t base = (((size_t)bc * H + h) * kCtx + t0) * kHeadDim;
-        attend_fetch<PASSES, true>(a.cross_k + base, a.cross_v + base, n, x.k, x.v);
-        attend_load_q(a.q + (size_t)b * d + h * kHeadDim, x.q);
-        const SeqState* sq = a.seq + b;
-        x.live = sq->active && !sq->done;
-        x.ti = sq->token_index;
-    };
-    // The publish of an item trails its compute by one iteration and its ticket by two, so that no wait is ever for something just issued:
-    // iteration i computes item n_i, then drains (what is outstanding - the rows of n_i+1, the partial of n_i-1, the ticket of n_i-2 -
-    // was issued an iteration ago), reads the ticket of n_i-2, issues the ticket of n_i-1 and the partial stores of n_i, combines
-    // n_i-2 if it arrived last, and only then requests the rows of n_i+2 into the registers n_i occupied.
-    struct Pend { int b, h, live; };
-    Pend p1{0, 0, 0}, p2{0, 0, 0};     // p1: partial stores in flight, no ticket yet; p2: ticket in flight
-    int tk1 = 0, tk2 = 0;              // thread 0: ticket values of p1 / p2
-    auto retire = [&](bool live_now, const float* o_src, float m, float l, float* mine) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            const int last = p2.live && tk2 == S - 1;
-            if (last) {
-                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(a.ticket + p2.b * H + p2.h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            }
-            last_flag = last;
-            if (p1.live) tk1 = __hip_atomic_fetch_add(a.ticket + p1.b * H + p1.h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (live_now && tid < 64) {     // the whole partial leaves from WAVE 0: the drain that precedes its ticket (thread 0, next iteration) is that wave's own
-            __hip_atomic_store(mine + 2 + tid, o_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid < 2) __hip_atomic_store(mine + tid, tid == 0 ? m : l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (last_flag) combine_splits(a, p2.b, p2.h, S);      // workgroup-uniform; one barrier inside
-        __syncthreads();                                      // last_flag / next_item / the combine's staging are rewritten by the next item
-    };
-    // one item: returns the item now loading into x (or -1)
-    auto step = [&](int it, XItemRegs<PASSES>& x) -> int {
-        const int sp = it % S, hb = it / S, h = hb % H, b = hb / H;
-        const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
-        int claim = 0;
-        if (DYNAMIC) {      // in flight under the compute; item = claim * 8 + shard
-            if (tid == 0) claim = __hip_atomic_fetch_add(claim_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + shard;
-        } else { claim = next_static; next_static += (int)gridDim.x; }
-        if (a.gate && tid == 0 && it == n_items - 1) xattn_gate_release(a.gate);
-        const bool live = x.live != 0;          // workgroup-uniform
-        float m = 0.0f, l = 0.0f;
-        if (live) {
-            float* raw = nullptr;
-            if (a.align) {
-                const int slot = a.align_slot[a.layer * H + h];
-                const int pos = min(max(x.ti, 0), kMaxTok - 1);
-                if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
-            }
-            attend_compute<PASSES>(x.q, x.k, x.v, n, raw, red, osum, o_l, &m, &l, nullptr);
-        }
-        if (DYNAMIC && tid == 0) next_item = claim < n_items ? claim : -1;     // read after retire's barrier
-        retire(live, o_l, m, l, a.part + (((size_t)b * H + h) * S + sp) * kPartStride);
-        const int nn = DYNAMIC ? next_item : (claim < n_items ? claim : -1);
-        if (nn >= 0) fetch(nn, x);
-        p2 = p1; tk2 = tk1; p1 = Pend{b, h, live ? 1 : 0};
-        return nn;
-    };
-
-    int c0 = blockIdx.x, c1 = blockIdx.x + (int)gridDim.x;
-    if (DYNAMIC) {
-        if (tid == 0) next_item = __hip_atomic_fetch_add(claim_cnt, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        c0 = next_item * 8 + shard; c1 = c0 + 8;
-        __syncthreads();
-    }
-    int itX = c0 < n_items ? c0 : -1, itY = c1 < n_items ? c1 : -1;
-    XItemRegs<PASSES> X, Y;
-    if (itX >= 0) fetch(itX, X);
-    if (itY >= 0) fetch(itY, Y);
-    for (;;) {
-        if (itX < 0) break;
-        itX = step(itX, X);
-        if (itY < 0) break;
-        itY = step(itY, Y);
-    }
-    for (int r = 0; r < 2; ++r) {       // the two items still on their way out
-        retire(false, o_l, 0.0f, 0.0f, nullptr);
-        p2 = p1; tk2 = tk1; p1 = Pend{0, 0, 0};
-    }
-    if (DYNAMIC && tid == 0) {     // the workgroup that leaves last re-arms the counters for the next launch of this session
-        const int gone = __hip_atomic_fetch_add(exit_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gone == (int)gridDim.x - 1) {
-            for (int x = 0; x < 8; ++x) __hip_atomic_store(a.xp_counters + 32 * x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(exit_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// Beam search (cross_div = beam size > 1): the beams of an audio attend over ONE cross K / V copy.  One workgroup per (key split, head,
-// AUDIO) fetches the split's K / V rows ONCE into registers and runs the query of every live beam against them, so the traffic of the
-// launch is that of `n_audio` slots, not of n_audio x beam (per-slot workgroups re-read the rows through L2 / MALL: 100 slots of 20
-// audios cost what 100 independent slots cost in request slots, large-v3: ~100 us per launch).  Per beam the arithmetic is that of
-// dec_cross_attn_kernel - same partials, same combine order, the same bits (tests/test_gpu_beam.py compares the two paths).  The
-// partials of all beams are published with ONE drain and one round of tickets.  No reference behaviour (the reference has no beam search).
-constexpr int kMaxBeamShare = 8;
-template <int PASSES>
-__global__ __launch_bounds__(256) void dec_cross_attn_beams_kernel(const AttnArgs a) {
-    constexpr int KPB = PASSES * 32;
-    __shared__ float red[16], osum[256], o_all[kMaxBeamShare][64], ml_all[kMaxBeamShare][2];
-    __shared__ int last_flags[kMaxBeamShare];
-    const int sp = blockIdx.x, h = blockIdx.y, au = blockIdx.z, NB = a.cross_div;
-    const int tid = threadIdx.x;
-    gate_release_if_mine(a);
-    const int d = a.d, S = a.n_split;
-    const int t0 = sp * KPB, n = min(KPB, kCtx - t0);
-    const size_t base = (((size_t)au * a.n_head + h) * kCtx + t0) * kHeadDim;
-    uint4 kreg[PASSES], vreg[PASSES];
-    attend_fetch<PASSES, true>(a.cross_k + base, a.cross_v + base, n, kreg, vreg);
-    int slot = -1;
-    if (a.align) slot = a.align_slot[a.layer * a.n_head + h];
-    unsigned live_mask = 0;
-    for (int j = 0; j < NB; ++j) {
-        const int b = au * NB + j;
-        if (b >= a.batch) break;
-        const SeqState* sq = a.seq + b;
-        if (!(sq->active && !sq->done)) continue;       // workgroup-uniform
-        live_mask |= 1u << j;
-        float qv[8];
-        attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
-        float* raw = nullptr;
-        const int pos = min(max(sq->token_index, 0), kMaxTok - 1);
-        if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
-        float m, l;
-        attend_compute<PASSES>(qv, kreg, vreg, n, raw, red, osum, o_all[j], &m, &l, nullptr);
-        if (tid == 0) { ml_all[j][0] = m; ml_all[j][1] = l; }
-    }
-    if (!live_mask) return;
-    __syncthreads();
-    // ---- publish every live beam's partial (write-through stores), ONE drain, one ticket per beam
-    for (int j = 0; j < NB; ++j) {
-        if (!((live_mask >> j) & 1)) continue;
-        const int b = au * NB + j;
-        float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
-        if (tid < 64) __hip_atomic_store(mine + 2 + tid, o_all[j][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 64) {
-            __hip_atomic_store(mine, ml_all[j][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mine + 1, ml_all[j][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < NB) {
-        int last = 0;
-        if ((live_mask >> tid) & 1) {
-            int* cnt = a.ticket + (au * NB + tid) * a.n_head + h;
-            const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (t == S - 1);
-            if (last) {
-                if (!a.no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            }
-        }
-        last_flags[tid] = last;
-    }
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        if (!last_flags[j]) continue;                   // workgroup-uniform
-        combine_splits(a, au * NB + j, h, S);
-        __syncthreads();                                // the combine's LDS staging is reused by the next beam
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- sampler
 constexpr int SAMP_T = 1024;
@@ -621,7 +459,10 @@ __device__ __forceinline__ void advance_decode_state(const SamplerCfg& cfg, SeqS
 }
 
 // MODE bit 0: apply filters; bit 1: sample; bit 2: advance decodeText state; bit 3: write filtered logits back
-template <int DO_FILTER, int DO_SAMPLE, int DO_ADVANCE, int WRITE_BACK>
+// TOPK > 0 (beam search, BeamSearchTokenSampler.update's device part, no reference behaviour): after the filters, the log-softmax of the
+// row and its TOPK best entries, descending, ties to the lower id (openai/whisper decoding.py:361 logprobs[idx].topk(beam_size + 1)) go to
+// logprob_out / token_out[b * kBeamTopK + k]; the row stays in registers (the two-kernel form re-read it K + 3 times through L2).
+template <int DO_FILTER, int DO_SAMPLE, int DO_ADVANCE, int WRITE_BACK, int TOPK = 0>
 __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __restrict__ cfgp, const int* __restrict__ suppress,
                                                         SeqState* __restrict__ seqs, float* __restrict__ logits_all,
                                                         int counter_override, int* __restrict__ token_out, float* __restrict__ logprob_out) {
@@ -629,7 +470,7 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
     __shared__ int sh_i[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     SeqState* sq = seqs + b;
-    if (DO_ADVANCE && !slot_live(sq)) return;
+    if ((DO_ADVANCE || TOPK) && !slot_live(sq)) return;
     const SamplerCfg cfg = *cfgp;
     const int V = cfg.n_vocab;
     float* logits = logits_all + (size_t)b * V;
@@ -702,6 +543,41 @@ __global__ __launch_bounds__(SAMP_T) void sampler_kernel(const SamplerCfg* __res
             int n = tid + SAMP_T * e;
             if (n < V) logits[n] = x[e];
         }
+    }
+    if (TOPK) {
+        const int K = min(counter_override, kBeamTopK);      // (the counter argument carries K in this mode)
+        float lm = -INFINITY;
+        int li = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < SAMP_E; ++e) {
+            const int n = tid + SAMP_T * e;
+            if (n < V && (x[e] > lm || (x[e] == lm && n < li))) { lm = x[e]; li = n; }
+        }
+        float gmax; int gidx;
+        block_argmax(lm, li, &br, &gmax, &gidx);
+        float se = 0.0f;
+#pragma unroll
+        for (int e = 0; e < SAMP_E; ++e) {
+            const int n = tid + SAMP_T * e;
+            if (n < V && x[e] != -INFINITY) se += expf(x[e] - gmax);
+        }
+        se = block_sum(se, &br);
+        const float lse = gmax + logf(se);
+        float bv = gmax; int bi = gidx;
+        unsigned long long taken = 0;                     // this thread's ids already reported (bit e)
+        for (int k = 0; k < K; ++k) {
+            if (tid == 0) { logprob_out[(size_t)b * kBeamTopK + k] = bv - lse; token_out[(size_t)b * kBeamTopK + k] = bi; }
+            if (k + 1 == K) break;
+            float m2 = -INFINITY; int i2 = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < SAMP_E; ++e) {
+                const int n = tid + SAMP_T * e;
+                if (n == bi) taken |= 1ull << e;
+                if (n < V && !((taken >> e) & 1) && (x[e] > m2 || (x[e] == m2 && n < i2))) { m2 = x[e]; i2 = n; }
+            }
+            block_argmax(m2, i2, &br, &bv, &bi);
+        }
+        return;
     }
     if (!DO_SAMPLE) return;
 
@@ -870,9 +746,22 @@ int cross_attn_splits(int batch, int n_head) {
     return (kCtx + passes * 32 - 1) / (passes * 32);
 }
 
-static void launch_self_attn(const AttnArgs& at, int passes, int H, int B, hipStream_t st) {
+static void launch_self_attn(const AttnArgs& at, int H, int B, hipStream_t st) {
     ProfScope ps_(KK_DEC_SELF_ATTN, st);
     const dim3 grid(H, B);
+    const int passes = at.self_rows > 0 ? (at.self_rows + 31) / 32 : 7;
+    if (at.self_owner) {
+        switch (passes) {
+            case 1: dec_self_attn_owner_kernel<1><<<grid, 256, 0, st>>>(at); break;
+            case 2: dec_self_attn_owner_kernel<2><<<grid, 256, 0, st>>>(at); break;
+            case 3: dec_self_attn_owner_kernel<3><<<grid, 256, 0, st>>>(at); break;
+            case 4: dec_self_attn_owner_kernel<4><<<grid, 256, 0, st>>>(at); break;
+            case 5: dec_self_attn_owner_kernel<5><<<grid, 256, 0, st>>>(at); break;
+            case 6: dec_self_attn_owner_kernel<6><<<grid, 256, 0, st>>>(at); break;
+            default: dec_self_attn_owner_kernel<7><<<grid, 256, 0, st>>>(at);
+        }
+        return;
+    }
     switch (passes) {
         case 1: dec_self_attn_kernel<1><<<grid, 256, 0, st>>>(at); break;
         case 2: dec_self_attn_kernel<2><<<grid, 256, 0, st>>>(at); break;
@@ -884,7 +773,6 @@ static void launch_self_attn(const AttnArgs& at, int passes, int H, int B, hipSt
     }
 }
 
-constexpr int kXattPersistDefault = 0;      // flipped once measured (profiles/r03l_*)
 static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStream_t st) {
     static const int nofence = env_int("WH_XATT_NOFENCE", 1);   // sc1 stores + sc1 loads need no acquire (MI355X_MICROARCH.md R1); 0 restores it (A/B)
     AttnArgs at = at_in;
@@ -898,35 +786,11 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     // non-temporal K / V loads (each row is read once per step; measured large-v3, 32 slots: 51.9 -> 49.7 us per launch, 3 sessions in
     // flight 13.4 k -> 14.2 k sequence-steps/s, profiles/r02i_*); WH_XATT_NT=0 is the A/B side
     static const int nt = env_int("WH_XATT_NT", 1);
-    // beam search: one workgroup per (split, head, AUDIO) runs all the beams' queries against one fetch; WH_XATT_BEAM_SHARED=0 (read per
-    // wh_decode_text_beam call) is the A/B side: per-slot workgroups with cacheable loads, the L2 / MALL serves the other beams of the
-    // audio - same bits either way (tests/test_gpu_beam.py)
-    if (at.beam_kernel && at.cross_div > 1 && at.cross_div <= kMaxBeamShare && B % at.cross_div == 0) {
-        const dim3 gb(S, H, B / at.cross_div);
-        at.gate_wg = std::max(0, S * H * (B / at.cross_div) - 1 - gate_lead);
-        if (S == 3) dec_cross_attn_beams_kernel<16><<<gb, 256, 0, st>>>(at);
-        else if (S == 4) dec_cross_attn_beams_kernel<12><<<gb, 256, 0, st>>>(at);
-        else if (S == 6) dec_cross_attn_beams_kernel<8><<<gb, 256, 0, st>>>(at);
-        else if (S == 8) dec_cross_attn_beams_kernel<6><<<gb, 256, 0, st>>>(at);
-        else if (S == 12) dec_cross_attn_beams_kernel<4><<<gb, 256, 0, st>>>(at);
-        else dec_cross_attn_beams_kernel<2><<<gb, 256, 0, st>>>(at);
-        return;
-    }
-    // persistent, software-pipelined form (same bits): WH_XATT_PERSIST = workgroups per CU (0 = the one-item-per-workgroup kernel);
-    // only where every workgroup gets >= 8 items - below that the launch is latency, not bandwidth (8 slots of large-v3: 1280 items)
-    static const int persist_k = env_int("WH_XATT_PERSIST", kXattPersistDefault);
-    static const int n_cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-    if (persist_k > 0 && nt && at.cross_div <= 1 && at.xp_counters && S == 8 && S * H * B >= 8 * persist_k * n_cus) {
-        static const int dyn = env_int("WH_XATT_CLAIM", 0);     // 1: items claimed from per-XCD counters; 0: static stride
-        if (dyn) dec_cross_attn_persist_kernel<6, true><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
-        else dec_cross_attn_persist_kernel<6, false><<<persist_k * n_cus, 256, 0, st>>>(at, S * H * B);
-        return;
-    }
-    if (nt && at.cross_div <= 1) {      // shared K / V without the beam kernel: cacheable loads
+    if (nt && at.cross_div <= 1) {      // (cross_div > 1, beam search: cacheable loads below - the L2 of the XCD serves the other beams of the audio)
         if (S == 3) dec_cross_attn_kernel<16, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 4) dec_cross_attn_kernel<12, true><<<grid, 256, xlds, st>>>(at);
         else if (S == 6) dec_cross_attn_kernel<8, true><<<grid, 256, xlds, st>>>(at);
-        else if (S == 8) dec_cross_attn_kernel<6, true><<<grid, 256, xlds, st>>>(at);
+        else if (S == 8) dec_cross_attn_kernel<6, true><<<grid, 256, xlds, st>>>(at);      // (held to 64 registers = 8 waves per SIMD: 2 % slower, profiles/r03p_*)
         else if (S == 12) dec_cross_attn_kernel<4, true><<<grid, 256, xlds, st>>>(at);
         else dec_cross_attn_kernel<2, true><<<grid, 256, xlds, st>>>(at);
         return;
@@ -961,12 +825,13 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a.self_k = db.self_k + (size_t)l * self_stride; a.self_v = db.self_v + (size_t)l * self_stride; a.prof_kind = KK_DEC_QKV;
         launch_dec32_proj(P32_QKV, a, n_bt, st);
         AttnArgs at{};
-        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div; at.beam_kernel = db.cross_beam_kernel;
+        at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div;
         at.self_k = a.self_k; at.self_v = a.self_v;
         at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
-        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate; at.xp_counters = db.ticket + (size_t)db.max_batch * H;
-        launch_self_attn(at, db.self_passes, H, B, st);
+        at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate;
+        at.self_rows = db.self_rows; at.self_owner = db.self_owner;
+        launch_self_attn(at, H, B, st);
         a = base;               // x += W_o att + b_o; planes gamma_2 x, statistics for LN2
         a.N = d; a.K = d; a.Wt = t.o_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.o_b; a.gamma_next = w.ln2_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
@@ -1012,68 +877,11 @@ void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits,
     sampler_kernel<0, 1, 0, 0><<<1, SAMP_T, 0, st>>>(cfg_dev, nullptr, seq, logits, counter, token_out, logprob_out);
 }
 
-void launch_filter_batch(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, hipStream_t st) {
-    sampler_kernel<1, 0, 0, 1><<<batch, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, seq, logits, 0, nullptr, nullptr);
-}
 
 // ---------------------------------------------------------------------------------------------- beam search support
-// BeamSearchTokenSampler.update, device part: log-softmax of a slot's FILTERED logits and its K best entries, descending, ties to the
-// lower token id (openai/whisper decoding.py:361 logprobs[idx].topk(beam_size + 1)).  One workgroup per slot; the row (200 KB) is
-// re-read from L2 for each of the K + 2 passes.  The reference's sampler of this name is fatalError: no reference behaviour.
-__global__ __launch_bounds__(SAMP_T) void beam_topk_kernel(const float* __restrict__ logits_all, const SeqState* __restrict__ seqs, int V, int K,
-                                                           float* __restrict__ lp_out, int* __restrict__ tok_out) {
-    __shared__ BlockRed br;
-    __shared__ int taken[kBeamTopK];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (!slot_live(seqs + b)) return;
-    const float* x = logits_all + (size_t)b * V;
-    float mx = -INFINITY;
-    for (int n = tid; n < V; n += SAMP_T) mx = fmaxf(mx, x[n]);
-    mx = block_max(mx, &br);
-    float se = 0.0f;
-    for (int n = tid; n < V; n += SAMP_T) { const float v = x[n]; if (v != -INFINITY) se += expf(v - mx); }
-    se = block_sum(se, &br);
-    const float lse = mx + logf(se);
-    for (int k = 0; k < K; ++k) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int n = tid; n < V; n += SAMP_T) {
-            bool skip = false;
-            for (int j = 0; j < k; ++j) skip |= taken[j] == n;
-            if (skip) continue;
-            const float v = x[n];
-            if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
-        }
-        float rv; int ri;
-        block_argmax(bv, bi, &br, &rv, &ri);
-        if (tid == 0) {
-            taken[k] = ri;
-            lp_out[(size_t)b * kBeamTopK + k] = rv - lse;
-            tok_out[(size_t)b * kBeamTopK + k] = ri;
-        }
-        __syncthreads();
-    }
-}
-void launch_beam_topk(const float* logits, const SeqState* seq, int batch, int V, int K, float* lp_out, int* tok_out, hipStream_t st) {
-    beam_topk_kernel<<<batch, SAMP_T, 0, st>>>(logits, seq, V, K, lp_out, tok_out);
-}
-
-// Slot-to-slot copies inside a [layers][max_batch][segments][seg_stride] f16 buffer (self / cross K and V): pair p copies the first
-// seg_copy halves of every segment of slot pairs[2p] of `src` to slot pairs[2p+1] of `dst`.  Beam search: replication of an audio's
-// cross K/V and pre-filled cache into its beam slots, and the per-step cache rearrangement (openai rearrange_kv_cache) through a
-// scratch buffer (src != dst), so no pair reads a slot another pair writes.
-__global__ __launch_bounds__(256) void copy_slots_kernel(const f16* __restrict__ src, f16* __restrict__ dst, size_t layer_stride, size_t slot_stride,
-                                                         int n_seg, int seg_stride, int seg_copy, const int* __restrict__ pairs) {
-    const int p = blockIdx.x, seg = blockIdx.y, l = blockIdx.z;
-    const int from = pairs[2 * p], to = pairs[2 * p + 1];
-    const uint4* s4 = reinterpret_cast<const uint4*>(src + (size_t)l * layer_stride + (size_t)from * slot_stride + (size_t)seg * seg_stride);
-    uint4* d4 = reinterpret_cast<uint4*>(dst + (size_t)l * layer_stride + (size_t)to * slot_stride + (size_t)seg * seg_stride);
-    for (int i = threadIdx.x; i < seg_copy / 8; i += 256) d4[i] = s4[i];
-}
-void launch_copy_slots(const f16* src, f16* dst, int n_layer, size_t layer_stride, size_t slot_stride, int n_seg, int seg_stride, int seg_copy,
-                       const int* pairs_dev, int n_pairs, hipStream_t st) {
-    if (n_pairs <= 0 || seg_copy <= 0) return;
-    copy_slots_kernel<<<dim3(n_pairs, n_seg, n_layer), 256, 0, st>>>(src, dst, layer_stride, slot_stride, n_seg, seg_stride, seg_copy, pairs_dev);
+void launch_beam_filter_topk(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int K, float* lp_out,
+                             int* tok_out, hipStream_t st) {
+    sampler_kernel<1, 0, 0, 0, 1><<<batch, SAMP_T, 0, st>>>(cfg_dev, suppress_dev, seq, logits, K, tok_out, lp_out);
 }
 
 void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st) {

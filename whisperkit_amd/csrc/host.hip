@@ -263,10 +263,10 @@ static bool use_graphs() {
 // Step graphs live in the session (a session is driven by one host thread at a time): no process-wide cache, no lock.
 // `first_step`: token_index of the live slots at the graph's first step (decodeText starts every slot at 0 and advances them in
 // lock step): the graph's self-attention launches fetch only the cache rows its 8 steps can reach, so there is one graph per
-// 32-position band (7 per key at most).
+// 8 positions (28 per key at most).
 static int get_step_graph(wh_session* s, int batch, int first_step, hipGraphExec_t* out) {
     DecodeBuffers db = whi::decode_buffers(s, batch, first_step + kStepsPerGraph - 1);
-    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_passes, db.xattn_gate ? 1 : 0};
+    const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_rows, db.xattn_gate ? 1 : 0};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WH_OK; }
     hipGraph_t graph;

@@ -52,9 +52,9 @@ struct wh_model {
 
 // step graphs are keyed by everything their captured launches bake in
 struct WhGraphKey {
-    int batch, align, fused, n_align, self_passes, gate;
+    int batch, align, fused, n_align, self_rows, gate;
     bool operator<(const WhGraphKey& o) const {
-        return std::tie(batch, align, fused, n_align, self_passes, gate) < std::tie(o.batch, o.align, o.fused, o.n_align, o.self_passes, o.gate);
+        return std::tie(batch, align, fused, n_align, self_rows, gate) < std::tie(o.batch, o.align, o.fused, o.n_align, o.self_rows, o.gate);
     }
 };
 
@@ -88,9 +88,8 @@ struct wh_session {
     bool fused_greedy = false;
     int *tok_out_dev = nullptr; float* lp_out_dev = nullptr;
     float* scratch_logits = nullptr;       // [V] for the filter / sample KAT entry points
-    // beam search (wh_decode_text_beam, allocated on first use): scratch self K/V for the cache rearrangement, slot pairs, top-k outputs
-    f16 *beam_k = nullptr, *beam_v = nullptr;
-    int *beam_pairs = nullptr, *beam_tok = nullptr; float* beam_lp = nullptr;
+    // beam search (wh_decode_text_beam, allocated on first use): row -> owning slot table of the self-attention cache, top-k outputs
+    int *beam_owner = nullptr, *beam_tok = nullptr; float* beam_lp = nullptr;
     hipEvent_t ev[8]{};
     bool align_enabled = false;
     wh_timings last_timings{};

@@ -178,9 +178,11 @@ struct DecodeBuffers {
     int n_align;
     SeqState* seq;           // [B]
     int cross_div;           // > 1: slot b reads the cross K / V of slot b / cross_div (beam search: the beams of an audio share ONE copy)
-    int cross_beam_kernel;   // cross_div > 1: the beams of an audio are served by ONE workgroup per (split, head) - one K / V fetch for all of them
     int* xattn_gate;         // null, or the model's cross-attention gate word (dec_shared.h): concurrent sessions take turns at the HBM
-    int self_passes;         // self-attention fetch bound: ceil((largest live token_index + 1) / 32), 1..7 (0 = 7: the whole cache)
+    int self_rows;           // self-attention fetch bound: 1 + the largest token_index a live slot can have in these launches (1..224);
+                             // the kernel instantiation covers ceil(self_rows / 32) passes of 32 rows
+    const int* self_owner;   // null, or [Bmax][224]: the slot whose cache holds row r of slot b's history (beam search: a beam that
+                             // continues another beam's sequence reads that beam's rows in place - no cache rearrangement copies)
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
 };
 constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
@@ -251,11 +253,10 @@ void launch_filter_only(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqS
 void launch_sample_only(const SamplerCfg* cfg_dev, SeqState* seq, float* logits, int n_vocab, int counter, int* token_out, float* logprob_out, hipStream_t st);
 // filter + sample without advancing the decode state (detectLanguage)
 void launch_filter_sample(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int* token_out, float* logprob_out, hipStream_t st);
-void launch_filter_batch(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, hipStream_t st);
 constexpr int kBeamTopK = 16;   // row stride of the top-k outputs: beam sizes up to 15 (topk(beam_size + 1))
-void launch_beam_topk(const float* logits, const SeqState* seq, int batch, int V, int K, float* lp_out, int* tok_out, hipStream_t st);
-void launch_copy_slots(const f16* src, f16* dst, int n_layer, size_t layer_stride, size_t slot_stride, int n_seg, int seg_stride, int seg_copy,
-                       const int* pairs_dev, int n_pairs, hipStream_t st);
+// beam search: the LogitsFiltering rules, log-softmax and the K best entries of every live slot's row in one pass (row in registers)
+void launch_beam_filter_topk(const SamplerCfg* cfg_dev, const int* suppress_dev, SeqState* seq, float* logits, int batch, int K, float* lp_out,
+                             int* tok_out, hipStream_t st);
 // mean over alignment heads -> [B][224][1500]
 void launch_alignment_mean(const float* align, int batch, int n_align, float* out, hipStream_t st);
 // openai/whisper-style alignment post-processing of one slot (z-normalise over the token rows, median filter, head mean)

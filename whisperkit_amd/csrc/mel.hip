@@ -9,8 +9,9 @@
 //     Re X[k] = sum_{n=1..200} (x[n] + x[400-n]) * w[n] cos(2 pi n k / 400)      (x[200] counted once)
 //     Im X[k] = sum_{n=1..199} (x[n] - x[400-n]) * w[n] sin(2 pi n k / 400)
 // (the periodic Hann window is symmetric about n = 200 and w[0] = 0, so the window folds into the
-// basis and the even/odd fold halves the MFMA work).  The folded frames live in LDS (bank-conflict-free
-// stride 202), the windowed basis (2 x 200 x 208 f32 = 333 KB) streams from L2.  Power -> LDS ->
+// basis and the even/odd fold halves the MFMA work).  The signal under the 64 frames (10480 samples) sits in LDS
+// once, skewed for conflict-free fragment reads, and is folded on the fly; the windowed basis
+// (2 x 200 x 208 f32 = 333 KB) streams from L2.  Power -> LDS ->
 // sparse triangular mel filters -> log10 -> f32 scratch [n_mels][3000] + per-chunk atomic max.
 // Kernel 2 (mel_finalize_kernel): clamp to max-8, scale, emit the time-major f16 [3002][n_mels]
 // operand of the conv1 GEMM (and the reference-layout f32 [n_mels][3000] copy for the C ABI).
@@ -19,18 +20,13 @@
 
 namespace wh {
 
-constexpr int LDA = 202;   // folded-frame row stride (floats): 202 % 32 = 10 -> conflict-free MFMA A reads
 constexpr int LDP = 209;   // power row stride
 
-__device__ __forceinline__ float load_padded(const float* __restrict__ pcm, int n_valid, int j) {
-    // index into the reflect-padded, zero-extended 480000-sample window
-    int p = j - kNFFT / 2;
-    if (p < 0) p = -p;
-    if (p >= kWindowSamples) p = 2 * (kWindowSamples - 1) - p;
-    return p < n_valid ? pcm[p] : 0.0f;
-}
-
 constexpr int FG = 4;      // 16-frame groups per workgroup: every basis fragment fetched from L2 feeds FG MFMAs
+constexpr int kSpan = (16 * FG - 1) * kHop + kNFFT;    // 10480 samples: the reflect-padded signal under a workgroup's 64 frames
+// sample j of the span sits at j + 2 (j / 160): frame i's sample n at i * 162 + n + 2 (n / 160), so the 16 frames an MFMA A-fragment
+// read touches (same n, lanes ai = 0..15, k slots ak, ak + 1) fall on banks 2 ai + ak: conflict-free ds_read_b32
+constexpr int kSpanLds = kSpan + 2 * (kSpan / kHop) + 2;
 
 __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ pcm_all, const int* __restrict__ n_valid_all,
                                                         const float* __restrict__ basis_c, const float* __restrict__ basis_s,
@@ -38,9 +34,8 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
                                                         const int2* __restrict__ filt_range,
                                                         int n_mels, float* __restrict__ logspec, unsigned* __restrict__ maxkey) {
     extern __shared__ __attribute__((aligned(16))) float mel_smem[];
-    float* fe = mel_smem;                        // [FG*16][LDA] even folds
-    float* fo = fe + FG * 16 * LDA;              // [FG*16][LDA] odd folds
-    float* pw = fo + FG * 16 * LDA;              // [16][LDP]    power of one frame group at a time
+    float* xs = mel_smem;                        // [kSpanLds]  the signal under the 64 frames (skewed, see above)
+    float* pw = xs + kSpanLds;                   // [16][LDP]   power of one frame group at a time
     __shared__ float red[4];
     __shared__ float fc_l[1024];                 // compact mel filter weights (a global-memory filter loop is a chain of
     __shared__ int2 rg_l[128];                   // dependent L2 round trips: it was the whole kernel time)
@@ -53,16 +48,26 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
     const float* pcm = pcm_all + (size_t)b * kWindowSamples;
     const int n_valid = n_valid_all[b];
 
-    // fold the 64 frames: fe[i][m] = x[n] + x[400-n], fo[i][m] = x[n] - x[400-n], n = m + 1
-    for (int idx = tid; idx < FG * 16 * 200; idx += 256) {
-        int i = idx / 200, m = idx - i * 200;
-        int n = m + 1;
-        int base = (f0 + i) * kHop;
-        float x1 = load_padded(pcm, n_valid, base + n);
-        float x2 = load_padded(pcm, n_valid, base + kNFFT - n);
-        bool mid = (n == 200);
-        fe[i * LDA + m] = mid ? x1 : x1 + x2;
-        fo[i * LDA + m] = mid ? 0.0f : x1 - x2;
+    // The span in ONE round of independent, coalesced loads (round 2 folded x[n] +- x[400 - n] into two LDS images with two dependent
+    // global loads per element: 50 latency-bound iterations per thread, 1.09 ms per 64 chunks = 0.2 TB/s; and 117 KB of LDS = one
+    // workgroup per CU).  Index of span sample j in the window: reflect padding at both ends, zeros past n_valid (padOrTrim).
+    {
+        constexpr int NLD = (kSpan + 255) / 256;
+        float v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            int p = f0 * kHop + tid + 256 * u - kNFFT / 2;
+            if (p < 0) p = -p;
+            if (p >= kWindowSamples) p = 2 * (kWindowSamples - 1) - p;
+            p = min(max(p, 0), kWindowSamples - 1);                      // (only the unused tail of the last span gets here)
+            const float x = pcm[p];
+            v[u] = p < n_valid ? x : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int j = tid + 256 * u;
+            if (j < kSpan) xs[j + 2 * (j / kHop)] = v[u];
+        }
     }
     __syncthreads();
 
@@ -75,10 +80,19 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict_
     // wave w owns bin tiles w, w+4, w+8, w+12 (13 tiles of 16 bins)
 #pragma unroll 2
     for (int ks = 0; ks < 50; ++ks) {
-        int k = ks * 4 + ak;
+        const int k = ks * 4 + ak, n = k + 1;
+        // fold on the fly: a_e = x[n] + x[400 - n], a_o = x[n] - x[400 - n] (x[200] counted once) - the same two LDS reads per
+        // operand pair the folded images cost, the same values
+        const int o1 = n + 2 * (n >= kHop), o2 = (kNFFT - n) + 2 * (1 + ((kNFFT - n) >= 2 * kHop));
+        const bool mid = n == kNFFT / 2;
         float a_e[FG], a_o[FG];
 #pragma unroll
-        for (int g = 0; g < FG; ++g) { a_e[g] = fe[(g * 16 + ai) * LDA + k]; a_o[g] = fo[(g * 16 + ai) * LDA + k]; }
+        for (int g = 0; g < FG; ++g) {
+            const int rowoff = (g * 16 + ai) * (kHop + 2);
+            const float x1 = xs[rowoff + o1], x2 = xs[rowoff + o2];
+            a_e[g] = mid ? x1 : x1 + x2;
+            a_o[g] = mid ? 0.0f : x1 - x2;
+        }
         const float* bc = basis_c + (size_t)k * kBinsPad + ai;
         const float* bs = basis_s + (size_t)k * kBinsPad + ai;
 #pragma unroll
@@ -176,7 +190,7 @@ void launch_log_mel(const MelTables& t, const float* pcm, const int* n_valid, in
                     f16* mel_t, float* mel_f32, hipStream_t st) {
     hipMemsetAsync(maxkey, 0, sizeof(unsigned) * batch, st);
     dim3 g1((kFrames + 16 * FG - 1) / (16 * FG), batch);
-    const size_t smem1 = (size_t)(2 * FG * 16 * LDA + 16 * LDP) * sizeof(float);   // 116.8 KB
+    const size_t smem1 = (size_t)(kSpanLds + 16 * LDP) * sizeof(float);   // 55.8 KB: two workgroups per CU
     static PerDeviceOnce raised;
     raised.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1); });
     { ProfScope ps_(KK_MEL_POWER, st); mel_power_kernel<<<g1, 256, smem1, st>>>(pcm, n_valid, t.basis_c, t.basis_s, t.filt_c, t.filt_off, t.filt_nnz, t.filt_range, t.n_mels, logspec, maxkey); }
