@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
 T_START = time.perf_counter()
 
 
@@ -508,6 +508,8 @@ def main():
         o = run_config(args, "large-v3", 64, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
         args.sample_length = saved
         other["whisper-large-v3, 64 chunks per step, 3 in flight, 64-token run (sampleLength 64, SURVEY 8d)"] = brief(o, 6)
+        o = run_config(args, "large-v3", 128, 3, 3, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        other["whisper-large-v3, 128 chunks per step (four decoder batch tiles per session), 3 in flight = 384 chunks resident, greedy, 1 GPU"] = brief(o, 3)
         other["configs[4] whisper-large-v3, 10 min audio in 30 s VAD chunks, temperature ladder forced once, 1 GPU"] = long_audio_config(args, local_rank)
         _MODELS.pop("large-v3")[0].close()
     if extra and (args.model, args.batch) != ("tiny.en", 1):
