@@ -342,11 +342,12 @@ int wh_beam_sampler_finalize(wh_beam_sampler* h, int n_beams, int len, const int
                              const float* sums, int sample_begin, int capacity, int32_t* best_tokens, float* best_token_logprobs,
                              int32_t* best_len, float* best_sum, int32_t* n_finished);
 /* decodeText at temperature 0 with that sampler, for n_audio windows whose decoder inputs were prepared in slots
- * [0, n_audio) (wh_prepare_decoder_inputs): the prompt is pre-filled exactly like wh_decode_text, every audio's cross K/V and
- * cache are then copied into its beam_size slots (audio a -> slots a * beam_size ...; n_audio * beam_size <= max_batch, and the
- * slots' previous decoder inputs are overwritten - prepare them again before another decode), and every position expands the
- * beams: decoder step, the LogitsFilters of opt per beam, log-softmax + top (beam_size + 1) on the device, candidate ranking on
- * the host, cache rearrangement.  language_tokens: per audio or NULL, as in wh_decode_text_languages.  Results follow the
+ * [0, n_audio) (wh_prepare_decoder_inputs): the prompt is pre-filled exactly like wh_decode_text; audio a then owns the slots
+ * a * beam_size ... (n_audio * beam_size <= max_batch; nothing is copied: its beams read the audio's one cross K/V and each
+ * other's self-attention rows in place, but the slots' self-attention caches are overwritten - prepare the decoder inputs again
+ * before another decode), and every position expands the beams: decoder step, the LogitsFilters of opt per beam + log-softmax +
+ * top (beam_size + 1) on the device, candidate ranking on the host (the cache "rearrangement" is a row -> owner table).
+ * language_tokens: per audio or NULL, as in wh_decode_text_languages.  Results follow the
  * DecodingResult conventions of wh_decode_text (temperature 0); word timestamps are not recorded along beams. */
 int wh_decode_text_beam(wh_session* s, int n_audio, int beam_size, float patience, const wh_decoding_options* opt,
                         const wh_special_tokens* st, const int32_t* prompt, int n_prompt, const int32_t* language_tokens,
