@@ -28,7 +28,9 @@ constexpr int kSpan = (16 * FG - 1) * kHop + kNFFT;    // 10480 samples: the ref
 // read touches (same n, lanes ai = 0..15, k slots ak, ak + 1) fall on banks 2 ai + ak: conflict-free ds_read_b32
 constexpr int kSpanLds = kSpan + 2 * (kSpan / kHop) + 2;
 
-__global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ pcm_all, const int* __restrict__ n_valid_all,
+// __launch_bounds__(256, 2): two workgroups per CU (the LDS allows it since round 3) = at most 256 registers per wave, which keeps the 128
+// accumulator registers in arch VGPRs (865 -> 634 us per 64 chunks; unrolling the k loop 5 / 10 deep instead of 2 is slower: profiles/r03r_*)
+__global__ __launch_bounds__(256, 2) void mel_power_kernel(const float* __restrict__ pcm_all, const int* __restrict__ n_valid_all,
                                                         const float* __restrict__ basis_c, const float* __restrict__ basis_s,
                                                         const float* __restrict__ filt_c, const int* __restrict__ filt_off, int filt_nnz,
                                                         const int2* __restrict__ filt_range,
