@@ -435,10 +435,11 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
 template <int MODE, bool HILO>
 static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
+    static const int tc_cap = env_int32("WH_D32_TC", 5);     // A/B knob: smaller chunks = fewer registers (TC 2: ~100) = room beside a cross-attention wave
     // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
-    if (tw % 5 == 0) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
-    else if (tw % 4 == 0) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
-    else if (tw % 3 == 0) dec32_proj_kernel<MODE, HILO, 3><<<grid, 256, 0, st>>>(a);
+    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
+    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3><<<grid, 256, 0, st>>>(a);
     else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
     else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
 }
