@@ -136,8 +136,8 @@ __device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, floa
     float4 q1 = *reinterpret_cast<const float4*>(qg + part * 8 + 4);
     qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
 }
-// attend_compute: the fetched rows against ONE query; n of them count.  The K / V registers survive (rows past n are zeroed, which is
-// the same for every query), so the beam-search kernel runs several queries against one fetch.
+// attend_compute: the fetched rows against ONE query; n of them count (rows past n: score -inf, V zeroed - they may be clamped re-reads
+// or, in the self-attention cache, rows no step has written yet).  Shared by the self- and cross-attention kernels.
 template <int PASSES>
 __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES], int n, float* raw_scores,
                                                float* red /* [16] */, float* osum /* [4][64] */, float* o_out /* [64] */, float* m_out, float* l_out,
