@@ -360,9 +360,6 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     ATT_STAMP(5);
 }
 
-
-
-
 // ---------------------------------------------------------------------------------------------- sampler
 constexpr int SAMP_T = 1024;
 constexpr int SAMP_E = 51;   // ceil(51866 / 1024)
