@@ -1,6 +1,6 @@
 """The multi-GPU step of the path behind the C ABI (wh_comm_*, include/whisperhip.h "multi-GPU"): chunk partition,
 all-gather of fixed-size chunk records, gather + merge of whole TranscriptionResults - the reference's TaskGroup fan-out and in-process
-merge (Core/WhisperKit.swift:735-812, Utilities/TranscriptionUtilities.swift:76-157).  CPU only: world sizes 2 and 3 over the library's
+merge (Core/WhisperKit.swift:735-812, Utilities/TranscriptionUtilities.swift:76-157).  CPU only: world sizes 2, 3 and 8 (configs[3]: 64 chunks over 8 ranks) over the library's
 TCP transport, one process per rank, NO torch.distributed anywhere (a Swift / C host has none either).  The RCCL transport of the same
 entry points runs in the -m gpu tests (tests/test_gpu_round3.py) and under bench.py --gpus N."""
 import multiprocessing as mp
@@ -73,7 +73,7 @@ def _records_worker(rank, world, port, n_chunks, q):
     c.close()
 
 
-@pytest.mark.parametrize("world,n_chunks", [(2, 5), (3, 7), (2, 1)])
+@pytest.mark.parametrize("world,n_chunks", [(2, 5), (3, 7), (2, 1), (8, 64)])      # (8, 64): BASELINE configs[3], 64 chunks over 8 ranks
 def test_gather_records_over_the_c_abi(world, n_chunks):
     port = _free_port()
     ctx = mp.get_context("spawn")
