@@ -53,7 +53,10 @@ def log(msg):
     print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: bool = True):
+XABS_SPLITS = 4      # csrc/kernels.h kXabsSplits
+
+
+def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: bool = True, absorbed: bool = False):
     """(bound, amount) one launch of each kernel kind must do: HBM bytes for the bandwidth-bound kernels, FLOPs for the
     MFMA-bound ones.  fp16 weights / KV / GEMM operands, fp32 residuals; decoder
     activations travel as f16 hi|lo plane pairs (4 B per element)."""
@@ -91,8 +94,16 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
         return "hbm", d * d * 2 + 4 * act
     if kind == "dec_proj_cq":    # W[d][d] + planes in, q out
         return "hbm", d * d * 2 + 2 * act
+    if kind == "dec_cross_attn" and absorbed:
+        # weight-absorbed form (csrc/xabs.hip): the slot's encoder output [1500][d] f16 ONCE, absorbed queries (f16 hi | lo) in,
+        # every key split's unnormalised O' [H][d] f32 + (m, l) out
+        return "hbm", B * T * d * 2 + B * H * d * 4 + XABS_SPLITS * B * H * (d * 4 + 8)
     if kind == "dec_cross_attn":  # 1500 K and V rows per slot, q in, att planes out
         return "hbm", B * 2 * T * d * 2 + 2 * act
+    if kind == "dec_xabs_qk":    # W_k^T tiles + q in, absorbed queries [H][d] per slot (f16 hi | lo) out
+        return "hbm", d * d * 2 + act + B * H * d * 4
+    if kind == "dec_xabs_vup":   # W_v tiles + the split partials in, att planes out
+        return "hbm", d * d * 2 + XABS_SPLITS * B * H * (d * 4 + 8) + act
     if kind == "dec_proj_fc1":   # W[4d][d] + planes in, hidden hi|lo plane pair out
         return "hbm", 4 * d * d * 2 + act + B * 4 * d * 4
     if kind == "dec_proj_fc2":   # W[d][4d] + hidden plane pair in, x read + written, planes out

@@ -121,6 +121,8 @@ SYMBOLS = {
     "wh_session_create": (I, [VP, I, PVP]),
     "wh_session_destroy": (None, [VP]),
     "wh_session_max_batch": (I, [VP]),
+    "wh_session_cross_attention_mode": (I, [VP]),
+    "wh_debug_peek": (I, [VP, C.c_char_p, VP, C.c_size_t]),
     "wh_session_synchronize": (I, [VP]),
     "wh_session_stream": (VP, [VP]),
     "wh_set_audio": (I, [VP, I, VP, I]),

@@ -197,6 +197,30 @@ static int build_dec32(wh_model* m) {
     return WH_OK;
 }
 
+// Absorbed cross-attention weights (xabs.hip): per layer W_k^T as A-fragment tiles of the Q' projection and W_v in the decoder
+// projection tiling; b_v stays where it is in the blob.
+static int build_xabs(wh_model* m) {
+    const wh_dims& D = m->dims;
+    const size_t d = D.n_text_state, L = D.n_text_layer, H = D.n_text_head;
+    if (!xabs_supported((int)d, (int)H)) return WH_OK;
+    const size_t bytes = L * (2 * d * d * 2 + 2 * 256);
+    hipError_t e = hipMalloc(&m->xabs_blob, bytes);
+    if (e != hipSuccess) return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the absorbed cross-attention weights failed: %s", bytes, hipGetErrorString(e));
+    Carver c; c.base = (char*)m->xabs_blob;
+    m->xabs.resize(L);
+    hipStream_t st = nullptr;
+    for (size_t l = 0; l < L; ++l) {
+        const f16* wk = m->ckv_w + (l * 2 * d) * d;
+        const f16* wv = m->ckv_w + (l * 2 * d + d) * d;
+        f16* p = c.take<f16>(d * d); xabs_tile_wk(wk, (int)d, (int)H, p, st); m->xabs[l].wkT = p;
+        p = c.take<f16>(d * d); dec32_tile_weights(wv, (int)d, (int)d, p, st); m->xabs[l].wv_t = p;
+        m->xabs[l].bv = m->ckv_b + l * 2 * d + d;
+    }
+    WH_CHECK_LAUNCH();
+    WH_HIP(hipDeviceSynchronize());
+    return WH_OK;
+}
+
 static int set_alignment_heads(wh_model* m, const int32_t* pairs, int n) {
     const int L = m->dims.n_text_layer, H = m->dims.n_text_head;
     std::vector<int> slot(L * H, -1);
@@ -266,6 +290,7 @@ static int model_create_impl(const void* blob, size_t nbytes, int device, wh_mod
     int r = bind_weights(m);
     if (!r) r = build_mel_tables(m);
     if (!r) r = build_dec32(m);
+    if (!r) r = build_xabs(m);
     if (!r) {
         std::vector<int32_t> pairs;
         auto ah = m->t.find("dec.alignment_heads");      // optional int32 [n][2] written by checkpoint conversion (generation_config.alignment_heads)
@@ -310,6 +335,7 @@ extern "C" void wh_model_destroy(wh_model* m) {
     if (!m) return;
     if (m->blob_dev) hipFree(m->blob_dev);
     if (m->dec32_blob) hipFree(m->dec32_blob);
+    if (m->xabs_blob) hipFree(m->xabs_blob);
     if (m->mel_tables_dev) hipFree(m->mel_tables_dev);
     if (m->align_slot_dev) hipFree(m->align_slot_dev);
     if (m->xattn_gate) hipFree(m->xattn_gate);
@@ -377,18 +403,41 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     if (max_batch < 1 || max_batch > 128) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 128]", max_batch);
     WH_HIP(hipSetDevice(m->device));
     wh_session* s = new wh_session();
-    s->m = m; s->B = max_batch;
-    m->n_sessions.fetch_add(1);
+    s->B = max_batch;
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.n_audio_state, L = D.n_text_layer, V = D.n_vocab, H = D.n_text_head;
     if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
+    s->m = m;                       // from here on wh_session_destroy undoes the count
+    m->n_sessions.fetch_add(1);
     DALLOC(s->pcm, B * kWindowSamples); DALLOC(s->n_valid, B);
     DALLOC(s->logspec, B * D.n_mels * kFrames); DALLOC(s->maxkey, B);
     DALLOC(s->mel_t, B * kFramesPad * D.n_mels); DALLOC(s->mel_f32, B * D.n_mels * kFrames);
     DALLOC(s->h1, B * kFramesPad * d); DALLOC(s->x, B * kCtx * d); DALLOC(s->xn, B * kCtx * d);
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
-    DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d); DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
+    // Cross-attention path, fixed per session: the absorbed form (xabs.hip) streams the encoder output instead of per-layer K / V rows;
+    // it pays from about 16 slots (three launches per layer instead of one).  WH_XABS=0 / 1 forces the choice (A/B, tests).
+    {
+        const char* e_ = getenv("WH_XABS");       // read per session: a process can hold sessions of both modes (tests, A/B)
+        const int xabs_mode = e_ ? atoi(e_) : -1;
+        s->use_xabs = !m->xabs.empty() && (xabs_mode < 0 ? max_batch >= 16 : xabs_mode != 0);
+    }
+    if (s->use_xabs) {
+        const size_t nht = H > 16 ? 2 : 1, S = kXabsSplits;
+        const size_t bytes = 2 * (B * nht * (d / 32) * 1024) + S * H * (d / 8) * B * 32 + S * H * B * 8 + 4 * 256;
+        if (hipMalloc(&s->xabs_blob, bytes) != hipSuccess || hipMemset(s->xabs_blob, 0, bytes) != hipSuccess) {
+            wh_session_destroy(s);
+            return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the absorbed cross-attention buffers failed", bytes);
+        }
+        Carver c; c.base = (char*)s->xabs_blob;
+        s->xabs.layers_host = m->xabs.data();
+        s->xabs.qf_hi = c.take<f16>(B * nht * (d / 32) * 512); s->xabs.qf_lo = c.take<f16>(B * nht * (d / 32) * 512);
+        s->xabs.part = c.take<float>(S * H * (d / 8) * B * 8);
+        s->xabs.ml = c.take<float2>(S * H * B);
+    } else {
+        DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d);
+    }
+    DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
     DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
     DALLOC(s->logits, B * V);
     DALLOC(s->align_mean, B * kMaxTok * kCtx);
@@ -427,6 +476,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->st) hipStreamSynchronize(s->st);
     whi::drop_session_graphs(s);
     if (s->d32_blob) hipFree(s->d32_blob);
+    if (s->xabs_blob) hipFree(s->xabs_blob);
     if (s->align_tmp) hipFree(s->align_tmp);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
                     s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
@@ -439,6 +489,24 @@ extern "C" void wh_session_destroy(wh_session* s) {
     delete s;
 }
 extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1; }
+extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ? (s->use_xabs ? 1 : 0) : -1; }
+// Development aid: copy the first `nbytes` of a named decode-step buffer to the host (after the session's stream has drained).
+extern "C" int wh_debug_peek(wh_session* s, const char* name, void* out, size_t nbytes) {
+    CHECK_SESSION(s);
+    if (!name || !out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_debug_peek: null argument");
+    const std::string n(name);
+    const void* src = nullptr;
+    if (n == "x") src = s->d32.x; else if (n == "q") src = s->d32.q;
+    else if (n == "za_hi") src = s->d32.za_hi; else if (n == "za_lo") src = s->d32.za_lo;
+    else if (n == "zb_hi") src = s->d32.zb_hi; else if (n == "zb_lo") src = s->d32.zb_lo;
+    else if (n == "qf_hi") src = s->xabs.qf_hi; else if (n == "qf_lo") src = s->xabs.qf_lo;
+    else if (n == "part") src = s->xabs.part; else if (n == "ml") src = s->xabs.ml;
+    else if (n == "enc16") src = s->enc16;
+    if (!src) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_debug_peek: no buffer named '%s' in this session", name);
+    WH_HIP(hipStreamSynchronize(s->st));
+    WH_HIP(hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost));
+    return WH_OK;
+}
 extern "C" int wh_session_synchronize(wh_session* s) {
     if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "session is null");
     WH_HIP(hipStreamSynchronize(s->st));
@@ -570,6 +638,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = s->n_align_alloc;
     db.d32 = &s->d32; db.x = s->d32.x; db.q = s->d32.q;
+    if (s->use_xabs) { s->xabs.enc = s->enc16; db.xabs = &s->xabs; }
     // cross-attention gate: WH_XATT_GATE=0 never, 1 always, unset: while the model carries more than one session (dec_shared.h)
     static const int gate_mode = [] { const char* e = getenv("WH_XATT_GATE"); return e ? atoi(e) : -1; }();
     const bool gate_on = gate_mode < 0 ? kXattnGateDefault && m->n_sessions.load() > 1 : gate_mode != 0;
@@ -620,12 +689,14 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
     const wh_model* m = s->m;
     const int d = m->dims.n_text_state, L = m->dims.n_text_layer;
-    GemmArgs g{};
-    g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
-    g.ldc = L * 2 * d; g.k16 = s->cross_k; g.vt16 = s->cross_v; g.d_model = d; g.max_batch = s->B;
-    g.prof_kind = KK_CROSS_KV;
-    launch_gemm(EPI_CROSS_KV, g, s->st);
-    WH_CHECK_LAUNCH();
+    if (!s->use_xabs) {     // (the absorbed cross-attention reads the encoder output itself: no per-layer K / V projection)
+        GemmArgs g{};
+        g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
+        g.ldc = L * 2 * d; g.k16 = s->cross_k; g.vt16 = s->cross_v; g.d_model = d; g.max_batch = s->B;
+        g.prof_kind = KK_CROSS_KV;
+        launch_gemm(EPI_CROSS_KV, g, s->st);
+        WH_CHECK_LAUNCH();
+    }
     return wh_reset_decoder_inputs(s, batch);
 }
 

@@ -835,10 +835,23 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_OPROJ;
         launch_dec32_proj(P32_RESID, a, n_bt, st);
         a = base;               // LN2 (folded) + cross-attention query
-        a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ; a.gate = db.xattn_gate;
+        a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
+        a.gate = db.xabs ? nullptr : db.xattn_gate;
         launch_dec32_proj(P32_Q, a, n_bt, st);
-        at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
-        launch_cross_attn(at, S, H, B, st);
+        if (db.xabs) {          // weight-absorbed cross-attention over the encoder output (xabs.hip): no per-layer K / V rows
+            const Xabs& X = *db.xabs;
+            XabsArgs xa{};
+            xa.batch = B; xa.max_batch = db.max_batch; xa.d = d; xa.n_head = H; xa.layer = l; xa.n_split = kXabsSplits; xa.cross_div = db.cross_div;
+            xa.enc = X.enc; xa.q = D.q; xa.wkT = X.layers_host[l].wkT; xa.wv_t = X.layers_host[l].wv_t; xa.bv = X.layers_host[l].bv;
+            xa.qf_hi = X.qf_hi; xa.qf_lo = X.qf_lo; xa.part = X.part; xa.ml = X.ml; xa.att_hi = D.zb_hi; xa.att_lo = D.zb_lo;
+            xa.align = db.align; xa.align_slot = db.align_slot; xa.n_align = db.n_align; xa.seq = db.seq; xa.kpart = D.part; xa.ticket = D.ticket;
+            launch_xabs_qk(xa, n_bt, st);
+            launch_xabs_attn(xa, st);
+            launch_xabs_vup(xa, n_bt, st);
+        } else {
+            at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
+            launch_cross_attn(at, S, H, B, st);
+        }
         a = base;               // x += W_co att + b_co; planes gamma_3 x, statistics for LN3
         a.N = d; a.K = d; a.Wt = t.co_t; a.zhi = D.zb_hi; a.zlo = D.zb_lo; a.bias = w.co_b; a.gamma_next = w.ln3_g;
         a.zhi_out = D.za_hi; a.zlo_out = D.za_lo; a.stat_out = D.stat; a.prof_kind = KK_DEC_COPROJ;

@@ -41,6 +41,9 @@ struct wh_model {
     std::vector<wh::Dec32LayerW> dec32;
     void* dec32_blob = nullptr;
     const f16* emb_t = nullptr; const float *lg_g = nullptr, *lg_c = nullptr;
+    // weight-absorbed cross-attention (xabs.hip): W_k^T tiles + W_v tiles per layer, built at load when the width supports it
+    std::vector<wh::XabsLayerW> xabs;
+    void* xabs_blob = nullptr;
     std::vector<int> align_slot;   // [L*H] -> slot or -1
     int n_align = 0;
     int* align_slot_dev = nullptr;
@@ -77,6 +80,9 @@ struct wh_session {
     float* align_tmp = nullptr; int align_tmp_heads = 0;   // [224][n_align][1500] softmax rows + [2][n_align][1500] statistics + 224 flags
     std::map<WhGraphKey, hipGraphExec_t> graphs;   // captured 8-step decode graphs of THIS session (no process-wide state)
     const volatile int32_t* cancel_flag = nullptr; // polled between step graphs and pipeline stages (Task.checkCancellation)
+    bool use_xabs = false;                // cross-attention path of this session (fixed at creation: never a function of the live batch)
+    wh::Xabs xabs{};                      // absorbed queries + split partials (one allocation: xabs_blob)
+    void* xabs_blob = nullptr;
     wh::Dec32 d32{};                      // decode-step activations: residual, planes, split-K scratch (one allocation: d32_blob)
     void* d32_blob = nullptr;
     wh::SeqState* seq = nullptr;

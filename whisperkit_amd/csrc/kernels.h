@@ -31,7 +31,7 @@ struct PerDeviceOnce {
 enum KernelKind {
     KK_MEL_POWER = 0, KK_MEL_FINALIZE, KK_CONV1, KK_CONV2, KK_LAYERNORM, KK_ENC_QKV, KK_ENC_ATTN, KK_ENC_O, KK_ENC_FC1, KK_ENC_FC2,
     KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_OPROJ, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_COPROJ, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS,
-    KK_SAMPLER, KK_DEC_EMBED,
+    KK_SAMPLER, KK_DEC_EMBED, KK_DEC_XQK, KK_DEC_XVUP,
     KK_COUNT
 };
 struct KernelProfiler {
@@ -184,6 +184,7 @@ struct DecodeBuffers {
     const int* self_owner;   // null, or [Bmax][224]: the slot whose cache holds row r of slot b's history (beam search: a beam that
                              // continues another beam's sequence reads that beam's rows in place - no cache rearrangement copies)
     const struct Dec32* d32; // activation planes / split-K scratch / tiled weights of the projection kernels (decoder32.hip)
+    const struct Xabs* xabs; // non-null: weight-absorbed cross-attention over the encoder output (xabs.hip) instead of the cross K / V stream
 };
 constexpr int kStatBlocks = 1792; // >= workgroups of the logits kernel (V / 64 rows: GEMV path, V / 32 rows: MFMA path), multiple of 256
 // Largest vocabulary the sampling kernels cover: sampler_kernel holds SAMP_T x SAMP_E = 1024 x 51 ids in registers, the fused greedy
@@ -243,6 +244,36 @@ void launch_dec32_embed(const f16* emb, const float* pos, const SeqState* seq, i
 void dec32_tile_weights(const f16* W, int N, int K, f16* out, hipStream_t st);
 void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* g, float* c, hipStream_t st);
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
+
+// ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
+constexpr int kXabsSplits = 4;      // key splits per slot: a constant of the build (the combine order fixes the bits)
+struct XabsLayerW {
+    const f16* wkT;      // W_k^T tiles [H][d / 32][4][64][8] (A fragments of the Q' projection)
+    const f16* wv_t;     // W_v in the decoder projection tiling [d / 32][d / 16][64][8]
+    const float* bv;     // [d]
+};
+struct Xabs {
+    const XabsLayerW* layers_host;   // [L]
+    const f16* enc;      // [Bmax][1500][d] encoder output (f16), the session's enc16
+    f16 *qf_hi, *qf_lo;  // [Bmax][head tiles][d / 32][64][8] absorbed queries as S-phase B fragments
+    float* part;         // [splits][H][d / 8][Bmax][8] unnormalised O' of every key split
+    float2* ml;          // [splits][H][Bmax] (running maximum, sum)
+};
+struct XabsArgs {
+    int batch, max_batch, d, n_head, layer, n_split, cross_div;
+    const f16* enc; const float* q;
+    const f16 *wkT, *wv_t; const float* bv;
+    f16 *qf_hi, *qf_lo; float* part; float2* ml;
+    f16 *att_hi, *att_lo;
+    float* align; const int* align_slot; int n_align;
+    const SeqState* seq;
+    float* kpart; int* ticket;       // K-slice scratch of xabs_vup (the projection kernels' part / ticket buffers)
+};
+bool xabs_supported(int d, int n_head);
+void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);
+void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st);
+void launch_xabs_attn(const XabsArgs& a, hipStream_t st);
+void launch_xabs_vup(const XabsArgs& a, int n_bt, hipStream_t st);
 
 // one decoder forward + (optionally) fused filter/sample/state-advance for all slots
 void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, const int* suppress_dev, bool sample, hipStream_t st);

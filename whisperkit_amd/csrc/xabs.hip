@@ -1,0 +1,496 @@
+// Weight-absorbed cross-attention of the decoder step (gfx950) - round 4.
+//
+// The reference feeds the encoder output to EVERY decoder call (TextDecoderInput.encoder_output_embeds, Core/Models.swift:970-1034,
+// Core/TextDecoder.swift:381-418); the per-layer cross K / V rows are an implementation detail of the CoreML graph.  Streaming those
+// rows is the dominant traffic of the step (large-v3, 64 slots: 491.5 MB per layer launch, 15.7 GB per session), so this path never
+// materialises them.  With K_h = enc W_k,h^T and V_h = enc W_v,h^T + b_v,h:
+//
+//     q_h . K_h[t]      = (W_k,h^T q_h) . enc[t]                  = Q'_h . enc[t]           (k_proj has no bias)
+//     sum_t p_t V_h[t]  = W_v,h (sum_t p_t enc[t]) + b_v,h        = W_v,h O'_h + b_v,h      (sum_t p_t = 1)
+//
+// so a layer reads the slot's encoder output [1500][d] f16 ONCE (half the bytes, the same tensor for all layers: 246 MB per session
+// at 64 slots - Infinity-Cache sized) and the heads become the 32-wide side of MFMA tiles.  Three launches replace dec_cross_attn:
+//
+//   xabs_qk     Q'[slot][head][c] = sum_j W_k[h 64 + j][c] q[slot][h 64 + j]     (batch tile = N side, W_k^T tiles pre-tiled at load)
+//   xabs_attn   one workgroup per (slot, key split): the split's encoder rows stream through an LDS ring by LDS-DMA (16-key tiles,
+//               40 KB at d = 1280, ring of 3); per tile S^T = enc Q'^T on v_mfma_f32_16x16x32_f16 (the 8 waves split the channels,
+//               partial tiles meet in LDS), online softmax with a deferred running maximum, P^T (f16) back through LDS,
+//               O'^T += enc^T P^T on v_mfma_f32_32x32x16_f16 with the enc^T operand read by ds_read_b64_tr_b16; the split's
+//               unnormalised O' [head][c] and (m, l) go to a partial buffer
+//   xabs_vup    combines the splits while loading them as B fragments, att[slot][h 64 + j] = W_v,h O'_h / l + b_v -> the att planes
+//               the cross out projection (dec32_proj RESID) already reads
+//
+// Everything is bit-deterministic and batch-invariant: a (slot, split) workgroup never looks at another slot, the split count depends
+// on nothing but the build, partial sums are combined in index order.
+#include "dec_shared.h"
+
+namespace wh {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+
+// 16-byte chunk c of tile row `key` lives in slot c ^ xswz(key) (low 4 bits): conflict-free for the S-phase ds_read_b128 (lane = key |
+// k group << 4) AND for the transpose reads of the P V phase (4 consecutive keys x 4 consecutive chunks per 32-lane group)
+__host__ __device__ __forceinline__ int xswz(int key) { return ((key & 3) << 2) | ((0x78 >> (2 * ((key >> 2) & 3))) & 3); }
+
+// ---------------------------------------------------------------------------------------------- model-load helper
+// W_k [d rows (h 64 + j)][d cols c] -> wkT[h][rt = c / 32][kt = j / 16][lane][8]: lane l = (c & 31) | (k half << 5) holds
+// W_k[h 64 + kt 16 + 8 (l >> 5) + 0..7][rt 32 + (l & 31)] - the A fragment of Q'_h tile rows rt 32.. against q_h
+__global__ void xabs_tile_wk_kernel(const f16* __restrict__ Wk, int d, int H, f16* __restrict__ out, size_t n_units) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_units) return;
+    const int lane = (int)(o & 63);
+    size_t t = o >> 6;
+    const int kt = (int)(t & 3); t >>= 2;
+    const int RT = d >> 5;
+    const int rt = (int)(t % RT), h = (int)(t / RT);
+    const int c = rt * 32 + (lane & 31), j0 = h * 64 + kt * 16 + 8 * (lane >> 5);
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = Wk[(size_t)(j0 + i) * d + c];
+    *reinterpret_cast<f16x8*>(out + o * 8) = v;
+}
+void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st) {
+    const size_t n_units = (size_t)H * (d / 32) * 4 * 64;
+    xabs_tile_wk_kernel<<<(unsigned)((n_units + 255) / 256), 256, 0, st>>>(Wk, d, H, out, n_units);
+}
+
+// ---------------------------------------------------------------------------------------------- xabs_qk
+// grid (d / 256, H, n_bt), 4 waves, wave w: row tiles (blockIdx.x 4 + w) 2 + {0, 1}.  Output in the B-fragment order of the S phase
+// (v_mfma_f32_16x16x32_f16, lane = (head & 15) | k group << 4, 8 channels ks 32 + 8 kg + 0..7):
+//     qf[slot][head tile][ks = c / 32][lane][8]   hi plane + lo plane (lo = (z - hi) 2048)
+template <int NHT>
+__global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, bt = blockIdx.z;
+    const int d = a.d, RT = d >> 5, KS = d >> 5;
+    const int j = lane & 31, hl = lane >> 5, gb = bt * 32 + j;
+    // q_h as B fragments (K = 16 j-channels x N = 32 slots), hi | lo
+    f16x8 qh[4], ql[4];
+    {
+        const float* qp = a.q + (size_t)gb * d + h * 64 + hl * 8;
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { v0[kt] = *reinterpret_cast<const float4*>(qp + kt * 16); v1[kt] = *reinterpret_cast<const float4*>(qp + kt * 16 + 4); }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float z[8] = {v0[kt].x, v0[kt].y, v0[kt].z, v0[kt].w, v1[kt].x, v1[kt].y, v1[kt].z, v1[kt].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f16 h_, l_; split_hilo(z[i], h_, l_); qh[kt][i] = h_; ql[kt][i] = l_; }
+        }
+    }
+    const int ht = h >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int rt = (blockIdx.x * 4 + wave) * 2 + s;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(a.wkT) + ((size_t)(h * RT + rt) * 4) * 64 + lane;
+        u32x4 w[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) w[kt] = wp[kt * 64];
+        f32x16 acc_h = {0}, acc_l = {0};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f16x8 wf = __builtin_bit_cast(f16x8, w[kt]);
+            acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, qh[kt], acc_h, 0, 0, 0);
+            acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, ql[kt], acc_l, 0, 0, 0);
+        }
+        // accumulator row (r & 3) + 8 (r >> 2) + 4 hl = channel c - rt 32; group g = r >> 2 is k group g, (r & 3) + 4 hl is the element
+        // index: lanes l and l + 32 hold the two halves of one 16-byte unit.  v_permlane32_swap pairs them: afterwards the lower lane
+        // owns the whole units of g = 0, 1, the upper lane those of g = 2, 3.
+        unsigned ph[4][2], pl[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16 zh[4], zl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_hilo(fmaf(acc_l[4 * g + i], 1.0f / 2048.0f, acc_h[4 * g + i]), zh[i], zl[i]);
+            ph[g][0] = __builtin_bit_cast(unsigned, f16x2{zh[0], zh[1]});
+            ph[g][1] = __builtin_bit_cast(unsigned, f16x2{zh[2], zh[3]});
+            pl[g][0] = __builtin_bit_cast(unsigned, f16x2{zl[0], zl[1]});
+            pl[g][1] = __builtin_bit_cast(unsigned, f16x2{zl[2], zl[3]});
+        }
+        u32x4 oh[2], ol[2];     // unit 0: g = 0 (lower lanes) / 2 (upper lanes); unit 1: g = 1 / 3
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // vdst = g = u (its upper half goes away), src0 = g = u + 2 (its lower half goes away)
+                auto sh = __builtin_amdgcn_permlane32_swap(ph[u][i], ph[u + 2][i], false, false);
+                auto sl = __builtin_amdgcn_permlane32_swap(pl[u][i], pl[u + 2][i], false, false);
+                oh[u][i] = sh[0]; oh[u][2 + i] = sh[1];
+                ol[u][i] = sl[0]; ol[u][2 + i] = sl[1];
+            }
+        }
+        if (gb < a.batch) {
+            const size_t base = (((size_t)gb * NHT + ht) * KS + rt) * 64 + (h & 15);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const size_t o = (base + (size_t)(u + 2 * hl) * 16) * 8;
+                *reinterpret_cast<u32x4*>(a.qf_hi + o) = oh[u];
+                *reinterpret_cast<u32x4*>(a.qf_lo + o) = ol[u];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- xabs_attn
+constexpr int kXabsRing = 3;
+constexpr int kXabsSpStride = 32 * 17;       // floats per wave partial: [32 heads][16 keys + 1]
+constexpr float kXabsDefer = 8.0f;           // the running maximum moves only when it would grow by more than this (p <= e^8 fits f16)
+__host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsRing * cw * 8192 + 8 * kXabsSpStride * 4 + 1024 + 128; }
+
+template <int CW, int NHT, bool HILO>
+__global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
+    constexpr int D = CW * 256, ROWB = D * 2, TILE = 16 * ROWB, KS = D / 32;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    float* spart = reinterpret_cast<float*>(smem + kXabsRing * TILE);
+    f16* pfrag = reinterpret_cast<f16*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4);
+    float* alpha_l = reinterpret_cast<float*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4 + 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sp = blockIdx.x, b = blockIdx.y, S = a.n_split, H = a.n_head;
+    constexpr int NT = (kCtx + 15) / 16;
+    const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
+    const int bc = a.cross_div > 1 ? b / a.cross_div : b;
+    const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
+
+    // ---- LDS-DMA: piece p of this wave fills LDS bytes [(wave CW + p) 1024 + lane 16, +16) of a tile slot
+    int p_row[CW], p_cb[CW];
+#pragma unroll
+    for (int p = 0; p < CW; ++p) {
+        const int o = (wave * CW + p) * 1024 + lane * 16;
+        const int row = o / ROWB, slot = (o - row * ROWB) >> 4;
+        p_row[p] = row;
+        p_cb[p] = (slot ^ xswz(row)) << 4;
+    }
+    auto issue = [&](int i) {
+        unsigned char* dst = smem + (i % kXabsRing) * TILE + wave * (CW * 1024);
+        const int t16 = (tile_lo + i) * 16;
+#pragma unroll
+        for (int p = 0; p < CW; ++p) {
+            const int row = min(t16 + p_row[p], kCtx - 1);        // rows past the end re-read the last row (masked below)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(enc + (size_t)row * ROWB + p_cb[p]),
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+    // ---- prologue: Q' fragments of this wave's channel slice (k-steps wave CW + j), the first two tiles, the slot state
+    f16x8 qh[NHT][CW], ql[HILO ? NHT : 1][HILO ? CW : 1];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qf_hi) + ((size_t)b * NHT * KS + wave * CW) * 64 + lane;
+        const u32x4* lp = reinterpret_cast<const u32x4*>(a.qf_lo) + ((size_t)b * NHT * KS + wave * CW) * 64 + lane;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                qh[ht][j] = __builtin_bit_cast(f16x8, qp[((size_t)ht * KS + j) * 64]);
+                if constexpr (HILO) ql[ht][j] = __builtin_bit_cast(f16x8, lp[((size_t)ht * KS + j) * 64]);
+            }
+    }
+    issue(0);
+    if (n > 1) issue(1);
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
+    // softmax owner coordinates: lane = key | (head & 3) << 4, wave = head >> 2
+    const int o_key = lane & 15, o_head = 4 * wave + (lane >> 4);
+    const bool owner = o_head < 16 * NHT;
+    int al_slot = -1;
+    if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
+    if (tid < 32) alpha_l[tid] = 1.0f;
+    for (int i = tid; i < 512; i += 512) pfrag[i] = (f16)0.0f;
+    if (!(s_act && !s_done)) {           // workgroup-uniform: a finished slot streams nothing more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int pos = min(max(s_ti, 0), kMaxTok - 1);
+    float* raw = nullptr;
+    if (al_slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + al_slot) * kCtx;
+
+    f32x16 acc[CW];
+#pragma unroll
+    for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    // S phase A operand: lane = key | k group << 4; P V phase transpose-read supplier: 16-lane group g16, supplier index s
+    const int s_key = lane & 15, s_kg = lane >> 4, s_sw = xswz(s_key);
+    const int g16 = lane >> 4, sl = lane & 15;
+    const int t_key0 = (g16 >> 1) * 8 + (sl >> 2), t_key1 = t_key0 + 4;
+    const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
+    const int t_off0 = t_key0 * ROWB + t_b, t_off1 = t_key1 * ROWB + t_b, t_sw0 = xswz(t_key0), t_sw1 = xswz(t_key1);
+
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // A: tile i landed for every wave; everybody is done with tile i - 1
+        if (i + 2 < n) issue(i + 2);
+        const unsigned char* tile = smem + (i % kXabsRing) * TILE;
+        // ---- S^T partial over this wave's channels: [16 keys] x [16 NHT heads]
+        {
+            f16x8 af[CW];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                const int c = (wave * CW + j) * 4 + s_kg;
+                af[j] = *reinterpret_cast<const f16x8*>(tile + s_key * ROWB + ((c ^ s_sw) << 4));
+            }
+            f32x4 sh[NHT], sl_[NHT];
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) { sh[ht] = f32x4{0, 0, 0, 0}; sl_[ht] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int j = 0; j < CW; ++j)
+#pragma unroll
+                for (int ht = 0; ht < NHT; ++ht) {
+                    sh[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], qh[ht][j], sh[ht], 0, 0, 0);
+                    if constexpr (HILO) sl_[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], ql[ht][j], sl_[ht], 0, 0, 0);
+                }
+            // D[key = 4 (lane >> 4) + r][head = lane & 15]
+            float* wpart = spart + wave * kXabsSpStride;
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = HILO ? fmaf(sl_[ht][r], 1.0f / 2048.0f, sh[ht][r]) : sh[ht][r];
+                    wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = v;
+                }
+        }
+        __syncthreads();                                  // B: the 8 channel-slice partials are in LDS
+        if (owner) {
+            float s = 0.0f;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) s += spart[v * kXabsSpStride + o_head * 17 + o_key];
+            const int t = (tile_lo + i) * 16 + o_key;
+            const bool valid = t < kCtx;
+            if (raw && valid) raw[t] = s;                 // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
+            s = valid ? s : -INFINITY;
+            float mt_ = s;                                // maximum over the 16 keys = the 16 lanes of a DPP row
+            mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
+            mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
+            mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
+            mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
+            const float m_new = fmaxf(m_run, mt_);
+            const float m_use = (m_new > m_run + kXabsDefer) ? m_new : m_run;     // (m_run = -inf: the first tile always takes its maximum)
+            const float al = __expf(m_run - m_use);       // 1 when the maximum stays, 0 on the first tile
+            float p = valid ? __expf(s - m_use) : 0.0f;
+            if (o_head >= H) p = 0.0f;
+            const f16 ph = (f16)p;
+            float ps = (float)ph;                         // the denominator sums what the numerator multiplies
+            ps += dpp_mov<kDppXor1>(ps);
+            ps += dpp_mov<kDppXor2>(ps);
+            ps += dpp_mov<kDppHalfMirror>(ps);
+            ps += dpp_mov<kDppMirror>(ps);
+            l_run = fmaf(l_run, al, ps);
+            m_run = m_use;
+            // P^T as the B fragment of the P V MFMA: lane' = head | (key >> 3) << 5, element key & 7
+            pfrag[(o_head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
+            if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
+        }
+        __syncthreads();                                  // C: P^T and the rescale factors are in LDS
+        {
+            const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
+            const float al = alpha_l[lane & 31];
+            if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {        // wave-uniform, rare: some head's running maximum moved
+#pragma unroll
+                for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
+            }
+            // O'^T[channel][head] += enc^T[channel][key] P^T[key][head]: A = enc^T tile (M = 32 channels, K = 16 keys), two transpose reads
+#pragma unroll
+            for (int mt = 0; mt < CW; ++mt) {
+                const int c = (wave * CW + mt) * 4 + t_c;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off0 + ((c ^ t_sw0) << 4)));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off1 + ((c ^ t_sw1) << 4)));
+                const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
+                const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- this split's partial: (m, l) per head, unnormalised O'[head][c] in the order xabs_vup loads B fragments:
+    //      part[split][head][c / 8][slot][c & 7]
+    if (owner && o_key == 0 && o_head < H) a.ml[((size_t)sp * H + o_head) * a.max_batch + b] = float2{m_run, l_run};
+    {
+        const int head = lane & 31, hl = lane >> 5;
+        if (head < H) {
+            float* pb = a.part + (((size_t)sp * H + head) * (D / 8)) * a.max_batch * 8 + (size_t)b * 8 + 4 * hl;
+#pragma unroll
+            for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c8 = (wave * CW + mt) * 4 + g;
+                    *reinterpret_cast<float4*>(pb + (size_t)c8 * a.max_batch * 8) = float4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- xabs_vup
+// att[slot][n] = (W_v[n][:] . sum_s w_s O'_s[head(n)][:]) / l + b_v[n],  w_s = exp(m_s - max m),  l = sum_s w_s l_s.
+// A workgroup = one 32-row tile of W_v (tiled like every decoder projection: Wt[rt][kt][lane][8]) x one K slice x one batch tile;
+// the B fragment of a k tile is the lane's slot, 8 consecutive channels: loaded from every split's partial and combined on the fly.
+// K slices meet through write-through partial tiles + a ticket exactly like dec32_proj_kernel.
+template <int S, int TW>
+__global__ __launch_bounds__(256, 2) void xabs_vup_kernel(const XabsArgs a, int ks, int n_bt) {
+    __shared__ float red[4][16][64];
+    __shared__ int last_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = a.d, H = a.n_head, n_rt = d >> 5, KT = d >> 4;
+    const int grp8 = blockIdx.x / (8 * n_bt), in8 = blockIdx.x % (8 * n_bt);
+    const int xw = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
+    if (xw >= n_rt * ks) return;
+    const int rt = xw % n_rt, ksi = xw / n_rt, h = rt >> 1;
+    const int kt0 = (ksi * 4 + wave) * TW;
+    const int j = lane & 31, hl = lane >> 5;
+    const int gbl = min(bt * 32 + j, a.max_batch - 1);          // fragment loads of padding lanes stay inside the buffers
+    // ---- split weights of this lane's slot
+    float wn[S];
+    {
+        float2 ml[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) ml[s] = a.ml[((size_t)s * H + h) * a.max_batch + gbl];
+        float mg = ml[0].x;
+#pragma unroll
+        for (int s = 1; s < S; ++s) mg = fmaxf(mg, ml[s].x);
+        float lg = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { wn[s] = __expf(ml[s].x - mg); lg = fmaf(wn[s], ml[s].y, lg); }
+        const float inv = 1.0f / lg;
+#pragma unroll
+        for (int s = 0; s < S; ++s) wn[s] *= inv;
+    }
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.wv_t) + ((size_t)rt * KT + kt0) * 64 + lane;
+    const size_t sstride = (size_t)H * (d / 8) * a.max_batch * 8;       // floats per split
+    const float* pp = a.part + ((size_t)h * (d / 8) + kt0 * 2 + hl) * a.max_batch * 8 + (size_t)gbl * 8;
+    u32x4 w[TW];
+    float4 p0[TW][S], p1[TW][S];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* q = pp + (size_t)s * sstride + (size_t)i * 2 * a.max_batch * 8;
+            p0[i][s] = *reinterpret_cast<const float4*>(q);
+            p1[i][s] = *reinterpret_cast<const float4*>(q + 4);
+        }
+    f32x16 acc_h = {0}, acc_l = {0};
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {          // index order: the combine fixes the bits
+            z[0] = fmaf(wn[s], p0[i][s].x, z[0]); z[1] = fmaf(wn[s], p0[i][s].y, z[1]); z[2] = fmaf(wn[s], p0[i][s].z, z[2]); z[3] = fmaf(wn[s], p0[i][s].w, z[3]);
+            z[4] = fmaf(wn[s], p1[i][s].x, z[4]); z[5] = fmaf(wn[s], p1[i][s].y, z[5]); z[6] = fmaf(wn[s], p1[i][s].z, z[6]); z[7] = fmaf(wn[s], p1[i][s].w, z[7]);
+        }
+        f16x8 zh, zl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f16 h_, l_; split_hilo(z[e], h_, l_); zh[e] = h_; zl[e] = l_; }
+        const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
+        acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, zh, acc_h, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, zl, acc_l, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]);
+    __syncthreads();
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
+    // epilogue coordinates as in dec32_proj_kernel: slot tid & 31, channels n .. n + 3
+    const int sub = tid >> 5;
+    const int nn = rt * 32 + 4 * sub, gb = bt * 32 + (tid & 31);
+    if (ks > 1) {
+        float* base = a.kpart + (((size_t)bt * n_rt + rt) * ks) * 1024 + tid * 4;
+        {
+            const f32x4 pv4 = {v[0], v[1], v[2], v[3]};
+            float* mine = base + (size_t)ksi * 1024;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int* cnt = a.ticket + bt * n_rt + rt;
+            const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == ks - 1);
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = last;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        float pv[8][4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float* p = base + (size_t)(s < ks ? s : 0) * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = pv[0][i];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) t += (s < ks) ? pv[s][i] : 0.0f;
+            v[i] = t;
+        }
+    }
+    if (gb < a.batch && slot_live(a.seq + gb)) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bv + nn);
+        const float y[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+        f16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(y[i], h_, l_); hi[i] = h_; lo[i] = l_; }
+        const size_t o = plane_index(gb, nn, d);
+        *reinterpret_cast<f16x4*>(a.att_hi + o) = hi;
+        *reinterpret_cast<f16x4*>(a.att_lo + o) = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static int xabs_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+bool xabs_supported(int d, int n_head) { return d % 256 == 0 && d >= 512 && d <= 1280 && n_head <= 32; }
+
+void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
+    ProfScope ps_(KK_DEC_XQK, st);
+    const dim3 grid(a.d / 256, a.n_head, n_bt);
+    if (a.n_head > 16) xabs_qk_kernel<2><<<grid, 256, 0, st>>>(a);
+    else xabs_qk_kernel<1><<<grid, 256, 0, st>>>(a);
+}
+
+template <int CW, int NHT>
+static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
+    static const int hilo = xabs_env("WH_XABS_QLO", 1);       // A/B: Q' as an f16 hi | lo pair (default) or a single f16 plane
+    const dim3 grid(a.n_split, a.batch);
+    constexpr int lds = xabs_lds_bytes(CW);
+    if (hilo) {
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+        xabs_attn_kernel<CW, NHT, true><<<grid, 512, lds, st>>>(a);
+    } else {
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+        xabs_attn_kernel<CW, NHT, false><<<grid, 512, lds, st>>>(a);
+    }
+}
+void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
+    ProfScope ps_(KK_DEC_CROSS_ATTN, st);
+    const bool two = a.n_head > 16;
+    switch (a.d / 256) {
+        case 2: two ? launch_attn_t<2, 2>(a, st) : launch_attn_t<2, 1>(a, st); break;
+        case 3: two ? launch_attn_t<3, 2>(a, st) : launch_attn_t<3, 1>(a, st); break;
+        case 4: two ? launch_attn_t<4, 2>(a, st) : launch_attn_t<4, 1>(a, st); break;
+        default: two ? launch_attn_t<5, 2>(a, st) : launch_attn_t<5, 1>(a, st); break;
+    }
+}
+
+void launch_xabs_vup(const XabsArgs& a, int n_bt, hipStream_t st) {
+    ProfScope ps_(KK_DEC_XVUP, st);
+    // K slices: d / 16 k tiles over 4 waves x ks workgroups, TW tiles per wave; ks = 4 at every supported width (TW = d / 256)
+    constexpr int ks = 4;
+    const int nx = (a.d / 32) * ks;
+    const unsigned grid = (unsigned)(((nx + 7) / 8) * 8 * n_bt);
+    switch (a.d / 256) {
+        case 2: xabs_vup_kernel<kXabsSplits, 2><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
+        case 3: xabs_vup_kernel<kXabsSplits, 3><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
+        case 4: xabs_vup_kernel<kXabsSplits, 4><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
+        default: xabs_vup_kernel<kXabsSplits, 5><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
+    }
+}
+
+}  // namespace wh
