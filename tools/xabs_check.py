@@ -72,9 +72,9 @@ Wv = sd[f"decoder.blocks.{l}.cross_attn.value.weight"].astype(np.float32)
 bv = sd[f"decoder.blocks.{l}.cross_attn.value.bias"].astype(np.float32)
 NHT = 2 if H > 16 else 1
 KS = d // 32
-qf = (peek(s1, "qf_hi", (B, NHT, KS, 64, 8), np.float16).astype(np.float32) + peek(s1, "qf_lo", (B, NHT, KS, 64, 8), np.float16).astype(np.float32) / 2048.0)
-# qf[b][ht][ks][lane = (head & 15) | kg << 4][e] = Q'[b][head][ks 32 + kg 8 + e]
-qp = qf.reshape(B, NHT, KS, 4, 16, 8).transpose(0, 1, 4, 2, 3, 5).reshape(B, NHT * 16, d)[:, :H]
+HP = NHT * 16
+qf = (peek(s1, "qf_hi", (B, HP, d), np.float16).astype(np.float32) + peek(s1, "qf_lo", (B, HP, d), np.float16).astype(np.float32) / 2048.0)
+qp = qf[:, :H]
 qp_ref = np.einsum("bhj,hjc->bhc", q.reshape(B, H, 64), Wk.reshape(H, 64, d))
 print(json.dumps({"check": "absorbed_queries", "max_abs_diff": float(np.abs(qp - qp_ref).max()), "rms": float(np.sqrt((qp_ref ** 2).mean()))}))
 

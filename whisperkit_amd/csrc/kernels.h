@@ -255,7 +255,7 @@ struct XabsLayerW {
 struct Xabs {
     const XabsLayerW* layers_host;   // [L]
     const f16* enc;      // [Bmax][1500][d] encoder output (f16), the session's enc16
-    f16 *qf_hi, *qf_lo;  // [Bmax][head tiles][d / 32][64][8] absorbed queries as S-phase B fragments
+    f16 *qf_hi, *qf_lo;  // [Bmax][heads padded to 16 / 32][d] absorbed queries Q' = W_k^T q, f16 hi | lo
     float* part;         // [splits][H][d / 8][Bmax][8] unnormalised O' of every key split
     float2* ml;          // [splits][H][Bmax] (running maximum, sum)
 };

@@ -57,14 +57,14 @@ void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_qk
-// grid (d / 256, H, n_bt), 4 waves, wave w: row tiles (blockIdx.x 4 + w) 2 + {0, 1}.  Output in the B-fragment order of the S phase
-// (v_mfma_f32_16x16x32_f16, lane = (head & 15) | k group << 4, 8 channels ks 32 + 8 kg + 0..7):
-//     qf[slot][head tile][ks = c / 32][lane][8]   hi plane + lo plane (lo = (z - hi) 2048)
+// grid (d / 256, H, n_bt), 4 waves, wave w: row tiles (blockIdx.x 4 + w) 2 + {0, 1}.  Output qf[slot][head (padded to 16 NHT)][c], an
+// f16 hi plane + lo plane (lo = (z - hi) 2048): a wave writes whole 128-byte lines, xabs_attn gathers its S-phase B fragments
+// (lane = (head & 15) | k group << 4, 8 channels ks 32 + 8 kg + 0..7) from it with 64 contiguous bytes per head and k-step
 template <int NHT>
 __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, bt = blockIdx.z;
-    const int d = a.d, RT = d >> 5, KS = d >> 5;
+    const int d = a.d, RT = d >> 5;
     const int j = lane & 31, hl = lane >> 5, gb = bt * 32 + j;
     // q_h as B fragments (K = 16 j-channels x N = 32 slots), hi | lo
     f16x8 qh[4], ql[4];
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
             for (int i = 0; i < 8; ++i) { f16 h_, l_; split_hilo(z[i], h_, l_); qh[kt][i] = h_; ql[kt][i] = l_; }
         }
     }
-    const int ht = h >> 4;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int rt = (blockIdx.x * 4 + wave) * 2 + s;
@@ -122,12 +121,13 @@ __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
             }
         }
         if (gb < a.batch) {
-            const size_t base = (((size_t)gb * NHT + ht) * KS + rt) * 64 + (h & 15);
+            // the lower lane holds channels rt 32 + 0..15 (units g = 0, 1), the upper lane rt 32 + 16..31: 32 contiguous bytes per lane and
+            // plane, 128 contiguous bytes per slot over the wave's two row tiles
+            const size_t o = ((size_t)gb * (NHT * 16) + h) * d + rt * 32 + 16 * hl;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const size_t o = (base + (size_t)(u + 2 * hl) * 16) * 8;
-                *reinterpret_cast<u32x4*>(a.qf_hi + o) = oh[u];
-                *reinterpret_cast<u32x4*>(a.qf_lo + o) = ol[u];
+                *reinterpret_cast<u32x4*>(a.qf_hi + o + 8 * u) = oh[u];
+                *reinterpret_cast<u32x4*>(a.qf_lo + o + 8 * u) = ol[u];
             }
         }
     }
@@ -147,7 +147,12 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     f16* pfrag = reinterpret_cast<f16*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4);
     float* alpha_l = reinterpret_cast<float*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4 + 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sp = blockIdx.x, b = blockIdx.y, S = a.n_split, H = a.n_head;
+    // workgroup id -> (split, slot): id % 8 is the XCD; an XCD takes ONE split index (two XCDs per split) and whole groups of 4 consecutive
+    // slots, whose 32-byte partial sectors share 128-byte lines (part[split][head][c / 8][slot][8]): the lines are assembled in one L2
+    const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;
+    const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
+    const int S = kXabsSplits, H = a.n_head;
+    if (b >= a.batch) return;
     constexpr int NT = (kCtx + 15) / 16;
     const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
     const int bc = a.cross_div > 1 ? b / a.cross_div : b;
@@ -175,18 +180,18 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     // ---- prologue: Q' fragments of this wave's channel slice (k-steps wave CW + j), the first two tiles, the slot state
     f16x8 qh[NHT][CW], ql[HILO ? NHT : 1][HILO ? CW : 1];
     {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(a.qf_hi) + ((size_t)b * NHT * KS + wave * CW) * 64 + lane;
-        const u32x4* lp = reinterpret_cast<const u32x4*>(a.qf_lo) + ((size_t)b * NHT * KS + wave * CW) * 64 + lane;
+        const size_t qo = ((size_t)b * (NHT * 16) + (lane & 15)) * D + wave * CW * 32 + (lane >> 4) * 8;
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht)
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
-                qh[ht][j] = __builtin_bit_cast(f16x8, qp[((size_t)ht * KS + j) * 64]);
-                if constexpr (HILO) ql[ht][j] = __builtin_bit_cast(f16x8, lp[((size_t)ht * KS + j) * 64]);
+                qh[ht][j] = *reinterpret_cast<const f16x8*>(a.qf_hi + qo + (size_t)ht * 16 * D + j * 32);
+                if constexpr (HILO) ql[ht][j] = *reinterpret_cast<const f16x8*>(a.qf_lo + qo + (size_t)ht * 16 * D + j * 32);
             }
     }
     issue(0);
     if (n > 1) issue(1);
+    if (n > 2) issue(2);
     const SeqState* sq = a.seq + b;
     const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
     // softmax owner coordinates: lane = key | (head & 3) << 4, wave = head >> 2
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     int al_slot = -1;
     if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
     if (tid < 32) alpha_l[tid] = 1.0f;
-    for (int i = tid; i < 512; i += 512) pfrag[i] = (f16)0.0f;
+    pfrag[tid] = (f16)0.0f;
     if (!(s_act && !s_done)) {           // workgroup-uniform: a finished slot streams nothing more
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -217,92 +222,111 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
     const int t_off0 = t_key0 * ROWB + t_b, t_off1 = t_key1 * ROWB + t_b, t_sw0 = xswz(t_key0), t_sw1 = xswz(t_key1);
 
+    // S^T partial of one tile over this wave's channels, [16 keys] x [16 NHT heads]: D[key = 4 (lane >> 4) + r][head = lane & 15]
+    auto s_phase = [&](const unsigned char* tile, float (&sreg)[NHT * 4]) {
+        f16x8 af[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            const int c = (wave * CW + j) * 4 + s_kg;
+            af[j] = *reinterpret_cast<const f16x8*>(tile + s_key * ROWB + ((c ^ s_sw) << 4));
+        }
+        f32x4 sh[NHT], sl_[NHT];
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) { sh[ht] = f32x4{0, 0, 0, 0}; sl_[ht] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) {
+                sh[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], qh[ht][j], sh[ht], 0, 0, 0);
+                if constexpr (HILO) sl_[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], ql[ht][j], sl_[ht], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sreg[ht * 4 + r] = HILO ? fmaf(sl_[ht][r], 1.0f / 2048.0f, sh[ht][r]) : sh[ht][r];
+    };
+    auto write_partials = [&](const float (&sreg)[NHT * 4]) {
+        float* wpart = spart + wave * kXabsSpStride;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = sreg[ht * 4 + r];
+    };
+    // the owner lane of (key, head): sum of the 8 channel-slice partials, online softmax with a deferred running maximum
+    auto softmax = [&](int i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) s += spart[v * kXabsSpStride + o_head * 17 + o_key];
+        const int t = (tile_lo + i) * 16 + o_key;
+        const bool valid = t < kCtx;
+        if (raw && valid) raw[t] = s;                 // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
+        s = valid ? s : -INFINITY;
+        float mt_ = s;                                // maximum over the 16 keys = the 16 lanes of a DPP row
+        mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
+        const float m_new = fmaxf(m_run, mt_);
+        const float m_use = (m_new > m_run + kXabsDefer) ? m_new : m_run;     // (m_run = -inf: the first tile always takes its maximum)
+        const float al = __expf(m_run - m_use);       // 1 when the maximum stays, 0 on the first tile
+        float p = valid ? __expf(s - m_use) : 0.0f;
+        if (o_head >= H) p = 0.0f;
+        const f16 ph = (f16)p;
+        float ps = (float)ph;                         // the denominator sums what the numerator multiplies
+        ps += dpp_mov<kDppXor1>(ps);
+        ps += dpp_mov<kDppXor2>(ps);
+        ps += dpp_mov<kDppHalfMirror>(ps);
+        ps += dpp_mov<kDppMirror>(ps);
+        l_run = fmaf(l_run, al, ps);
+        m_run = m_use;
+        // P^T as the B fragment of the P V MFMA: lane' = head | (key >> 3) << 5, element key & 7
+        pfrag[(o_head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
+        if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
+    };
+    // O'^T[channel][head] += enc^T[channel][key] P^T[key][head]: A = enc^T tile (M = 32 channels, K = 16 keys), two transpose reads
+    auto pv = [&](const unsigned char* tile) {
+        const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
+        const float al = alpha_l[lane & 31];
+        if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {        // wave-uniform, rare: some head's running maximum moved
+#pragma unroll
+            for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
+        }
+#pragma unroll
+        for (int mt = 0; mt < CW; ++mt) {
+            const int c = (wave * CW + mt) * 4 + t_c;
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off0 + ((c ^ t_sw0) << 4)));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off1 + ((c ^ t_sw1) << 4)));
+            const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
+            const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
+        }
+    };
+
+    // Software pipeline, two barriers per tile:  Y_i = softmax(i) (LDS / VALU latency chain of the owner lanes) beside S(i + 1) (MFMA);
+    // Z_i = partials(i + 1) -> LDS, P V(i).  Tiles i (P V) and i + 1 (S) are resident, tile i + 2 is in flight; tile i + 3 is
+    // requested into tile i's slot at the barrier that ends Z_i.
+    float sreg[NHT * 4];
+    if (n > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory");
+    else if (n > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    s_phase(smem, sreg);
+    write_partials(sreg);
+    if (n > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                      // partials(0) in LDS, tile 1 landed
     for (int i = 0; i < n; ++i) {
-        if (i + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                  // A: tile i landed for every wave; everybody is done with tile i - 1
-        if (i + 2 < n) issue(i + 2);
         const unsigned char* tile = smem + (i % kXabsRing) * TILE;
-        // ---- S^T partial over this wave's channels: [16 keys] x [16 NHT heads]
-        {
-            f16x8 af[CW];
-#pragma unroll
-            for (int j = 0; j < CW; ++j) {
-                const int c = (wave * CW + j) * 4 + s_kg;
-                af[j] = *reinterpret_cast<const f16x8*>(tile + s_key * ROWB + ((c ^ s_sw) << 4));
-            }
-            f32x4 sh[NHT], sl_[NHT];
-#pragma unroll
-            for (int ht = 0; ht < NHT; ++ht) { sh[ht] = f32x4{0, 0, 0, 0}; sl_[ht] = f32x4{0, 0, 0, 0}; }
-#pragma unroll
-            for (int j = 0; j < CW; ++j)
-#pragma unroll
-                for (int ht = 0; ht < NHT; ++ht) {
-                    sh[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], qh[ht][j], sh[ht], 0, 0, 0);
-                    if constexpr (HILO) sl_[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], ql[ht][j], sl_[ht], 0, 0, 0);
-                }
-            // D[key = 4 (lane >> 4) + r][head = lane & 15]
-            float* wpart = spart + wave * kXabsSpStride;
-#pragma unroll
-            for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = HILO ? fmaf(sl_[ht][r], 1.0f / 2048.0f, sh[ht][r]) : sh[ht][r];
-                    wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = v;
-                }
-        }
-        __syncthreads();                                  // B: the 8 channel-slice partials are in LDS
-        if (owner) {
-            float s = 0.0f;
-#pragma unroll
-            for (int v = 0; v < 8; ++v) s += spart[v * kXabsSpStride + o_head * 17 + o_key];
-            const int t = (tile_lo + i) * 16 + o_key;
-            const bool valid = t < kCtx;
-            if (raw && valid) raw[t] = s;                 // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
-            s = valid ? s : -INFINITY;
-            float mt_ = s;                                // maximum over the 16 keys = the 16 lanes of a DPP row
-            mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
-            mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
-            mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
-            mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
-            const float m_new = fmaxf(m_run, mt_);
-            const float m_use = (m_new > m_run + kXabsDefer) ? m_new : m_run;     // (m_run = -inf: the first tile always takes its maximum)
-            const float al = __expf(m_run - m_use);       // 1 when the maximum stays, 0 on the first tile
-            float p = valid ? __expf(s - m_use) : 0.0f;
-            if (o_head >= H) p = 0.0f;
-            const f16 ph = (f16)p;
-            float ps = (float)ph;                         // the denominator sums what the numerator multiplies
-            ps += dpp_mov<kDppXor1>(ps);
-            ps += dpp_mov<kDppXor2>(ps);
-            ps += dpp_mov<kDppHalfMirror>(ps);
-            ps += dpp_mov<kDppMirror>(ps);
-            l_run = fmaf(l_run, al, ps);
-            m_run = m_use;
-            // P^T as the B fragment of the P V MFMA: lane' = head | (key >> 3) << 5, element key & 7
-            pfrag[(o_head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
-            if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
-        }
-        __syncthreads();                                  // C: P^T and the rescale factors are in LDS
-        {
-            const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
-            const float al = alpha_l[lane & 31];
-            if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {        // wave-uniform, rare: some head's running maximum moved
-#pragma unroll
-                for (int mt = 0; mt < CW; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
-            }
-            // O'^T[channel][head] += enc^T[channel][key] P^T[key][head]: A = enc^T tile (M = 32 channels, K = 16 keys), two transpose reads
-#pragma unroll
-            for (int mt = 0; mt < CW; ++mt) {
-                const int c = (wave * CW + mt) * 4 + t_c;
-                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off0 + ((c ^ t_sw0) << 4)));
-                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off1 + ((c ^ t_sw1) << 4)));
-                const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
-                const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
-            }
-        }
+        if (i + 1 < n) s_phase(smem + ((i + 1) % kXabsRing) * TILE, sreg);
+        if (owner) softmax(i);
+        __syncthreads();                                  // C: P^T(i) and the rescale factors are in LDS; partials(i) are consumed
+        if (i + 1 < n) write_partials(sreg);
+        pv(tile);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile i + 2 (the only LDS-DMA outstanding) has landed
+        __syncthreads();                                  // D: partials(i + 1) in LDS; everybody is done with tile i
+        if (i + 3 < n) issue(i + 3);
     }
     // ---- this split's partial: (m, l) per head, unnormalised O'[head][c] in the order xabs_vup loads B fragments:
     //      part[split][head][c / 8][slot][c & 7]
@@ -324,28 +348,53 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
 
 // ---------------------------------------------------------------------------------------------- xabs_vup
 // att[slot][n] = (W_v[n][:] . sum_s w_s O'_s[head(n)][:]) / l + b_v[n],  w_s = exp(m_s - max m),  l = sum_s w_s l_s.
-// A workgroup = one 32-row tile of W_v (tiled like every decoder projection: Wt[rt][kt][lane][8]) x one K slice x one batch tile;
-// the B fragment of a k tile is the lane's slot, 8 consecutive channels: loaded from every split's partial and combined on the fly.
-// K slices meet through write-through partial tiles + a ticket exactly like dec32_proj_kernel.
+// A workgroup = one HEAD (the two 32-row tiles of W_v that share its O'_h: the partials are read once) x one K slice x one batch tile;
+// W_v is tiled like every decoder projection (Wt[rt][kt][lane][8]); the B fragment of a k tile is the lane's slot, 8 consecutive
+// channels: loaded from every split's partial and combined on the fly (index order).  K slices meet through write-through partial
+// tiles + a ticket exactly like dec32_proj_kernel.  Every load of a wave is requested before the first use.
+// (__launch_bounds__(256, 1): the TW x (2 + 2 S) 16-byte loads of a lane live in registers at once - 200 at d = 1280 - beside 64 accumulators)
 template <int S, int TW>
-__global__ __launch_bounds__(256, 2) void xabs_vup_kernel(const XabsArgs a, int ks, int n_bt) {
-    __shared__ float red[4][16][64];
+__global__ __launch_bounds__(256, 1) void xabs_vup_kernel(const XabsArgs a, int ks, int n_bt) {
+    __shared__ float red[4][2][16][64];
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int d = a.d, H = a.n_head, n_rt = d >> 5, KT = d >> 4;
+    const int d = a.d, H = a.n_head, KT = d >> 4;
     const int grp8 = blockIdx.x / (8 * n_bt), in8 = blockIdx.x % (8 * n_bt);
     const int xw = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
-    if (xw >= n_rt * ks) return;
-    const int rt = xw % n_rt, ksi = xw / n_rt, h = rt >> 1;
+    if (xw >= H * ks) return;
+    const int h = xw % H, ksi = xw / H;
     const int kt0 = (ksi * 4 + wave) * TW;
     const int j = lane & 31, hl = lane >> 5;
     const int gbl = min(bt * 32 + j, a.max_batch - 1);          // fragment loads of padding lanes stay inside the buffers
+    float2 ml[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) ml[s] = a.ml[((size_t)s * H + h) * a.max_batch + gbl];
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.wv_t) + ((size_t)(2 * h) * KT + kt0) * 64 + lane;
+    const size_t sstride = (size_t)H * (d / 8) * a.max_batch * 8;       // floats per split
+    const float* pp = a.part + ((size_t)h * (d / 8) + kt0 * 2 + hl) * a.max_batch * 8 + (size_t)gbl * 8;
+    u32x4 w0[TW], w1[TW];
+    f32x4 p0[TW][S], p1[TW][S];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) { w0[i] = __builtin_nontemporal_load(wp + (size_t)i * 64); w1[i] = __builtin_nontemporal_load(wp + ((size_t)KT + i) * 64); }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* q = pp + (size_t)s * sstride + (size_t)i * 2 * a.max_batch * 8;
+            p0[i][s] = *reinterpret_cast<const f32x4*>(q);
+            p1[i][s] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+    // pin: every request above is issued before anything is consumed (the optimiser otherwise sinks the loads next to their uses:
+    // five dependent rounds of memory latency instead of one)
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        asm volatile("" : "+v"(w0[i]), "+v"(w1[i]));
+#pragma unroll
+        for (int s = 0; s < S; ++s) asm volatile("" : "+v"(p0[i][s]), "+v"(p1[i][s]));
+    }
     // ---- split weights of this lane's slot
     float wn[S];
     {
-        float2 ml[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) ml[s] = a.ml[((size_t)s * H + h) * a.max_batch + gbl];
         float mg = ml[0].x;
 #pragma unroll
         for (int s = 1; s < S; ++s) mg = fmaxf(mg, ml[s].x);
@@ -356,57 +405,48 @@ __global__ __launch_bounds__(256, 2) void xabs_vup_kernel(const XabsArgs a, int 
 #pragma unroll
         for (int s = 0; s < S; ++s) wn[s] *= inv;
     }
-    const u32x4* wp = reinterpret_cast<const u32x4*>(a.wv_t) + ((size_t)rt * KT + kt0) * 64 + lane;
-    const size_t sstride = (size_t)H * (d / 8) * a.max_batch * 8;       // floats per split
-    const float* pp = a.part + ((size_t)h * (d / 8) + kt0 * 2 + hl) * a.max_batch * 8 + (size_t)gbl * 8;
-    u32x4 w[TW];
-    float4 p0[TW][S], p1[TW][S];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);
-#pragma unroll
-    for (int i = 0; i < TW; ++i)
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const float* q = pp + (size_t)s * sstride + (size_t)i * 2 * a.max_batch * 8;
-            p0[i][s] = *reinterpret_cast<const float4*>(q);
-            p1[i][s] = *reinterpret_cast<const float4*>(q + 4);
-        }
-    f32x16 acc_h = {0}, acc_l = {0};
+    f32x16 acc_h[2] = {{0}, {0}}, acc_l[2] = {{0}, {0}};
 #pragma unroll
     for (int i = 0; i < TW; ++i) {
         float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < S; ++s) {          // index order: the combine fixes the bits
-            z[0] = fmaf(wn[s], p0[i][s].x, z[0]); z[1] = fmaf(wn[s], p0[i][s].y, z[1]); z[2] = fmaf(wn[s], p0[i][s].z, z[2]); z[3] = fmaf(wn[s], p0[i][s].w, z[3]);
-            z[4] = fmaf(wn[s], p1[i][s].x, z[4]); z[5] = fmaf(wn[s], p1[i][s].y, z[5]); z[6] = fmaf(wn[s], p1[i][s].z, z[6]); z[7] = fmaf(wn[s], p1[i][s].w, z[7]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { z[e] = fmaf(wn[s], p0[i][s][e], z[e]); z[4 + e] = fmaf(wn[s], p1[i][s][e], z[4 + e]); }
         }
         f16x8 zh, zl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { f16 h_, l_; split_hilo(z[e], h_, l_); zh[e] = h_; zl[e] = l_; }
-        const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
-        acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, zh, acc_h, 0, 0, 0);
-        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, zl, acc_l, 0, 0, 0);
+        const f16x8 wf0 = __builtin_bit_cast(f16x8, w0[i]), wf1 = __builtin_bit_cast(f16x8, w1[i]);
+        acc_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, zh, acc_h[0], 0, 0, 0);
+        acc_l[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, zl, acc_l[0], 0, 0, 0);
+        acc_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, zh, acc_h[1], 0, 0, 0);
+        acc_l[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, zl, acc_l[1], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]);
-    __syncthreads();
-    float v[4];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
-    // epilogue coordinates as in dec32_proj_kernel: slot tid & 31, channels n .. n + 3
-    const int sub = tid >> 5;
-    const int nn = rt * 32 + 4 * sub, gb = bt * 32 + (tid & 31);
+        for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = fmaf(acc_l[t][r], 1.0f / 2048.0f, acc_h[t][r]);
+    __syncthreads();
+    // epilogue coordinates: slot tid & 31, rows 4 sub .. 4 sub + 3 of each of the two row tiles (the accumulator rows 4 wave' + i of half-wave hl)
+    const int sub = tid >> 5, gb = bt * 32 + (tid & 31);
+    float v[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[t][i] = ((red[0][t][4 * wave + i][lane] + red[1][t][4 * wave + i][lane]) + red[2][t][4 * wave + i][lane]) + red[3][t][4 * wave + i][lane];
     if (ks > 1) {
-        float* base = a.kpart + (((size_t)bt * n_rt + rt) * ks) * 1024 + tid * 4;
-        {
-            const f32x4 pv4 = {v[0], v[1], v[2], v[3]};
-            float* mine = base + (size_t)ksi * 1024;
+        float* base = a.kpart + (((size_t)bt * H + h) * ks) * 2048 + tid * 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 pv4 = {v[t][0], v[t][1], v[t][2], v[t][3]};
+            float* mine = base + (size_t)ksi * 2048 + t * 1024;
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            int* cnt = a.ticket + bt * n_rt + rt;
+            int* cnt = a.ticket + bt * H + h;
             const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == ks - 1);
             if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -414,30 +454,38 @@ __global__ __launch_bounds__(256, 2) void xabs_vup_kernel(const XabsArgs a, int 
         }
         __syncthreads();
         if (!last_flag) return;
-        float pv[8][4];
+        float pv[4][2][4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float* p = base + (size_t)(s < ks ? s : 0) * 1024;
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pv[s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+            for (int t = 0; t < 2; ++t) {
+                const float* p = base + (size_t)(s < ks ? s : 0) * 2048 + t * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float t = pv[0][i];
+                for (int i = 0; i < 4; ++i) pv[s][t][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
-            for (int s = 1; s < 8; ++s) t += (s < ks) ? pv[s][i] : 0.0f;
-            v[i] = t;
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = pv[0][t][i];
+#pragma unroll
+                for (int s = 1; s < 4; ++s) x += (s < ks) ? pv[s][t][i] : 0.0f;
+                v[t][i] = x;
+            }
     }
     if (gb < a.batch && slot_live(a.seq + gb)) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.bv + nn);
-        const float y[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
-        f16x4 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(y[i], h_, l_); hi[i] = h_; lo[i] = l_; }
-        const size_t o = plane_index(gb, nn, d);
-        *reinterpret_cast<f16x4*>(a.att_hi + o) = hi;
-        *reinterpret_cast<f16x4*>(a.att_lo + o) = lo;
+        for (int t = 0; t < 2; ++t) {
+            const int nn = (2 * h + t) * 32 + 4 * sub;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bv + nn);
+            const float y[4] = {v[t][0] + bv.x, v[t][1] + bv.y, v[t][2] + bv.z, v[t][3] + bv.w};
+            f16x4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(y[i], h_, l_); hi[i] = h_; lo[i] = l_; }
+            const size_t o = plane_index(gb, nn, d);
+            *reinterpret_cast<f16x4*>(a.att_hi + o) = hi;
+            *reinterpret_cast<f16x4*>(a.att_lo + o) = lo;
+        }
     }
 }
 
@@ -456,7 +504,7 @@ void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     static const int hilo = xabs_env("WH_XABS_QLO", 1);       // A/B: Q' as an f16 hi | lo pair (default) or a single f16 plane
-    const dim3 grid(a.n_split, a.batch);
+    const dim3 grid((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits));
     constexpr int lds = xabs_lds_bytes(CW);
     if (hilo) {
         static PerDeviceOnce once;
@@ -483,7 +531,7 @@ void launch_xabs_vup(const XabsArgs& a, int n_bt, hipStream_t st) {
     ProfScope ps_(KK_DEC_XVUP, st);
     // K slices: d / 16 k tiles over 4 waves x ks workgroups, TW tiles per wave; ks = 4 at every supported width (TW = d / 256)
     constexpr int ks = 4;
-    const int nx = (a.d / 32) * ks;
+    const int nx = a.n_head * ks;
     const unsigned grid = (unsigned)(((nx + 7) / 8) * 8 * n_bt);
     switch (a.d / 256) {
         case 2: xabs_vup_kernel<kXabsSplits, 2><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
