@@ -203,7 +203,7 @@ void wh_session_destroy(wh_session* s);
 int wh_session_max_batch(const wh_session* s);
 /* 1: the session's decoder attends over the encoder output directly (weight-absorbed cross-attention: encoder_output_embeds is the
    decoder input in the reference too, Core/Models.swift:986-987), 0: per-layer cross K / V rows are materialised by
-   wh_prepare_decoder_inputs.  Fixed at creation (width supported and max_batch >= 16, or WH_XABS=0 / 1); results agree within the
+   wh_prepare_decoder_inputs.  Fixed at creation (width supported and max_batch >= 48, or WH_XABS=0 / 1); results agree within the
    parity tolerance, bit-identity across batch sizes holds within a mode. */
 int wh_session_cross_attention_mode(const wh_session* s);
 /* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...) */

@@ -416,11 +416,12 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     // Cross-attention path, fixed per session: the absorbed form (xabs.hip) streams the encoder output instead of per-layer K / V rows;
-    // it pays from about 16 slots (three launches per layer instead of one).  WH_XABS=0 / 1 forces the choice (A/B, tests).
+    // it pays from about 48 slots (three launches per layer instead of one, one workgroup per (slot, key split) and CU: measured
+    // large-v3 5.36 -> 4.79 ms per step at 64 slots, 3.65 -> 3.99 at 32; profiles/r04*).  WH_XABS=0 / 1 forces the choice (A/B, tests).
     {
         const char* e_ = getenv("WH_XABS");       // read per session: a process can hold sessions of both modes (tests, A/B)
         const int xabs_mode = e_ ? atoi(e_) : -1;
-        s->use_xabs = !m->xabs.empty() && (xabs_mode < 0 ? max_batch >= 16 : xabs_mode != 0);
+        s->use_xabs = !m->xabs.empty() && (xabs_mode < 0 ? max_batch >= 48 : xabs_mode != 0);
     }
     if (s->use_xabs) {
         const size_t nht = H > 16 ? 2 : 1, S = kXabsSplits;

@@ -268,6 +268,7 @@ struct XabsArgs {
     float* align; const int* align_slot; int n_align;
     const SeqState* seq;
     float* kpart; int* ticket;       // K-slice scratch of xabs_vup (the projection kernels' part / ticket buffers)
+    unsigned long long* dbg;         // WH_DBG=1 timeline stamps of xabs_attn
 };
 bool xabs_supported(int d, int n_head);
 void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);

@@ -134,64 +134,75 @@ __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_attn
-constexpr int kXabsRing = 3;
+constexpr int kXabsHalves = 7;               // LDS ring of half tiles (8 keys): tiles i, i + 1 resident, i + 2 and half of i + 3 in flight
 constexpr int kXabsSpStride = 32 * 17;       // floats per wave partial: [32 heads][16 keys + 1]
 constexpr float kXabsDefer = 8.0f;           // the running maximum moves only when it would grow by more than this (p <= e^8 fits f16)
-__host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsRing * cw * 8192 + 8 * kXabsSpStride * 4 + 1024 + 128; }
+__host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsHalves * cw * 4096 + 8 * kXabsSpStride * 4 + 1024 + 128; }
 
-template <int CW, int NHT, bool HILO>
+template <int CW, int NHT, bool HILO, bool DBG, bool NTL>
 __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
-    constexpr int D = CW * 256, ROWB = D * 2, TILE = 16 * ROWB, KS = D / 32;
+    constexpr int D = CW * 256, ROWB = D * 2, HALF = 8 * ROWB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    float* spart = reinterpret_cast<float*>(smem + kXabsRing * TILE);
-    f16* pfrag = reinterpret_cast<f16*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4);
-    float* alpha_l = reinterpret_cast<float*>(smem + kXabsRing * TILE + 8 * kXabsSpStride * 4 + 1024);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* spart = reinterpret_cast<float*>(smem + kXabsHalves * HALF);
+    f16* pfrag = reinterpret_cast<f16*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4);
+    float* alpha_l = reinterpret_cast<float*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4 + 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: no waterfall loops around the buffer resource / M0
     // workgroup id -> (split, slot): id % 8 is the XCD; an XCD takes ONE split index (two XCDs per split) and whole groups of 4 consecutive
     // slots, whose 32-byte partial sectors share 128-byte lines (part[split][head][c / 8][slot][8]): the lines are assembled in one L2
     const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;
     const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
     const int S = kXabsSplits, H = a.n_head;
     if (b >= a.batch) return;
+    // WH_DBG=1: shader-clock stamps (tools/xabs_timeline.py): 9 entry, 10 slot state known, 11 loop entry, 12 loop exit, 13 partials stored
+#define XPHASE(k) do { if constexpr (DBG) if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 64) \
+        a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    XPHASE(9);
     constexpr int NT = (kCtx + 15) / 16;
     const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
     const int bc = a.cross_div > 1 ? b / a.cross_div : b;
     const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
 
-    // ---- LDS-DMA: piece p of this wave fills LDS bytes [(wave CW + p) 1024 + lane 16, +16) of a tile slot
-    int p_row[CW], p_cb[CW];
+    // ---- LDS-DMA: a 16-key tile is two half tiles of 8 keys; half k (= 2 tile + {0, 1}) lives in ring slot k % 7.  Waves 0-3 fetch the
+    // first half of a tile, waves 4-7 the second (CW pieces of 1 KB each per wave and tile): the two halves of a tile can be requested
+    // at different times, so that a freed tile (two slots) is refilled with the second half of tile i + 3 and the first half of
+    // tile i + 4 - the fetch pipe of the CU (~11 B / clk: the bound of this kernel) always has a request queued behind the one it waits for.
+    const int half_w = wave >> 2, wq = wave & 3;
+    int p_off[CW];                       // byte offset of this lane's 16 bytes inside a tile's rows (loop-invariant)
 #pragma unroll
     for (int p = 0; p < CW; ++p) {
-        const int o = (wave * CW + p) * 1024 + lane * 16;
+        const int o = (wq * CW + p) * 1024 + lane * 16;
         const int row = o / ROWB, slot = (o - row * ROWB) >> 4;
-        p_row[p] = row;
-        p_cb[p] = (slot ^ xswz(row)) << 4;
+        p_off[p] = (half_w * 8 + row) * ROWB + ((slot ^ xswz(half_w * 8 + row)) << 4);
     }
+    int hi_mine = -1;                    // the last tile this wave has requested (wave-uniform)
+    // buffer_load ... lds with a per-tile resource (base = the tile's first row, num_records = bytes to the end of the slot's encoder
+    // output): the per-lane offset is loop-invariant, rows past position 1499 are out of range (nothing is fetched; they are masked
+    // below), and a request costs two scalar instructions beside the load itself (a flat global_load_lds needs a 64-bit per-lane
+    // address per piece: 600 - 800 cycles per tile and wave in the first version's timeline, profiles/r04g_*)
     auto issue = [&](int i) {
-        unsigned char* dst = smem + (i % kXabsRing) * TILE + wave * (CW * 1024);
+        unsigned char* dst = smem + ((2 * i + half_w) % kXabsHalves) * HALF + wq * (CW * 1024);
         const int t16 = (tile_lo + i) * 16;
+#if defined(__HIP_DEVICE_COMPILE__)      // (the buffer-resource builtins do not exist in the host pass, which still has to emit this kernel's launch stub)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(enc) + (size_t)t16 * ROWB, 0, (kCtx - t16) * ROWB, 0x00020000);
 #pragma unroll
-        for (int p = 0; p < CW; ++p) {
-            const int row = min(t16 + p_row[p], kCtx - 1);        // rows past the end re-read the last row (masked below)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(enc + (size_t)row * ROWB + p_cb[p]),
-                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        for (int p = 0; p < CW; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, p_off[p], 0, 0, NTL ? 2 : 0);
+#else
+        (void)dst; (void)t16; (void)p_off;
+#endif
+        hi_mine = i;
+    };
+    auto wait_tile = [&](int k) {        // this wave's pieces of tile k have landed; younger tiles stay in flight (requests return in order)
+        switch (hi_mine - k) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
         }
     };
-    // ---- prologue: Q' fragments of this wave's channel slice (k-steps wave CW + j), the first two tiles, the slot state
-    f16x8 qh[NHT][CW], ql[HILO ? NHT : 1][HILO ? CW : 1];
-    {
-        const size_t qo = ((size_t)b * (NHT * 16) + (lane & 15)) * D + wave * CW * 32 + (lane >> 4) * 8;
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int j = 0; j < CW; ++j) {
-                qh[ht][j] = *reinterpret_cast<const f16x8*>(a.qf_hi + qo + (size_t)ht * 16 * D + j * 32);
-                if constexpr (HILO) ql[ht][j] = *reinterpret_cast<const f16x8*>(a.qf_lo + qo + (size_t)ht * 16 * D + j * 32);
-            }
-    }
-    issue(0);
-    if (n > 1) issue(1);
-    if (n > 2) issue(2);
+    // ---- prologue.  Request order = return order: the slot state first (so that the liveness test does not wait for the tile stream),
+    // then the Q' fragments of this wave's channel slice (k-steps wave CW + j), then the first three and a half tiles.
     const SeqState* sq = a.seq + b;
     const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
     // softmax owner coordinates: lane = key | (head & 3) << 4, wave = head >> 2
@@ -199,6 +210,23 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const bool owner = o_head < 16 * NHT;
     int al_slot = -1;
     if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
+    f16x8 qh[NHT][CW], ql[HILO ? NHT : 1][HILO ? CW : 1];
+    {
+        const size_t qo = ((size_t)b * (NHT * 16) + (lane & 15)) * D + wave * CW * 32 + (lane >> 4) * 8;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                const bool real = ht * 16 + (lane & 15) < H;      // padded heads: no request at all (large-v3: 12 of 32 rows)
+                const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                qh[ht][j] = real ? *reinterpret_cast<const f16x8*>(a.qf_hi + qo + (size_t)ht * 16 * D + j * 32) : zero;
+                if constexpr (HILO) ql[ht][j] = real ? *reinterpret_cast<const f16x8*>(a.qf_lo + qo + (size_t)ht * 16 * D + j * 32) : zero;
+            }
+    }
+    issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 3 && half_w == 0) issue(3);
     if (tid < 32) alpha_l[tid] = 1.0f;
     pfrag[tid] = (f16)0.0f;
     if (!(s_act && !s_done)) {           // workgroup-uniform: a finished slot streams nothing more
@@ -208,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const int pos = min(max(s_ti, 0), kMaxTok - 1);
     float* raw = nullptr;
     if (al_slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + al_slot) * kCtx;
+    XPHASE(10);
 
     f32x16 acc[CW];
 #pragma unroll
@@ -220,15 +249,18 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const int g16 = lane >> 4, sl = lane & 15;
     const int t_key0 = (g16 >> 1) * 8 + (sl >> 2), t_key1 = t_key0 + 4;
     const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
-    const int t_off0 = t_key0 * ROWB + t_b, t_off1 = t_key1 * ROWB + t_b, t_sw0 = xswz(t_key0), t_sw1 = xswz(t_key1);
+    const int t_off0 = (t_key0 & 7) * ROWB + t_b, t_off1 = (t_key1 & 7) * ROWB + t_b, t_sw0 = xswz(t_key0), t_sw1 = xswz(t_key1);
+    // tile i, this lane's half as S-phase reader (key >> 3) and as transpose-read supplier (g16 >> 1)
+    auto s_base = [&](int i) { return smem + ((2 * i + (s_key >> 3)) % kXabsHalves) * HALF + (s_key & 7) * ROWB; };
+    auto t_base = [&](int i) { return smem + ((2 * i + (g16 >> 1)) % kXabsHalves) * HALF; };
 
     // S^T partial of one tile over this wave's channels, [16 keys] x [16 NHT heads]: D[key = 4 (lane >> 4) + r][head = lane & 15]
-    auto s_phase = [&](const unsigned char* tile, float (&sreg)[NHT * 4]) {
+    auto s_phase = [&](const unsigned char* row, float (&sreg)[NHT * 4]) {
         f16x8 af[CW];
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
             const int c = (wave * CW + j) * 4 + s_kg;
-            af[j] = *reinterpret_cast<const f16x8*>(tile + s_key * ROWB + ((c ^ s_sw) << 4));
+            af[j] = *reinterpret_cast<const f16x8*>(row + ((c ^ s_sw) << 4));
         }
         f32x4 sh[NHT], sl_[NHT];
 #pragma unroll
@@ -305,29 +337,42 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     };
 
     // Software pipeline, two barriers per tile:  Y_i = softmax(i) (LDS / VALU latency chain of the owner lanes) beside S(i + 1) (MFMA);
-    // Z_i = partials(i + 1) -> LDS, P V(i).  Tiles i (P V) and i + 1 (S) are resident, tile i + 2 is in flight; tile i + 3 is
-    // requested into tile i's slot at the barrier that ends Z_i.
+    // Z_i = partials(i + 1) -> LDS, P V(i).  Tiles i (P V) and i + 1 (S) are resident, tile i + 2 and the first half of tile i + 3 are in
+    // flight; the barrier that ends Z_i frees tile i's two half slots for the second half of tile i + 3 and the first half of tile i + 4.
     float sreg[NHT * 4];
-    if (n > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory");
-    else if (n > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_tile(0);
     __syncthreads();
-    s_phase(smem, sreg);
+    s_phase(s_base(0), sreg);
     write_partials(sreg);
-    if (n > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n > 1) wait_tile(1);
     __syncthreads();                                      // partials(0) in LDS, tile 1 landed
+    XPHASE(11);
+    // WH_DBG=1: shader-clock stamps of tiles 10 and 11 for waves 0 and 5 of the first 64 workgroups (tools/xabs_timeline.py)
+#define XSTAMP(k) do { if constexpr (DBG) if (a.dbg && (i == 10 || i == 11) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 64) \
+        a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2 + (i - 10)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int i = 0; i < n; ++i) {
-        const unsigned char* tile = smem + (i % kXabsRing) * TILE;
-        if (i + 1 < n) s_phase(smem + ((i + 1) % kXabsRing) * TILE, sreg);
+        XSTAMP(0);
+        if (i + 1 < n) s_phase(s_base(i + 1), sreg);
+        XSTAMP(1);
         if (owner) softmax(i);
+        XSTAMP(2);
         __syncthreads();                                  // C: P^T(i) and the rescale factors are in LDS; partials(i) are consumed
+        XSTAMP(3);
         if (i + 1 < n) write_partials(sreg);
-        pv(tile);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile i + 2 (the only LDS-DMA outstanding) has landed
-        __syncthreads();                                  // D: partials(i + 1) in LDS; everybody is done with tile i
-        if (i + 3 < n) issue(i + 3);
+        XSTAMP(4);
+        pv(t_base(i));
+        XSTAMP(5);
+        if (i + 2 < n) wait_tile(i + 2);
+        XSTAMP(6);
+        __syncthreads();                                  // D: partials(i + 1) in LDS; tile i + 2 landed; everybody is done with tile i
+        XSTAMP(7);
+        const int nx = i + 3 + (1 - half_w);              // waves 4-7: second half of tile i + 3; waves 0-3: first half of tile i + 4
+        if (nx < n) issue(nx);
+        XSTAMP(8);
     }
+#undef XSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XPHASE(12);
     // ---- this split's partial: (m, l) per head, unnormalised O'[head][c] in the order xabs_vup loads B fragments:
     //      part[split][head][c / 8][slot][c & 7]
     if (owner && o_key == 0 && o_head < H) a.ml[((size_t)sp * H + o_head) * a.max_batch + b] = float2{m_run, l_run};
@@ -344,6 +389,9 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
                 }
         }
     }
+    if constexpr (DBG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XPHASE(13);
+#undef XPHASE
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_vup
@@ -501,20 +549,20 @@ void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
     else xabs_qk_kernel<1><<<grid, 256, 0, st>>>(a);
 }
 
+template <int CW, int NHT, bool HILO, bool DBG, bool NTL>
+static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
+    constexpr int lds = xabs_lds_bytes(CW);
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, HILO, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    xabs_attn_kernel<CW, NHT, HILO, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
+}
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     static const int hilo = xabs_env("WH_XABS_QLO", 1);       // A/B: Q' as an f16 hi | lo pair (default) or a single f16 plane
-    const dim3 grid((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits));
-    constexpr int lds = xabs_lds_bytes(CW);
-    if (hilo) {
-        static PerDeviceOnce once;
-        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-        xabs_attn_kernel<CW, NHT, true><<<grid, 512, lds, st>>>(a);
-    } else {
-        static PerDeviceOnce once;
-        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-        xabs_attn_kernel<CW, NHT, false><<<grid, 512, lds, st>>>(a);
-    }
+    static const int nt = xabs_env("WH_XABS_NT", 1);          // non-temporal policy on the encoder-output stream (in flight: 19.2 k vs 18.1 k sequence-steps/s, profiles/r04l_*); 0 = A/B side
+    if (a.dbg) { launch_attn_k<CW, NHT, true, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation (tools/xabs_timeline.py)
+    if (hilo) { if (nt) launch_attn_k<CW, NHT, true, false, true>(a, st); else launch_attn_k<CW, NHT, true, false, false>(a, st); }
+    else launch_attn_k<CW, NHT, false, false, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
