@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
 T_START = time.perf_counter()
 
 
@@ -125,11 +125,12 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
     cnt = (ctypes.c_int32 * nk)()
     api._check(lib.wh_measure_kernels(sess.handle, B, n_meas, avg, cnt))
     avg_len = (n_meas + 1) / 2.0
+    absorbed = lib.wh_session_cross_attention_mode(sess.handle) == 1     # the session's cross-attention streams the encoder output (csrc/xabs.hip)
     table, step_us = {}, {}
     for k, name in enumerate(names):
         if cnt[k] == 0:
             continue
-        bound, amount = algorithmic_work(name, dims, B, avg_len)
+        bound, amount = algorithmic_work(name, dims, B, avg_len, absorbed=absorbed)
         is_dec = name.startswith("dec_") or name == "sampler"
         per_step = cnt[k] / n_meas * decode_steps if is_dec else cnt[k]      # launches in one full hot-path step
         step_us[name] = avg[k] * per_step
@@ -155,7 +156,8 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
         table[name]["traffic"] = traffic.get(name)
     dom = max(step_us, key=step_us.get)
     t = table[dom]
-    return {"kernel": dom, "bound": t["bound"], "achieved": t["achieved"],
+    return {"kernel": dom, "cross_attention": "absorbed (encoder output streamed once per layer, csrc/xabs.hip)" if absorbed else "per-layer K / V rows",
+            "bound": t["bound"], "achieved": t["achieved"],
             "peak": HBM_PEAK_GBS if t["bound"] == "hbm" else MFMA_F16_PEAK_TF, "unit": t["unit"], "frac": t["frac"], "traffic": t["traffic"],
             "avg_us": t["avg_us"], "alg_per_launch": t["alg_per_launch"], "share_of_step_time": t["share_of_step"],
             "sum_kernel_ms_per_step": round(tot / 1e3, 3), "kernels": table,
