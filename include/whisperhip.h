@@ -206,6 +206,9 @@ int wh_session_max_batch(const wh_session* s);
    wh_prepare_decoder_inputs.  Fixed at creation (width supported and max_batch >= 48, or WH_XABS=0 / 1); results agree within the
    parity tolerance, bit-identity across batch sizes holds within a mode. */
 int wh_session_cross_attention_mode(const wh_session* s);
+/* wh_session_create with the cross-attention mode chosen by the caller: -1 automatic (= wh_session_create), 0 K / V rows, 1 absorbed
+   (WH_ERR_INVALID_ARGUMENT when the model width does not support it) */
+int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out);
 /* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...) */
 int wh_debug_peek(wh_session* s, const char* name, void* out_host, size_t nbytes);
 int wh_session_synchronize(wh_session* s);

@@ -10,7 +10,8 @@ one-pass teacher-forced decoder (`DecoderState.forward_full`, pinned to the step
 tests/test_oracle_golden.py).
 
 Per configuration and checked slot:
-  1. stage-isolated  - the oracle decodes from the GPU's own encoder output: teacher-forced logits at positions {0, 1, 2, 3, 129, 222}
+  1. stage-isolated  - the oracle decodes from the GPU's own encoder output: teacher-forced logits at ALL 223 positions (round 4; round 3
+                       sampled {0, 1, 2, 3, 129, 222})
                        within the contract's 1e-3 (BASELINE north_star) of the oracle with Float16 key / value storage (the reference's
                        and the device's cache type), the distance to the fp32-cache oracle measured and asserted at 2 x; alignment
                        rows within 1e-4;
@@ -18,7 +19,7 @@ Per configuration and checked slot:
                        fed with the teacher-forced logits; a difference passes only as a near-tie PROVEN from the oracle's own
                        filtered logits (tests/neartie.py), after which the oracle follows the device's token;
   3. end to end      - the oracle runs its OWN fp64 mel + fp32 encoder from the same PCM: max |delta| of the encoder output and of the
-                       logits is MEASURED, written to gpurun_out/r03_fulldepth_errors.json (committed copy: profiles/), and asserted
+                       logits is MEASURED, written to gpurun_out/r04_fulldepth_errors.json (committed copy: profiles/r04_fulldepth_errors.json), and asserted
                        at <= 2 x the value measured when the test was written (E2E_MEASURED below).  Measured on MI355X (profiles/
                        r03d_fulldepth_errors.json): the encoder output differs from the fp32 oracle by <= 2.4e-3 (mean 3.3e-4; fp16 GEMM
                        operands over 32 layers) and the logits END TO END by 7.3e-4 at large-v3 - inside the contract's 1e-3, which is
@@ -78,7 +79,7 @@ _REPORT = {}
 def _write_report():
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r03_fulldepth_errors.json"), "w") as f:
+    with open(os.path.join(out, "r04_fulldepth_errors.json"), "w") as f:
         json.dump(_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -87,10 +88,11 @@ class FollowingSampler(OD.GreedyTokenSampler):
     step, the oracle's own filtered logits must show a top-2 gap below the logits tolerance with exactly these two ids, or the test
     fails; the oracle then continues on the device's token so that the remaining 200 steps are still compared."""
 
-    def __init__(self, eot, opts, device_tokens, prompt_len):
+    def __init__(self, eot, opts, device_tokens, prompt_len, logit_tol=None):
         super().__init__(0.0, eot, opts)
         self.dev, self.prompt_len = list(device_tokens), prompt_len
         self.near_ties, self.compared, self.worst_lp = [], 0, 0.0
+        self.logit_tol = logit_tol
 
     def sample(self, logits, counter=0):
         tok, lp = super().sample(logits, counter)
@@ -101,7 +103,7 @@ class FollowingSampler(OD.GreedyTokenSampler):
         self.compared += 1
         want = self.dev[k]
         if tok != want:
-            assert _explain(logits, want, tok, 0.0, 0, counter, 5), \
+            assert _explain(logits, want, tok, 0.0, 0, counter, 5, **({} if self.logit_tol is None else {"logit_tol": self.logit_tol})), \
                 f"decode step {counter}: device sampled {want}, oracle {tok}: not a near-tie of the oracle's filtered logits"
             self.near_ties.append(counter)
             x = np.asarray(logits, dtype=np.float64)
@@ -111,21 +113,22 @@ class FollowingSampler(OD.GreedyTokenSampler):
 
 
 class Rig:
-    def __init__(self, name):
+    def __init__(self, name, sd=None, tag=None, config=None, report=None, sample_length=None, mode=None):
+        """sd / tag / config: another weight set on the same architecture (tests/test_gpu_realistic.py); default = the weights bench.py times"""
         t0 = time.time()
         torch.set_num_threads(min(32, os.cpu_count() or 1))              # the oracle's thread count (bench.py's cpu_baseline uses the same)
-        self.name = name
-        self.B, self.check, self.word_ts = CONFIGS[name]
+        self.name = tag or name
+        self.B, self.check, self.word_ts = config or CONFIGS[name]
         self.dims = weights.MODEL_DIMS[name]
-        self.sd = weights.synthetic_state_dict(self.dims, seed=0)         # the weights bench.py times
+        self.sd = sd if sd is not None else weights.synthetic_state_dict(self.dims, seed=0)         # the weights bench.py times
         self.model = api.Model(self.dims, self.sd, alignment_heads=ALIGNMENT_HEADS[name])
         self.om = OracleWhisper(self.dims, self.sd, alignment_heads=ALIGNMENT_HEADS[name])
         self.xs = [synthetic_chunk(1234 + b) for b in range(self.B)]       # bench.py's chunks
         self.st, self.langs = OD.special_tokens_for_vocab(self.dims.n_vocab)
         self.ml = self.dims.is_multilingual
-        kw = dict(**NOFALLBACK, wordTimestamps=self.word_ts)
+        kw = dict(**NOFALLBACK, wordTimestamps=self.word_ts, **({} if sample_length is None else {"sampleLength": sample_length}))
         self.opts, self.oopts = api.DecodingOptions(**kw), OD.DecodingOptions(**kw)
-        self.sess = self._session(self.B, range(self.B))
+        self.sess = self._session(self.B, range(self.B), mode=mode)
         self.prompt = self.sess.prefillPrompt(self.opts)
         assert self.prompt == OD.prefill_prompt(self.oopts, self.st, self.ml)
         self.res = self.sess.decodeText(self.prompt, self.opts, batch=self.B)
@@ -141,12 +144,13 @@ class Rig:
             for b in self.check:
                 self.dev_logits[b][p] = lg[b].copy()
         self.align_tf = {b: self.sess.getAlignmentWeights(b) for b in self.check}
-        self.report = _REPORT.setdefault(name, {"slots": self.B, "checked_slots": self.check, "decoder_inputs": n_in,
-                                                "layers": [self.dims.n_audio_layer, self.dims.n_text_layer]})
+        self.report = (_REPORT if report is None else report).setdefault(self.name, {"slots": self.B, "checked_slots": self.check, "decoder_inputs": n_in,
+                                                "layers": [self.dims.n_audio_layer, self.dims.n_text_layer],
+                                                "cross_attention": "absorbed" if self.sess.crossAttentionMode == 1 else "per-layer K / V rows"})
         self.report["setup_s"] = round(time.time() - t0, 1)
 
-    def _session(self, B, chunk_ids):
-        s = api.Session(self.model, B)
+    def _session(self, B, chunk_ids, mode=None):
+        s = api.Session(self.model, B, crossAttentionMode=mode)
         for b, i in enumerate(chunk_ids):
             s.padOrTrim(self.xs[i], b)
         s.logMelSpectrogram(B); s.encodeFeatures(B); s.prepareDecoderInputs(B)
@@ -176,20 +180,23 @@ def test_fulldepth_stage_isolated_logits_greedy_tokens_and_alignment(rig):
         folded LayerNorm) must stay within the contract's 1e-3;
       * keys / values in fp32 (openai/whisper in fp32): the rounding of 2 x 32 layers of cached keys and values to Float16 is part
         of the error - measured, recorded, asserted at 2 x the recorded value (STAGE_MEASURED)."""
-    worst16, worst32, worst_align, ties, compared, worst_lp = 0.0, 0.0, 0.0, {}, 0, 0.0
+    worst16, worst32, worst_align, ties, compared, worst_lp, sigma = 0.0, 0.0, 0.0, {}, 0, 0.0, 0.0
     per_pos = {}
     for b in rig.check:
         res = rig.res[b]
         enc16 = rig.enc[b].astype(np.float16).astype(np.float32)
         inputs = res.tokens[: rig.n_in]
-        full16 = rig.om.new_state(enc16, kvFloat16=True).forward_full(inputs, logits_at=POSITIONS)
+        full16 = rig.om.new_state(enc16, kvFloat16=True).forward_full(inputs)
         state = rig.om.new_state(enc16)
         full = state.forward_full(inputs)
-        for p in POSITIONS:
+        sig = float(np.std([full[p] for p in POSITIONS]))
+        for p in range(rig.n_in):                    # every position of the run, not a sample of six
             e16 = float(np.abs(rig.dev_logits[b][p] - full16[p]).max())
             e32 = float(np.abs(rig.dev_logits[b][p] - full[p]).max())
-            per_pos[f"slot{b}_pos{p}"] = {"kv_f16_oracle": e16, "kv_f32_oracle": e32}
+            if p in POSITIONS or e32 >= worst32:
+                per_pos[f"slot{b}_pos{p}"] = {"kv_f16_oracle": e16, "kv_f32_oracle": e32}
             worst16, worst32 = max(worst16, e16), max(worst32, e32)
+        sigma = max(sigma, sig)
         rows = [p + 1 for p in POSITIONS if p + 1 < 224]
         worst_align = max(worst_align, float(np.abs(rig.align_tf[b][rows] - state.alignment[rows]).max()))
         if rig.word_ts:           # the rows the fused greedy loop wrote are the rows of the step API
@@ -209,7 +216,8 @@ def test_fulldepth_stage_isolated_logits_greedy_tokens_and_alignment(rig):
     rig.report["stage_isolated"] = {"logits_max_abs_err_vs_f16_kv_oracle": worst16, "logits_max_abs_err_vs_f32_kv_oracle": worst32,
                                     "alignment_rows_max_abs_err": worst_align, "token_logprob_max_abs_err": worst_lp,
                                     "greedy_tokens_compared": compared, "proven_near_ties_at_steps": {str(k): v for k, v in ties.items()},
-                                    "positions": POSITIONS, "per_slot_position": per_pos}
+                                    "positions": f"all {rig.n_in}", "logits_sigma": sigma, "logits_rel_err_vs_f32_kv_oracle": worst32 / sigma,
+                                    "per_slot_position": per_pos}
     _write_report()
     assert worst16 <= 1e-3, (rig.name, worst16)
     m = STAGE_MEASURED[rig.name]
@@ -226,15 +234,15 @@ def test_fulldepth_end_to_end_from_pcm(rig):
         ref_enc = rig.om.encode(omel.log_mel_spectrogram(rig.xs[b], rig.dims.n_mels).astype(np.float32))
         err = np.abs(rig.enc[b] - ref_enc)
         state = rig.om.new_state(ref_enc)
-        full = state.forward_full(rig.res[b].tokens[: rig.n_in], logits_at=POSITIONS)
-        le = max(float(np.abs(rig.dev_logits[b][p] - full[p]).max()) for p in POSITIONS)
+        full = state.forward_full(rig.res[b].tokens[: rig.n_in])
+        le = max(float(np.abs(rig.dev_logits[b][p] - full[p]).max()) for p in range(rig.n_in))      # all 223 positions
         per_slot[str(b)] = {"encoder_max": float(err.max()), "encoder_mean": float(err.mean()), "logits_max": le,
                             "encoder_ref_rms": float(np.sqrt((ref_enc ** 2).mean()))}
         enc_max, enc_mean, logit_max = max(enc_max, float(err.max())), max(enc_mean, float(err.mean())), max(logit_max, le)
     got = dict(encoder_max=enc_max, encoder_mean=enc_mean, logits_max=logit_max)
     rig.report["end_to_end"] = {"encoder_max_abs_err": enc_max, "encoder_mean_abs_err": enc_mean, "logits_max_abs_err": logit_max,
                                 "per_slot": per_slot, "contract_logits_tolerance": 1e-3, "within_contract": bool(logit_max <= 1e-3),
-                                "positions": POSITIONS}
+                                "positions": f"all {rig.n_in}"}
     _write_report()
     for k, v in got.items():
         m = E2E_MEASURED[rig.name][k]
@@ -245,7 +253,7 @@ def test_fulldepth_end_to_end_from_pcm(rig):
 
 def test_fulldepth_batch_invariance(rig):
     last = rig.B - 1            # one slot: a second session must reproduce the run bit for bit
-    s1 = rig._session(1, [last])
+    s1 = rig._session(1, [last], mode=rig.sess.crossAttentionMode)      # (bit-identity across batch sizes holds within a cross-attention mode)
     r1 = s1.decodeText(rig.prompt, rig.opts)[0]
     assert r1.tokens == rig.res[last].tokens
     assert r1.tokenLogProbs == rig.res[last].tokenLogProbs                                   # bit-exact

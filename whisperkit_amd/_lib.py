@@ -122,6 +122,7 @@ SYMBOLS = {
     "wh_session_destroy": (None, [VP]),
     "wh_session_max_batch": (I, [VP]),
     "wh_session_cross_attention_mode": (I, [VP]),
+    "wh_session_create_with_mode": (I, [VP, I, I, PVP]),
     "wh_debug_peek": (I, [VP, C.c_char_p, VP, C.c_size_t]),
     "wh_session_synchronize": (I, [VP]),
     "wh_session_stream": (VP, [VP]),

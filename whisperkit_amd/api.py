@@ -446,10 +446,19 @@ class Model:
 class Session:
     """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
 
-    def __init__(self, model: Model, maxBatch: int = 1):
+    def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None):
+        """crossAttentionMode: None = the library's choice (absorbed from 48 slots at the widths that support it), 0 = per-layer
+        cross K / V rows, 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip)."""
         self.model, self.lib, self.B = model, model.lib, maxBatch
         self.handle = C.c_void_p()
-        _check(self.lib.wh_session_create(model.handle, maxBatch, C.byref(self.handle)))
+        if crossAttentionMode is None:
+            _check(self.lib.wh_session_create(model.handle, maxBatch, C.byref(self.handle)))
+        else:
+            _check(self.lib.wh_session_create_with_mode(model.handle, maxBatch, int(crossAttentionMode), C.byref(self.handle)))
+
+    @property
+    def crossAttentionMode(self) -> int:
+        return int(self.lib.wh_session_cross_attention_mode(self.handle))
 
     def close(self):
         if self.handle:

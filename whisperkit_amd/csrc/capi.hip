@@ -398,7 +398,16 @@ static int dalloc(T** p, size_t n, bool zero = true) {
 }
 #define DALLOC(ptr, n) do { int _r = dalloc(&(ptr), (size_t)(n)); if (_r) { wh_session_destroy(s); return _r; } } while (0)
 
-extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out);
+extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) { return session_create_impl(m, max_batch, -1, out); }
+extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
+    if (cross_attention_mode < -1 || cross_attention_mode > 1)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create_with_mode: cross_attention_mode %d (expected -1 auto, 0 K / V rows, 1 absorbed)", cross_attention_mode);
+    if (cross_attention_mode == 1 && m && m->xabs.empty())
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create_with_mode: the absorbed cross-attention needs a model width of 512 / 768 / 1024 / 1280 (this model: %d)", m->dims.n_text_state);
+    return session_create_impl(m, max_batch, cross_attention_mode, out);
+}
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
     if (max_batch < 1 || max_batch > 128) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 128]", max_batch);
     WH_HIP(hipSetDevice(m->device));
@@ -420,7 +429,7 @@ extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) {
     // large-v3 5.36 -> 4.79 ms per step at 64 slots, 3.65 -> 3.99 at 32; profiles/r04*).  WH_XABS=0 / 1 forces the choice (A/B, tests).
     {
         const char* e_ = getenv("WH_XABS");       // read per session: a process can hold sessions of both modes (tests, A/B)
-        const int xabs_mode = e_ ? atoi(e_) : -1;
+        const int xabs_mode = cross_attention_mode >= 0 ? cross_attention_mode : (e_ ? atoi(e_) : -1);
         s->use_xabs = !m->xabs.empty() && (xabs_mode < 0 ? max_batch >= 48 : xabs_mode != 0);
     }
     if (s->use_xabs) {
