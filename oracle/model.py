@@ -72,8 +72,8 @@ class OracleWhisper:
         return x.numpy()
 
     # ---------------------------------------------------------------- decoder
-    def new_state(self, enc: np.ndarray, kvFloat16: bool = False) -> "DecoderState":
-        return DecoderState(self, enc, kvFloat16)
+    def new_state(self, enc: np.ndarray, kvFloat16: bool = False, crossFloat16: Optional[bool] = None) -> "DecoderState":
+        return DecoderState(self, enc, kvFloat16, crossFloat16)
 
 
 class DecoderState:
@@ -82,19 +82,31 @@ class DecoderState:
 
     MAX_CTX = 224
 
-    def __init__(self, model: OracleWhisper, enc: np.ndarray, kvFloat16: bool = False):
+    def __init__(self, model: OracleWhisper, enc: np.ndarray, kvFloat16: bool = False, crossFloat16: Optional[bool] = None):
         """kvFloat16: keys and values (cross and self) are rounded to Float16 when they are stored - the storage type of the
         reference's caches (FloatType key/value MLMultiArrays, Core/Models.swift:291-323) and of the device's.  Default off: the
-        fp32 model the logits tolerance is quoted against; on for fixtures whose sharpened attention amplifies that rounding."""
+        fp32 model the logits tolerance is quoted against; on for fixtures whose sharpened attention amplifies that rounding.
+        crossFloat16 (default: = kvFloat16): the same choice for the cross-attention keys / values alone - False models the device's
+        weight-absorbed cross-attention, which never materialises (or rounds) them, beside a Float16 self-attention cache."""
         self.m = model
         self.kv16 = kvFloat16
+        self.cross16 = kvFloat16 if crossFloat16 is None else crossFloat16
         w, dims = model.w, model.dims
         xa = _t(enc)
+        rnd = (lambda t: t.half().float()) if self.cross16 else (lambda t: t)
         with torch.no_grad():
-            self.cross_k = [self._store(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.key.weight"])) for i in range(dims.n_text_layer)]
-            self.cross_v = [self._store(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.value.weight"],
-                                                 w[f"decoder.blocks.{i}.cross_attn.value.bias"])) for i in range(dims.n_text_layer)]
+            self.cross_k = [rnd(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.key.weight"])) for i in range(dims.n_text_layer)]
+            self.cross_v = [rnd(F.linear(xa, w[f"decoder.blocks.{i}.cross_attn.value.weight"],
+                                         w[f"decoder.blocks.{i}.cross_attn.value.bias"])) for i in range(dims.n_text_layer)]
         self.reset()
+
+    def fresh_like(self) -> "DecoderState":
+        """A reset decode state of the SAME window: shares the (read-only) cross keys / values instead of recomputing them - what
+        makes beam search and the temperature ladder affordable at 32 layers (every pass / beam needs its own self-attention cache)."""
+        s = object.__new__(DecoderState)
+        s.m, s.kv16, s.cross16, s.cross_k, s.cross_v = self.m, self.kv16, self.cross16, self.cross_k, self.cross_v
+        s.reset()
+        return s
 
     def _store(self, t):
         return t.half().float() if self.kv16 else t
