@@ -117,3 +117,95 @@ def test_whole_results_gathered_and_merged_over_the_c_abi(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == want and got[1] == want
+
+
+# ---- failure behaviour: nothing hangs; a bad hello is dropped; an error on one rank is an error on every rank
+def _timeout_worker(rank, world, port, token, q):
+    import os
+    os.environ["WH_COMM_TIMEOUT_S"] = "3"
+    if token:
+        os.environ["WH_COMM_TOKEN"] = token
+    import time
+    t0 = time.time()
+    try:
+        c = parallel.Comm(world, rank, transport="tcp", tcp_address=f"127.0.0.1:{port}")
+        c.barrier()
+        q.put((rank, "ok", time.time() - t0))
+        c.close()
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, "error: " + str(e)[:160], time.time() - t0))
+
+
+def _run(target, argsets, timeout=60):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(*a, q)) for a in argsets]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    return {g[0]: g[1:] for g in got}
+
+
+def test_missing_peer_is_an_error_after_the_deadline_not_a_hang():
+    got = _run(_timeout_worker, [(0, 2, _free_port(), "")])
+    status, dt = got[0]
+    assert status.startswith("error") and "0 of 1 peers joined" in status and dt < 20, got
+
+
+def test_wrong_job_token_is_refused_on_both_sides():
+    port = _free_port()
+    got = _run(_timeout_worker, [(0, 2, port, "job-a"), (1, 2, port, "job-b")])
+    assert got[0][0].startswith("error") and got[1][0].startswith("error"), got
+    assert max(got[0][1], got[1][1]) < 20
+
+
+def _stray_then_join_worker(rank, world, port, q):
+    import os
+    import time
+    os.environ["WH_COMM_TIMEOUT_S"] = "20"
+    if rank == 1:                         # a stray connection first: four garbage bytes, then silence
+        time.sleep(0.5)
+        for _ in range(50):
+            try:
+                sk = socket.create_connection(("127.0.0.1", port), timeout=1)
+                break
+            except OSError:
+                time.sleep(0.1)
+        sk.sendall(b"\xff\xff\xff\x7f" + b"x" * 32)
+        sk.close()
+    c = parallel.Comm(world, rank, transport="tcp", tcp_address=f"127.0.0.1:{port}")
+    c.barrier()
+    q.put((rank, "ok", 0.0))
+    c.close()
+
+
+def test_bad_hello_is_dropped_and_the_real_peer_still_joins():
+    port = _free_port()
+    got = _run(_stray_then_join_worker, [(r, 2, port) for r in range(2)])
+    assert got[0][0] == "ok" and got[1][0] == "ok", got
+
+
+def _poison_worker(rank, world, port, tok_path, q):
+    import ctypes as C
+    from whisperkit_amd import api
+    c = parallel.Comm(world, rank, transport="tcp", tcp_address=f"127.0.0.1:{port}")
+    lib = c.lib
+    ordered, _ = parallel.transcribe_chunked_sharded(_FakeSession(api.Tokenizer(tok_path)), _long_audio())      # local results (single process)
+    handles = (C.c_void_p * 1)(ordered[0][1]._handle if rank == 0 else None)      # rank 1 has nothing it can serialise
+    idx = (C.c_int32 * 1)(rank)
+    out = (C.c_void_p * 8)(); oidx = (C.c_int32 * 8)(); n = C.c_int()
+    rc = lib.wh_comm_gather_transcriptions(c.handle, handles, idx, 1, out, oidx, 8, C.byref(n))
+    q.put((rank, rc, lib.wh_last_error().decode()[:120]))
+    c.close()
+
+
+def test_a_rank_that_cannot_serialise_fails_every_rank_together(tmp_path):
+    from whisperkit_amd import synth
+    tok_path = synth.write_kat_tokenizer(str(tmp_path), 51865)
+    port = _free_port()
+    got = _run(_poison_worker, [(r, 2, port, tok_path) for r in range(2)], timeout=120)
+    assert got[0][0] != 0 and got[1][0] != 0, got                    # both return the error, nobody is left inside the collective
+    assert "rank 1" in got[0][1] and "this rank" in got[1][1], got

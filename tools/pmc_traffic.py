@@ -11,7 +11,8 @@ import re
 import sys
 
 KIND = [  # (regex on the kernel name, kernel kind of bench.py)
-    (r"dec_cross_attn_kernel", "dec_cross_attn"), (r"dec_self_attn_kernel", "dec_self_attn"),
+    (r"dec_cross_attn_kernel", "dec_cross_attn"), (r"xabs_attn_kernel", "dec_cross_attn"), (r"xabs_qk_kernel", "dec_xabs_qk"),
+    (r"xabs_vup_kernel", "dec_xabs_vup"), (r"dec_self_attn_kernel", "dec_self_attn"),
     (r"dec32_proj_kernel<0,", "dec_proj_qkv"), (r"dec32_proj_kernel<1,", "dec_proj_cq"),
     (r"dec32_proj_kernel<2, true", "dec_proj_resid_avg"), (r"dec32_proj_kernel<2, false", "dec_proj_fc2"),
     (r"dec32_proj_kernel<3,", "dec_proj_fc1"), (r"dec32_proj_kernel<4,", "dec_proj_logits"),

@@ -13,13 +13,23 @@
 //                 dependency on it and single-GPU hosts never load it.  The 128-byte id is RCCL's ncclUniqueId, created on rank 0
 //                 and handed to the other ranks by the caller (environment, file, socket - as with any NCCL bootstrap).
 //   WH_COMM_TCP   a star over TCP on the host (rank 0 listens; gather then broadcast): for hosts without RCCL, CPU-only tests and
-//                 the two-ranks-on-one-GPU rehearsal, where RCCL refuses duplicate devices.  The id carries "host:port".
+//                 the two-ranks-on-one-GPU rehearsal, where RCCL refuses duplicate devices.  The id carries "host:port" or
+//                 "host:port#token" (every rank derives it from the same address; the token - up to 32 characters, from the caller or
+//                 the launcher's WH_COMM_TOKEN - is checked in every peer's hello, so a stray connection or a peer of another job
+//                 cannot take a rank slot; a bad hello is dropped and the accept loop goes on).  Loopback / trusted networks only all
+//                 the same: the payload is not encrypted.
+//
+// Failure behaviour (round-3 ADVICE): nothing blocks for ever on the TCP transport - accept, connect, send and receive carry a deadline
+// (WH_COMM_TIMEOUT_S, default 120 s) and fail with a status; a rank whose LOCAL step fails before a collective still takes part in it
+// and sends a poison size, so every rank returns an error together instead of the healthy ones waiting for the missing one.
 #include <arpa/inet.h>
 #include <dlfcn.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -48,6 +58,7 @@ struct RcclApi {
     int (*CommDestroy)(RcclComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 constexpr int kRcclUint8 = 1;   // ncclUint8
@@ -66,13 +77,31 @@ const RcclApi* rccl_api(std::string* why) {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
-        if (!api.ok()) err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
+        if (!api.ok()) { err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather"; return; }
+        // the four entry points are declared by hand above (128-byte id by value, ncclUint8 = 1): stable since NCCL 2.0, checked here
+        int ver = 0;
+        if (api.GetVersion && api.GetVersion(&ver) == 0 && ver < 2000) {
+            err = "librccl.so reports version " + std::to_string(ver) + " (< 2.0: unknown ABI)";
+            api.AllGather = nullptr;
+        }
     });
     if (!api.ok()) { if (why) *why = err; return nullptr; }
     return &api;
 }
 
-// ---- TCP helpers (blocking, whole buffers)
+// ---- TCP helpers (whole buffers; every socket carries SO_RCVTIMEO / SO_SNDTIMEO, so a dead peer is an error after the deadline)
+int comm_timeout_s() {
+    static const int t = [] { const char* e = getenv("WH_COMM_TIMEOUT_S"); const int v = e ? atoi(e) : 120; return v > 0 ? v : 120; }();
+    return t;
+}
+void set_deadlines(int fd) {
+    timeval tv{};
+    tv.tv_sec = comm_timeout_s();
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+constexpr int kTokenBytes = 16;
 bool send_all(int fd, const void* p, size_t n) {
     const char* c = static_cast<const char*>(p);
     while (n) { ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) { if (errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
@@ -119,18 +148,29 @@ extern "C" int wh_comm_unique_id(int transport, const char* address, uint8_t* id
         return WH_OK;
     }
     if (transport != WH_COMM_TCP) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: unknown transport %d", transport);
-    if (!address || !strchr(address, ':') || strlen(address) >= WH_COMM_ID_BYTES)
+    if (!address || !strchr(address, ':') || strlen(address) + 2 + 2 * kTokenBytes >= WH_COMM_ID_BYTES)
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: the TCP transport needs \"host:port\" of rank 0");
-    strcpy(reinterpret_cast<char*>(id), address);
+    std::string a(address);
+    if (a.find('#') == std::string::npos) {          // the job's token: "host:port#token" from the caller, or WH_COMM_TOKEN from the launcher's environment
+        const char* t = getenv("WH_COMM_TOKEN");
+        if (t && *t) { a += '#'; a.append(t, strnlen(t, 2 * kTokenBytes)); }
+    }
+    if (a.size() >= WH_COMM_ID_BYTES) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_unique_id: address + token exceed %d bytes", WH_COMM_ID_BYTES - 1);
+    strcpy(reinterpret_cast<char*>(id), a.c_str());
     return WH_OK;
 }
 
 static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
     std::string addr(reinterpret_cast<const char*>(id), strnlen(reinterpret_cast<const char*>(id), WH_COMM_ID_BYTES));
+    std::string token;
+    const size_t hash = addr.find('#');
+    if (hash != std::string::npos) { token = addr.substr(hash + 1); addr.resize(hash); }
+    token.resize(2 * kTokenBytes, '0');
     const size_t colon = addr.rfind(':');
     if (colon == std::string::npos) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: TCP id is not host:port");
     const std::string host = addr.substr(0, colon), port = addr.substr(colon + 1);
     const int one = 1;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(comm_timeout_s());
     if (c->rank == 0) {
         addrinfo hints{}, *res = nullptr;
         hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM; hints.ai_flags = AI_PASSIVE;
@@ -141,15 +181,30 @@ static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
         freeaddrinfo(res);
         if (!ok) return set_error(WH_ERR_HIP, "wh_comm_create: rank 0 cannot listen on %s: %s", addr.c_str(), strerror(errno));
         c->socks.assign(c->world, -1);
-        for (int k = 1; k < c->world; ++k) {
+        int joined = 0;
+        while (joined < c->world - 1) {
+            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+            pollfd pf{c->listen_fd, POLLIN, 0};
+            if (left <= 0 || ::poll(&pf, 1, (int)std::min<long long>(left, 1000)) < 0)
+                return set_error(WH_ERR_HIP, "wh_comm_create: %d of %d peers joined within %d s", joined, c->world - 1, comm_timeout_s());
+            if (!(pf.revents & POLLIN)) continue;
             const int fd = ::accept(c->listen_fd, nullptr, nullptr);
+            if (fd < 0) continue;
+            set_deadlines(fd);
+            // hello = rank + the job's token; anything else (a stray connection, a peer of another job, a duplicate) is dropped and
+            // the loop keeps accepting - one bad hello must not abort the communicator while the real peers are still on their way
             int32_t peer = -1;
-            if (fd < 0 || !recv_all(fd, &peer, 4) || peer < 1 || peer >= c->world || c->socks[peer] >= 0) {
-                if (fd >= 0) ::close(fd);
-                return set_error(WH_ERR_HIP, "wh_comm_create: bad hello from a peer (rank %d)", peer);
+            char tok[2 * kTokenBytes];
+            if (!recv_all(fd, &peer, 4) || !recv_all(fd, tok, sizeof(tok)) || memcmp(tok, token.data(), sizeof(tok)) != 0 || peer < 1 ||
+                peer >= c->world || c->socks[peer] >= 0) {
+                ::close(fd);
+                continue;
             }
             setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            const int32_t ack = 1;
+            if (!send_all(fd, &ack, 4)) { ::close(fd); continue; }
             c->socks[peer] = fd;
+            ++joined;
         }
         return WH_OK;
     }
@@ -157,8 +212,7 @@ static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
     hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
     if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) || !res) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_create: cannot resolve %s", addr.c_str());
     int fd = -1;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(60);      // rank 0 may not be listening yet
-    while (true) {
+    while (true) {                           // rank 0 may not be listening yet
         fd = ::socket(res->ai_family, SOCK_STREAM, 0);
         if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
         if (fd >= 0) ::close(fd);
@@ -167,10 +221,15 @@ static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
     freeaddrinfo(res);
-    if (fd < 0) return set_error(WH_ERR_HIP, "wh_comm_create: rank %d cannot reach rank 0 at %s", c->rank, addr.c_str());
+    if (fd < 0) return set_error(WH_ERR_HIP, "wh_comm_create: rank %d cannot reach rank 0 at %s within %d s", c->rank, addr.c_str(), comm_timeout_s());
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    set_deadlines(fd);
     const int32_t me = c->rank;
-    if (!send_all(fd, &me, 4)) { ::close(fd); return set_error(WH_ERR_HIP, "wh_comm_create: hello to rank 0 failed"); }
+    int32_t ack = 0;
+    if (!send_all(fd, &me, 4) || !send_all(fd, token.data(), 2 * kTokenBytes) || !recv_all(fd, &ack, 4) || ack != 1) {
+        ::close(fd);
+        return set_error(WH_ERR_HIP, "wh_comm_create: rank 0 did not accept the hello of rank %d (wrong job token, duplicate rank, or no answer within %d s)", c->rank, comm_timeout_s());
+    }
     c->socks.assign(1, fd);
     return WH_OK;
 }
@@ -313,23 +372,30 @@ extern "C" int wh_comm_gather_transcriptions(wh_comm* c, const wh_transcription*
     if (!c || (n_local > 0 && (!local || !chunk_indices)) || !all_out || !n_out || n_local < 0)
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_comm_gather_transcriptions: invalid argument");
     WH_TRY
-    // payload = n x [int32 chunk index, int32 json bytes, json]
+    // payload = n x [int32 chunk index, int32 json bytes, json].  A rank that cannot serialise its results still takes part in the
+    // size all-gather and sends -1: every rank then returns the error together (returning early would leave the others blocked in
+    // the collective for ever).
     std::string payload;
-    for (int i = 0; i < n_local; ++i) {
+    int bad = -1;
+    for (int i = 0; i < n_local && bad < 0; ++i) {
         const int need = wh_transcription_to_json(local[i], nullptr, 0);
-        if (need < 0) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: result %d cannot be serialised", i);
+        if (need < 0) { bad = i; break; }
         std::string js((size_t)need + 1, '\0');
         const int got = wh_transcription_to_json(local[i], js.data(), need + 1);
-        if (got < 0) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: result %d cannot be serialised", i);
+        if (got < 0) { bad = i; break; }
         js.resize((size_t)need);
         const int32_t head[2] = {chunk_indices[i], (int32_t)js.size()};
         payload.append(reinterpret_cast<const char*>(head), sizeof(head));
         payload += js;
     }
     std::vector<int64_t> sizes((size_t)c->world);
-    const int64_t mine = (int64_t)payload.size();
+    const int64_t mine = bad >= 0 ? -1 : (int64_t)payload.size();
     int r = wh_comm_all_gather(c, &mine, sizes.data(), sizeof(mine));
     if (r) return r;
+    for (int k = 0; k < c->world; ++k)
+        if (sizes[k] < 0)
+            return k == c->rank ? set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: result %d of this rank cannot be serialised", bad)
+                                : set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_comm_gather_transcriptions: rank %d could not serialise its results", k);
     const size_t cap = (size_t)std::max<int64_t>(*std::max_element(sizes.begin(), sizes.end()), 1);
     payload.resize(cap, '\0');
     std::string all(cap * (size_t)c->world, '\0');

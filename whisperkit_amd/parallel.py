@@ -8,7 +8,7 @@ tests); ~1 KB per chunk, so it is latency-bound and never bandwidth-bound.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -30,13 +30,16 @@ class Comm:
     star for CPU-only hosts and several ranks on one GPU (`transport="tcp"`).  `exchange_id(id_bytes) -> id_bytes` hands rank 0's
     128-byte id to the other ranks (any out-of-band channel: here a torch.distributed broadcast or the environment)."""
 
-    def __init__(self, world_size: int, rank: int, transport: str = "rccl", device: int = 0, tcp_address: str = "127.0.0.1:29533",
+    def __init__(self, world_size: int, rank: int, transport: str = "rccl", device: Optional[int] = None, tcp_address: str = "127.0.0.1:29533",
                  exchange_id=None):
         import ctypes as C
 
         from . import _lib as L
         self._C, self._L, self.lib = C, L, L.load()
         self.transport = L.COMM_RCCL if transport == "rccl" else L.COMM_TCP
+        if self.transport == L.COMM_RCCL and device is None:
+            raise ValueError("an RCCL communicator needs the rank's device (its LOCAL_RANK): every rank defaulting to GPU 0 is refused by RCCL")
+        device = 0 if device is None else int(device)
         ident = (C.c_uint8 * L.COMM_ID_BYTES)()
         if world_size > 1:
             if rank == 0 or self.transport == L.COMM_TCP:
