@@ -288,6 +288,9 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert len(allrecs) == total and [r["chunk_index"] for r in allrecs] == list(range(total)), (len(allrecs), world, total)
+    if rank == 0 and getattr(args, "dump_records", None):
+        with open(args.dump_records, "w") as f:
+            json.dump([{"chunk_index": r["chunk_index"], "tokens": r["tokens"], "steps": r["steps"], "avg_logprob": r["avg_logprob"]} for r in allrecs], f)
     log(f"{model_name}: timed region done: {elapsed:.3f} s for {steps} steps of {total} chunks ({n_local} on this rank), {F} batches in flight")
     dec_steps = [r.steps for r in res] if res else [min(args.sample_length, 224) - 1]
     audio_s = total * 30.0 * steps
@@ -451,6 +454,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered result records of the last timed step (chunk index, "
+                    "token ids, steps) to this JSON file: the N-rank rehearsal compares them with a 1-rank run (tests/test_gpu_round4.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -1,0 +1,89 @@
+"""Round-4 GPU tests: the 8-rank strong-scaling rehearsal on one GPU under the driver's launch line (VERDICT r03 "next round" 6) and the
+failure behaviour of the RCCL transport of wh_comm_* when a communicator cannot form."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, nproc, port, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--model", "tiny.en", "--batch", "8", "--inflight", "1", "--steps", "8", "--warmup", "1",
+            "--no-cpu-baseline", "--no-roofline", "--no-other-configs", "--sample-length", "32"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_eight_ranks_on_one_gpu_strong_scaling_rehearsal(tmp_path):
+    """BASELINE configs[3]'s shape (a step's chunks block-partitioned over 8 ranks, G = 8 consecutive steps packed into one device batch
+    per rank, the per-step result records all-gathered through wh_comm_*) executed with 8 processes on the ONE GPU of the box, under the
+    driver's launch line `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` (the library's TCP transport: RCCL
+    refuses duplicate devices).  The gathered records of a step must equal the records of the same step computed by one rank.  This
+    is a rehearsal of the control flow, not a measurement: no 1 -> 8 GPU curve exists."""
+    one = str(tmp_path / "one.json")
+    eight = str(tmp_path / "eight.json")
+    l1 = _bench(["--dump-records", one], 1, 0)
+    l8 = _bench(["--dump-records", eight, "--single-device", "--dist-backend", "gloo"], 8, 29581)
+    assert l8["n_gpus"] == 8 and l8["scaling"] == "strong" and l8["config"]["chunks_per_step"] == 8 and l8["config"]["chunks_per_gpu"] == 1
+    assert l8["config"]["steps_per_device_batch"] == 8 and l8["config"]["device_batch_slots"] == 8
+    assert l8["config"]["result_gather"].startswith("wh_comm_gather_records"), l8["config"]["result_gather"]
+    assert l1["config"]["chunks_per_gpu"] == 8 and l1["config"]["steps_per_device_batch"] == 1
+    r1, r8 = json.load(open(one)), json.load(open(eight))
+    assert [r["chunk_index"] for r in r8] == list(range(8))
+    assert [(r["chunk_index"], r["tokens"], r["steps"]) for r in r1] == [(r["chunk_index"], r["tokens"], r["steps"]) for r in r8]
+
+
+_DUP = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from whisperkit_amd import parallel
+rank = int(sys.argv[1]); path = sys.argv[2]
+def exchange(raw):
+    if rank == 0:
+        open(path + ".tmp", "wb").write(raw); os.replace(path + ".tmp", path); return raw
+    for _ in range(600):
+        if os.path.exists(path): return open(path, "rb").read()
+        time.sleep(0.05)
+    raise SystemExit("no id")
+t0 = time.time()
+try:
+    c = parallel.Comm(2, rank, transport="rccl", device=0, exchange_id=exchange)
+    print("CREATED", flush=True)
+    c.close()
+except Exception as e:
+    print("STATUS", round(time.time() - t0, 1), str(e)[:200].replace("\n", " "), flush=True)
+"""
+
+
+def test_rccl_communicator_that_cannot_form_fails_with_a_status(tmp_path):
+    """Two ranks that both name GPU 0 (a rank / device mismatch: the only multi-rank RCCL call a one-GPU box can make): ncclCommInitRank
+    must come back with an error that wh_comm_create turns into a status and a message - not a hang.  Every rank also refuses an RCCL
+    communicator without an explicit device (parallel.Comm)."""
+    from whisperkit_amd import parallel
+    with pytest.raises(ValueError):
+        parallel.Comm(2, 0, transport="rccl", exchange_id=lambda raw: raw)
+    script = tmp_path / "dup.py"
+    script.write_text(_DUP % ROOT)
+    idf = str(tmp_path / "id.bin")
+    env = dict(os.environ, PYTHONPATH=ROOT, NCCL_DEBUG="WARN")
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), idf], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out = "HANG"
+        outs.append(out)
+    assert all("STATUS" in o for o in outs), outs          # an error status on both ranks, no hang, no communicator
+    assert all("ncclCommInitRank failed" in o or "RCCL" in o for o in outs), outs
