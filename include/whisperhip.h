@@ -297,6 +297,26 @@ typedef struct wh_progress {
 typedef int (*wh_progress_fn)(void* user, const wh_progress* progress);
 int wh_session_set_progress_callback(wh_session* s, wh_progress_fn fn, void* user);
 
+/* The window-level extension points of TranscribeTask (Core/TranscribeTask.swift), for hosts that use the library's own orchestrator
+ * (wh_transcribe, wh_transcribe_batch, wh_transcribe_chunked) instead of a Swift TranscribeTask of their own.  All are optional (NULL);
+ * they run on the calling thread; `audio_index` is the index of the audio in the call's batch (0 for wh_transcribe).
+ *   window_preprocess   TranscribeTask.windowPreprocess (:42-46, called at :130): after padOrTrim of a window, before the decoder
+ *                       pipeline runs on it; `samples` are the window's segment_size samples (the zero padding to 480000 is implied)
+ *   window_postprocess  TranscribeTask.windowPostProcess (:49-55, called at :246): the window's segments are segments
+ *                       [first_segment, first_segment + n_segments) of `t`; the hook may change their times
+ *                       (wh_transcription_set_segment_times) and returns how many of them to KEEP (0 .. n_segments, a negative value
+ *                       keeps all): the others are removed before segment discovery and never reach the result
+ *   segment_discovery   SegmentDiscoveryCallback (Core/Models.swift:668, called at :260) with the window's final segments
+ * Windows without segments call neither of the last two (`guard let currentSegments`, :239-242). */
+typedef struct wh_window_hooks {
+    void (*window_preprocess)(void* user, int audio_index, const float* samples, int seek, int segment_size);
+    int (*window_postprocess)(void* user, int audio_index, int seek, int segment_size, wh_transcription* t, int first_segment, int n_segments);
+    void (*segment_discovery)(void* user, int audio_index, const wh_transcription* t, int first_segment, int n_segments);
+    void* user;
+} wh_window_hooks;
+int wh_session_set_window_hooks(wh_session* s, const wh_window_hooks* hooks);   /* copied; NULL removes them */
+int wh_transcription_set_segment_times(wh_transcription* t, int i, float start, float end);
+
 /* TextDecoding.decodeText (Core/TextDecoder.swift:541-855) for slots [0, batch), whole token loop on device.
  * temperatures[b] is the sampler temperature of slot b; active[b]==0 skips the slot (may be NULL = all active). */
 int wh_decode_text(wh_session* s, int batch, const wh_decoding_options* opt, const wh_special_tokens* st,

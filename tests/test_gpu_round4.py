@@ -87,3 +87,51 @@ def test_rccl_communicator_that_cannot_form_fails_with_a_status(tmp_path):
         outs.append(out)
     assert all("STATUS" in o for o in outs), outs          # an error status on both ranks, no hang, no communicator
     assert all("ncclCommInitRank failed" in o or "RCCL" in o for o in outs), outs
+
+
+def test_window_hooks_of_the_native_orchestrator():
+    """TranscribeTask.windowPreprocess / windowPostProcess / segmentDiscoveryCallback (Core/TranscribeTask.swift:42-55,130,246,260) as
+    hooks of wh_transcribe*: the pre-process hook sees every window's samples before the pipeline runs, segment discovery sees exactly
+    the segments that end up in the result, a post-process hook that drops a window's last segment (and shifts the first one's
+    times) removes its tokens from the result as well."""
+    import numpy as np
+    from whisperkit_amd import api, weights
+    from whisperkit_amd.synth import synthetic_chunk
+    dims = weights.MODEL_DIMS["test-micro"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
+    audio = np.concatenate([synthetic_chunk(61), synthetic_chunk(62), synthetic_chunk(63)[:240000]])
+    opts = api.DecodingOptions(sampleLength=14, firstTokenLogProbThreshold=None, compressionRatioThreshold=None, logProbThreshold=None,
+                               temperatureFallbackCount=0)
+    sess = api.Session(model, 1)
+    plain = sess.transcribe([audio], opts)[0]
+    assert len(plain.seeks) == 3 and len(plain.segments) >= 3
+    pre, found = [], []
+    sess.setWindowHooks(windowPreprocess=lambda ai, x, seek, size: pre.append((ai, seek, size, float(x[0]), float(x[-1]))),
+                        segmentDiscovery=lambda ai, segs: found.extend(segs))
+    hooked = sess.transcribe([audio], opts)[0]
+    assert hooked.tokens == plain.tokens and hooked.seeks == plain.seeks                     # observers change nothing
+    assert [(p[0], p[1]) for p in pre] == [(0, s) for s in plain.seeks]
+    for (_, seek, size, x0, x1) in pre:
+        assert size == min(480000, len(audio) - seek) and x0 == float(audio[seek]) and x1 == float(audio[seek + size - 1])
+    assert [(g.seek, g.tokens, g.start, g.end) for g in found] == [(g.seek, g.tokens, g.start, g.end) for g in plain.segments]
+    by_window = {}
+    for g in plain.segments:
+        by_window.setdefault(g.seek, []).append(g)
+
+    def post(ai, seek, size, segs, set_times):
+        assert [g.tokens for g in segs] == [g.tokens for g in by_window[seek]]
+        set_times(0, segs[0].start + 100.0, segs[0].end + 100.0)
+        return max(len(segs) - 1, 1)                                                            # drop the window's last segment (keep at least one)
+    found.clear()
+    sess.setWindowHooks(windowPostProcess=post, segmentDiscovery=lambda ai, segs: found.extend(segs))
+    cut = sess.transcribe([audio], opts)[0]
+    want = [g for w in by_window.values() for g in w[:max(len(w) - 1, 1)]]
+    assert [g.tokens for g in cut.segments] == [g.tokens for g in want] == [g.tokens for g in found]
+    assert cut.tokens == [t for g in want for t in g.tokens]                                  # the dropped segments' tokens are gone too
+    firsts = {w[0].seek: w[0] for w in by_window.values()}
+    for g in cut.segments:
+        if g.tokens == firsts[g.seek].tokens:
+            assert g.start == pytest.approx(firsts[g.seek].start + 100.0) and g.end == pytest.approx(firsts[g.seek].end + 100.0)
+    sess.setWindowHooks()
+    assert sess.transcribe([audio], opts)[0].tokens == plain.tokens
+    sess.close(); model.close()

@@ -74,6 +74,14 @@ class WhProgress(C.Structure):
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(WhProgress))
+WINDOW_PRE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int)
+WINDOW_POST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int)
+SEGMENT_DISCOVERY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+class WhWindowHooks(C.Structure):
+    _fields_ = [("window_preprocess", WINDOW_PRE_FN), ("window_postprocess", WINDOW_POST_FN), ("segment_discovery", SEGMENT_DISCOVERY_FN),
+                ("user", C.c_void_p)]
 # wh_logits_filter_fn / wh_token_sampler_fn: LogitsFiltering.filterLogits / TokenSampling.update as C callbacks (wh_decode_text_custom)
 LOGITS_FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.c_int32)
 TOKEN_SAMPLER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int32,
@@ -122,6 +130,8 @@ SYMBOLS = {
     "wh_session_destroy": (None, [VP]),
     "wh_session_max_batch": (I, [VP]),
     "wh_session_cross_attention_mode": (I, [VP]),
+    "wh_session_set_window_hooks": (I, [VP, C.POINTER(WhWindowHooks)]),
+    "wh_transcription_set_segment_times": (I, [VP, I, F, F]),
     "wh_session_create_with_mode": (I, [VP, I, I, PVP]),
     "wh_debug_peek": (I, [VP, C.c_char_p, VP, C.c_size_t]),
     "wh_session_synchronize": (I, [VP]),

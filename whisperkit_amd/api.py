@@ -495,6 +495,53 @@ class Session:
         self._progress = L.PROGRESS_FN(tramp)      # keep the thunk alive
         _check(self.lib.wh_session_set_progress_callback(self.handle, self._progress, None))
 
+    def setWindowHooks(self, windowPreprocess=None, windowPostProcess=None, segmentDiscovery=None):
+        """The window-level extension points of TranscribeTask for the library's own orchestrator (transcribe / transcribeChunked):
+          windowPreprocess(audioIndex, samples: np.ndarray, seek, segmentSize)                  TranscribeTask.windowPreprocess (:42-46)
+          windowPostProcess(audioIndex, seek, segmentSize, segments, setTimes) -> int | None    TranscribeTask.windowPostProcess (:49-55):
+              `segments` = the window's TranscriptionSegments, setTimes(k, start, end) edits segment k of them; return how many to keep
+              (None = all)
+          segmentDiscovery(audioIndex, segments)                                                SegmentDiscoveryCallback (Models.swift:668)
+        All None removes the hooks."""
+        if windowPreprocess is None and windowPostProcess is None and segmentDiscovery is None:
+            self._hooks = None
+            _check(self.lib.wh_session_set_window_hooks(self.handle, None))
+            return
+        lib = self.lib
+
+        def segments_of(t, first, n):
+            tp, lp, nn = L.PI32(), L.PF(), C.c_int()
+            _check(lib.wh_transcription_tokens(t, C.byref(tp), C.byref(lp), C.byref(nn)))
+            out = []
+            for i in range(first, first + n):
+                g = L.WhSegment()
+                _check(lib.wh_transcription_segment(t, i, C.byref(g)))
+                out.append(TranscriptionSegment(g.id, g.seek, g.start, g.end, [tp[k] for k in range(g.token_offset, g.token_offset + g.n_tokens)],
+                                                [lp[k] for k in range(g.token_offset, g.token_offset + g.n_tokens)], g.temperature, g.avg_logprob,
+                                                g.compression_ratio, g.no_speech_prob, [], ""))
+            return out
+
+        def pre(_u, ai, ptr, seek, size):
+            windowPreprocess(ai, np.ctypeslib.as_array(ptr, shape=(size,)).copy() if size > 0 else np.zeros(0, np.float32), seek, size)
+
+        def post(_u, ai, seek, size, t, first, n):
+            t = C.c_void_p(t)
+            r = windowPostProcess(ai, seek, size, segments_of(t, first, n),
+                                  lambda k, a, b: _check(lib.wh_transcription_set_segment_times(t, first + k, a, b)))
+            return -1 if r is None else int(r)
+
+        def disc(_u, ai, t, first, n):
+            segmentDiscovery(ai, segments_of(C.c_void_p(t), first, n))
+        h = L.WhWindowHooks()
+        if windowPreprocess is not None:
+            h.window_preprocess = L.WINDOW_PRE_FN(pre)
+        if windowPostProcess is not None:
+            h.window_postprocess = L.WINDOW_POST_FN(post)
+        if segmentDiscovery is not None:
+            h.segment_discovery = L.SEGMENT_DISCOVERY_FN(disc)
+        self._hooks = h                       # keeps the thunks alive
+        _check(self.lib.wh_session_set_window_hooks(self.handle, C.byref(h)))
+
     # ---- AudioProcessing.padOrTrimAudio
     def padOrTrim(self, audio, slot: int = 0):
         a = np.ascontiguousarray(audio, dtype=np.float32)

@@ -669,6 +669,8 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             AudioJob& j = jobs[slot_job[b]];
             int r = wh_set_audio(s, b, j.pcm + j.cur_seek, j.cur_size);   // padOrTrim (TranscribeTask.swift:126-127)
             if (r) return r;
+            if (s->hooks.window_preprocess)                                // TranscribeTask.windowPreprocess (:130)
+                s->hooks.window_preprocess(s->hooks.user, slot_job[b], j.pcm + j.cur_seek, j.cur_seek, j.cur_size);
             j.tr->seeks.push_back(j.cur_seek);
         }
         double t1 = now_s();
@@ -748,8 +750,17 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             }
             const double windows_before = tr->timings.total_decoding_windows;
             int32_t seek = j.seek;
+            const int seg_before = (int)tr->segments.size();
             r = wh_transcription_add_window(tr, s->tok, opt, st, &res[b], alignment, lang_slot[b], j.cur_size, &seek); if (r) return r;
             j.seek = seek;
+            if (tr->timings.total_decoding_windows > windows_before) {      // the window had segments (`guard let currentSegments`, :239-242)
+                int n_new = (int)tr->segments.size() - seg_before;
+                if (s->hooks.window_postprocess) {                         // TranscribeTask.windowPostProcess (:246-250)
+                    const int keep = s->hooks.window_postprocess(s->hooks.user, slot_job[b], j.cur_seek, j.cur_size, tr, seg_before, n_new);
+                    if (keep >= 0 && keep < n_new) { whi::transcription_truncate_segments(tr, seg_before + keep); n_new = keep; }
+                }
+                if (s->hooks.segment_discovery) s->hooks.segment_discovery(s->hooks.user, slot_job[b], tr, seg_before, n_new);   // segmentDiscoveryCallback (:260)
+            }
             if (tr->timings.total_decoding_windows > windows_before) j.windows += 1;
             tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
             tr->timings.decoding_loop += (t4 - t3) / nb; tr->timings.total_logmel_runs += 1; tr->timings.total_encoding_runs += 1;
@@ -826,6 +837,12 @@ extern "C" int wh_session_set_progress_callback(wh_session* s, wh_progress_fn fn
     if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_progress_callback: null session");
     s->progress_cb = fn;
     s->progress_user = user;
+    return WH_OK;
+}
+
+extern "C" int wh_session_set_window_hooks(wh_session* s, const wh_window_hooks* hooks) {
+    if (!s) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_set_window_hooks: null session");
+    s->hooks = hooks ? *hooks : wh_window_hooks{};
     return WH_OK;
 }
 

@@ -102,6 +102,7 @@ struct wh_session {
     const wh_tokenizer* tok = nullptr;       // TextDecoding.tokenizer; not owned
     wh_progress_fn progress_cb = nullptr;    // TranscriptionCallback
     void* progress_user = nullptr;
+    wh_window_hooks hooks{};                 // TranscribeTask.windowPreprocess / windowPostProcess / segmentDiscoveryCallback
     bool skip_special_in_progress = false;
     int special_begin_in_progress = 1 << 30;
 };
@@ -129,6 +130,7 @@ void drop_session_graphs(wh_session* s);
 int ensure_align(wh_session* s);          // (re)allocate the raw alignment-head score buffer for the model's current head set
 int reset_decoder_inputs_masked(wh_session* s, int batch, const int32_t* active);
 // host logic shared by wh_decode_text / wh_transcribe (host.hip)
+void transcription_truncate_segments(wh_transcription* t, int n_keep);     // results.cpp: drop segments [n_keep, end) with their tokens / words
 void finalize_decoding_result(const wh::SeqState& sq, const wh_decoding_options* opt, const wh_special_tokens* st,
                               float temperature, wh_decoding_result* out);
 }  // namespace whi

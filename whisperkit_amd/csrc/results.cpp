@@ -216,6 +216,33 @@ extern "C" int wh_transcription_add_window(wh_transcription* tr, const wh_tokeni
     return WH_OK;
 }
 
+// Drop segments [n_keep, end) of a transcription together with their tokens, log-probs, words and texts (segments are appended in
+// order, so everything that belongs to the dropped tail is a tail as well): the "replace the segments of the window" half of
+// TranscribeTask.windowPostProcess (Core/TranscribeTask.swift:49-55) as far as a C hook can express it.
+namespace whi {
+void transcription_truncate_segments(wh_transcription* t, int n_keep) {
+    if (!t || n_keep < 0 || n_keep >= (int)t->segments.size()) return;
+    const wh_segment& g = t->segments[(size_t)n_keep];
+    t->tokens.resize((size_t)g.token_offset);
+    t->logprobs.resize((size_t)g.token_offset);
+    if (g.word_offset >= 0 && g.word_offset <= (int)t->words.size()) {
+        const size_t wt = g.word_offset < (int)t->words.size() ? (size_t)t->words[(size_t)g.word_offset].token_offset : t->word_tokens.size();
+        t->word_tokens.resize(std::min(wt, t->word_tokens.size()));
+        t->words.resize((size_t)g.word_offset);
+        if (t->word_text.size() > (size_t)g.word_offset) t->word_text.resize((size_t)g.word_offset);
+    }
+    if (t->segment_text.size() > (size_t)n_keep) t->segment_text.resize((size_t)n_keep);
+    t->segments.resize((size_t)n_keep);
+}
+}  // namespace whi
+
+extern "C" int wh_transcription_set_segment_times(wh_transcription* t, int i, float start, float end) {
+    if (!t || i < 0 || i >= (int)t->segments.size()) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_set_segment_times: segment %d out of range", i);
+    t->segments[(size_t)i].start = start;
+    t->segments[(size_t)i].end = end;
+    return WH_OK;
+}
+
 // finalizeTranscriptionResult (TranscribeTask.swift:297-312): text = decode(all text tokens) trimmed, language code
 extern "C" int wh_transcription_finalize(wh_transcription* tr, const wh_tokenizer* tok, const wh_decoding_options* opt, const wh_special_tokens* st) {
     if (!tr || !st) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_transcription_finalize: null argument");
