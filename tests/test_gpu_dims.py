@@ -26,9 +26,12 @@ POSITIONS = [0, 1, 2, 3, 129, 130, 200, 222]        # includes cache positions >
 
 
 class Rig:
-    """One model + one 32-slot session with every slot's window encoded (shared by the tests of a config)."""
+    """One model + one 32-slot session with every slot's window encoded (shared by the tests of a config).  `mode`: the sessions'
+    cross-attention (0 = per-layer K / V rows, 1 = weight-absorbed over the encoder output, csrc/xabs.hip) - every test runs in both,
+    and "batched == single slot bit for bit" holds within a mode."""
 
-    def __init__(self, name, seed):
+    def __init__(self, name, seed, mode=0):
+        self.mode = mode
         self.dims = weights.MODEL_DIMS[name]
         self.sd = weights.synthetic_state_dict(self.dims, seed=seed)
         self.model = api.Model(self.dims, self.sd)
@@ -40,7 +43,8 @@ class Rig:
     def session(self, B, slots=None):
         """fresh session (zero KV cache) with chunks `slots` (default 0..B-1) encoded into slots 0..B-1"""
         slots = list(range(B)) if slots is None else slots
-        s = api.Session(self.model, B)
+        s = api.Session(self.model, B, crossAttentionMode=self.mode)
+        assert s.crossAttentionMode == self.mode
         for b, i in enumerate(slots):
             s.padOrTrim(self.xs[i], b)
         s.logMelSpectrogram(B); s.encodeFeatures(B); s.prepareDecoderInputs(B)
@@ -51,9 +55,10 @@ class Rig:
         return self.om.new_state(sess.getEncoderOutput(b).astype(np.float16).astype(np.float32))
 
 
-@pytest.fixture(scope="module", params=["test-small-l2", "test-large-v3-l2"])
+@pytest.fixture(scope="module", params=[("test-small-l2", 0), ("test-large-v3-l2", 0), ("test-small-l2", 1), ("test-large-v3-l2", 1)],
+                ids=["small-kv-rows", "large-v3-kv-rows", "small-absorbed", "large-v3-absorbed"])
 def rig(request):
-    return Rig(request.param, seed=11)
+    return Rig(request.param[0], seed=11, mode=request.param[1])
 
 
 def test_dims_shapes_match_reference_pins(rig):
