@@ -845,6 +845,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             xa.enc = X.enc; xa.q = D.q; xa.wkT = X.layers_host[l].wkT; xa.wv_t = X.layers_host[l].wv_t; xa.bv = X.layers_host[l].bv;
             xa.qf_hi = X.qf_hi; xa.qf_lo = X.qf_lo; xa.part = X.part; xa.ml = X.ml; xa.att_hi = D.zb_hi; xa.att_lo = D.zb_lo;
             xa.align = db.align; xa.align_slot = db.align_slot; xa.n_align = db.n_align; xa.seq = db.seq; xa.kpart = D.part; xa.ticket = D.ticket;
+            xa.gate = db.xattn_gate;
             xa.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
             launch_xabs_qk(xa, n_bt, st);
             launch_xabs_attn(xa, st);

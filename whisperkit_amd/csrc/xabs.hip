@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
             }
         }
     }
+    // cross-attention gate (dec_shared.h; opt-in): concurrent sessions take turns at the one kernel of a layer that saturates the HBM
+    if (a.gate && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) xattn_gate_acquire(a.gate);
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_attn
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;
     const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
     const int S = kXabsSplits, H = a.n_head;
+    if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);     // the grid is draining from here on
     if (b >= a.batch) return;
     // WH_DBG=1: shader-clock stamps (tools/xabs_timeline.py): 9 entry, 10 slot state known, 11 loop entry, 12 loop exit, 13 partials stored
 #define XPHASE(k) do { if constexpr (DBG) if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 64) \
