@@ -73,7 +73,10 @@ bv = sd[f"decoder.blocks.{l}.cross_attn.value.bias"].astype(np.float32)
 NHT = 2 if H > 16 else 1
 KS = d // 32
 HP = NHT * 16
-qf = (peek(s1, "qf_hi", (B, HP, d), np.float16).astype(np.float32) + peek(s1, "qf_lo", (B, HP, d), np.float16).astype(np.float32) / 2048.0)
+hi = peek(s1, "qf_hi", (B, HP, d), np.float16).astype(np.float32)
+lo = peek(s1, "qf_lo", (B, HP, d), np.float16).astype(np.float32)
+# rows 0..15: hi (qf_hi) | lo (qf_lo) of heads 0..15; packed second tile: qf_hi rows 16..23 = hi, rows 24..31 = lo of heads 16..23
+qf = np.concatenate([hi[:, :16] + lo[:, :16] / 2048.0] + ([hi[:, 16:24] + hi[:, 24:32] / 2048.0] if NHT == 2 else []), axis=1)
 qp = qf[:, :H]
 qp_ref = np.einsum("bhj,hjc->bhc", q.reshape(B, H, 64), Wk.reshape(H, 64, d))
 print(json.dumps({"check": "absorbed_queries", "max_abs_diff": float(np.abs(qp - qp_ref).max()), "rms": float(np.sqrt((qp_ref ** 2).mean()))}))

@@ -57,9 +57,13 @@ void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_qk
-// grid (d / 256, H, n_bt), 4 waves, wave w: row tiles (blockIdx.x 4 + w) 2 + {0, 1}.  Output qf[slot][head (padded to 16 NHT)][c], an
-// f16 hi plane + lo plane (lo = (z - hi) 2048): a wave writes whole 128-byte lines, xabs_attn gathers its S-phase B fragments
-// (lane = (head & 15) | k group << 4, 8 channels ks 32 + 8 kg + 0..7) from it with 64 contiguous bytes per head and k-step
+// grid (d / 256, H, n_bt), 4 waves, wave w: row tiles (blockIdx.x 4 + w) 2 + {0, 1}.  Output rows of d channels, f16, z ~ hi + lo / 2048:
+//     qf_hi[slot][row 0..15]  = hi of heads 0..15        qf_lo[slot][row 0..15] = lo of heads 0..15
+//     qf_hi[slot][row 16..23] = hi of heads 16..23       qf_hi[slot][row 24..31] = lo of heads 16..23        (NHT = 2 only)
+// i.e. the second head tile of a 20-head model is PACKED: its (at most 8) real heads carry hi and lo in ONE 16-row tile, so the S phase
+// of xabs_attn spends 3 MFMAs per k-step (tile 0 hi, tile 0 lo, tile 1 hi | lo) instead of 4 and keeps 60 instead of 80 fragment
+// registers.  A wave writes whole 128-byte lines; xabs_attn gathers its S-phase B fragments (lane = row | k group << 4, 8 channels
+// ks 32 + 8 kg + 0..7) with 64 contiguous bytes per row and k-step.
 template <int NHT>
 __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,15 +128,56 @@ __global__ __launch_bounds__(256, 2) void xabs_qk_kernel(const XabsArgs a) {
             // the lower lane holds channels rt 32 + 0..15 (units g = 0, 1), the upper lane rt 32 + 16..31: 32 contiguous bytes per lane and
             // plane, 128 contiguous bytes per slot over the wave's two row tiles
             const size_t o = ((size_t)gb * (NHT * 16) + h) * d + rt * 32 + 16 * hl;
+            f16* lo_dst = h < 16 ? a.qf_lo + o : a.qf_hi + o + (size_t)8 * d;        // packed second tile: lo of head h lives 8 rows below its hi
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 *reinterpret_cast<u32x4*>(a.qf_hi + o + 8 * u) = oh[u];
-                *reinterpret_cast<u32x4*>(a.qf_lo + o + 8 * u) = ol[u];
+                *reinterpret_cast<u32x4*>(lo_dst + 8 * u) = ol[u];
             }
         }
     }
     // cross-attention gate (dec_shared.h; opt-in): concurrent sessions take turns at the one kernel of a layer that saturates the HBM
     if (a.gate && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) xattn_gate_acquire(a.gate);
+}
+
+// ---------------------------------------------------------------------------------------------- S-phase fragments (shared)
+// The Q' slice of one wave (k-steps wave CW + j) as B fragments of v_mfma_f32_16x16x32_f16: tile 0 hi, tile 0 lo, packed tile 1.
+template <int CW, int NHT>
+struct XabsQFrag { f16x8 h0[CW], l0[CW], p1[NHT == 2 ? CW : 1]; };
+template <int CW, int NHT>
+__device__ __forceinline__ void xabs_load_qfrag(const XabsArgs& a, int b, int wave, int lane, XabsQFrag<CW, NHT>& q) {
+    constexpr int D = CW * 256;
+    const int row = lane & 15, H = a.n_head;
+    const size_t qo = ((size_t)b * (NHT * 16) + row) * D + wave * CW * 32 + (lane >> 4) * 8;
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool real0 = row < H;                                            // padded heads: no request at all
+    const bool real1 = NHT == 2 && 16 + (row & 7) < H;                     // packed tile: rows 0..7 hi, 8..15 lo of heads 16 + (row & 7)
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        q.h0[j] = real0 ? *reinterpret_cast<const f16x8*>(a.qf_hi + qo + j * 32) : zero;
+        q.l0[j] = real0 ? *reinterpret_cast<const f16x8*>(a.qf_lo + qo + j * 32) : zero;
+        if constexpr (NHT == 2) q.p1[j] = real1 ? *reinterpret_cast<const f16x8*>(a.qf_hi + qo + (size_t)16 * D + j * 32) : zero;
+    }
+}
+// S^T partial of one 16-key tile over this wave's channels: D[key = 4 (lane >> 4) + r][head = 16 ht + (lane & 15)] -> sreg[4 ht + r]
+template <int CW, int NHT>
+__device__ __forceinline__ void xabs_s_tile(const f16x8 (&af)[CW], const XabsQFrag<CW, NHT>& q, int lane, float (&sreg)[NHT * 4]) {
+    f32x4 sh = {0, 0, 0, 0}, sl = {0, 0, 0, 0}, sp = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        sh = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], q.h0[j], sh, 0, 0, 0);
+        sl = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], q.l0[j], sl, 0, 0, 0);
+        if constexpr (NHT == 2) sp = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], q.p1[j], sp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sreg[r] = fmaf(sl[r], 1.0f / 2048.0f, sh[r]);
+    if constexpr (NHT == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lo = dpp_mov<kDppRor8>(sp[r]);             // column c + 8 of the packed tile: the lo part of head 16 + c
+            sreg[4 + r] = (lane & 15) < 8 ? fmaf(lo, 1.0f / 2048.0f, sp[r]) : 0.0f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_attn
@@ -141,8 +186,8 @@ constexpr int kXabsSpStride = 32 * 17;       // floats per wave partial: [32 hea
 constexpr float kXabsDefer = 8.0f;           // the running maximum moves only when it would grow by more than this (p <= e^8 fits f16)
 __host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsHalves * cw * 4096 + 8 * kXabsSpStride * 4 + 1024 + 128; }
 
-template <int CW, int NHT, bool HILO, bool DBG, bool NTL>
-__global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
+template <int CW, int NHT, bool DBG, bool NTL>
+__global__ __launch_bounds__(512, 2) void xabs_attn_dma_kernel(const XabsArgs a) {
     constexpr int D = CW * 256, ROWB = D * 2, HALF = 8 * ROWB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float* spart = reinterpret_cast<float*>(smem + kXabsHalves * HALF);
@@ -213,19 +258,8 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     const bool owner = o_head < 16 * NHT;
     int al_slot = -1;
     if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
-    f16x8 qh[NHT][CW], ql[HILO ? NHT : 1][HILO ? CW : 1];
-    {
-        const size_t qo = ((size_t)b * (NHT * 16) + (lane & 15)) * D + wave * CW * 32 + (lane >> 4) * 8;
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int j = 0; j < CW; ++j) {
-                const bool real = ht * 16 + (lane & 15) < H;      // padded heads: no request at all (large-v3: 12 of 32 rows)
-                const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                qh[ht][j] = real ? *reinterpret_cast<const f16x8*>(a.qf_hi + qo + (size_t)ht * 16 * D + j * 32) : zero;
-                if constexpr (HILO) ql[ht][j] = real ? *reinterpret_cast<const f16x8*>(a.qf_lo + qo + (size_t)ht * 16 * D + j * 32) : zero;
-            }
-    }
+    XabsQFrag<CW, NHT> qf;
+    xabs_load_qfrag<CW, NHT>(a, b, wave, lane, qf);
     issue(0);
     if (n > 1) issue(1);
     if (n > 2) issue(2);
@@ -265,20 +299,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
             const int c = (wave * CW + j) * 4 + s_kg;
             af[j] = *reinterpret_cast<const f16x8*>(row + ((c ^ s_sw) << 4));
         }
-        f32x4 sh[NHT], sl_[NHT];
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht) { sh[ht] = f32x4{0, 0, 0, 0}; sl_[ht] = f32x4{0, 0, 0, 0}; }
-#pragma unroll
-        for (int j = 0; j < CW; ++j)
-#pragma unroll
-            for (int ht = 0; ht < NHT; ++ht) {
-                sh[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], qh[ht][j], sh[ht], 0, 0, 0);
-                if constexpr (HILO) sl_[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], ql[ht][j], sl_[ht], 0, 0, 0);
-            }
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sreg[ht * 4 + r] = HILO ? fmaf(sl_[ht][r], 1.0f / 2048.0f, sh[ht][r]) : sh[ht][r];
+        xabs_s_tile<CW, NHT>(af, qf, lane, sreg);
     };
     auto write_partials = [&](const float (&sreg)[NHT * 4]) {
         float* wpart = spart + wave * kXabsSpStride;
@@ -395,6 +416,186 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     if constexpr (DBG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XPHASE(13);
 #undef XPHASE
+}
+
+// ---------------------------------------------------------------------------------------------- xabs_attn, register-staged form
+// The same mathematics with the encoder rows fetched by ordinary buffer loads into REGISTERS instead of LDS-DMA.  Why: the LDS-DMA path of
+// a CU lands about 11 B / clk (22 - 25 GB/s) whatever the chip is doing - the ring kernel above streams at that ceiling with 256 workgroups
+// and leaves the chip idle with fewer (8 slots: 43 us for 31 MB) - while register loads are bounded by what a wave keeps in flight.
+// Each wave fetches, per 16-key tile, exactly its own channel slice [wave CW 32, +CW 32) as CW 16-byte pieces per lane
+// (lane = key | k group << 4): those registers ARE the A fragments of the S phase (no LDS read at all), and afterwards they are written to
+// a wave-PRIVATE LDS slot (16 keys x CW 64 bytes, two slots per wave) from which the same wave reads the enc^T operand of its P V tiles
+// with ds_read_b64_tr_b16 - the channel slice of a wave's S phase is the channel slice of its P V tiles, so no encoder byte crosses
+// waves and the slots need no barrier.  Row stride 320 bytes tiles the 64 banks exactly for the transpose reads (4 keys x 64 bytes);
+// the 16-byte chunk index is XORed with (key >> 1) & 3 so that the 8-lane groups of ds_write_b128 spread over all banks as well
+// (both checked on the CPU, tests/test_kernel_index_math.py).  Two tiles (40 registers) are in flight per wave: 80 KB per CU.
+constexpr int xabs_rs_lds_bytes(int cw) { return 8 * 2 * 16 * cw * 64 + 8 * kXabsSpStride * 4 + 1024 + 128; }
+
+template <int CW, int NHT, bool NTL>
+__global__ __launch_bounds__(512, 2) void xabs_attn_rs_kernel(const XabsArgs a) {
+    constexpr int D = CW * 256, ROWB = D * 2, WROW = CW * 64, SLOT = 16 * WROW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    float* spart = reinterpret_cast<float*>(smem + 16 * SLOT);
+    f16* pfrag = reinterpret_cast<f16*>(smem + 16 * SLOT + 8 * kXabsSpStride * 4);
+    float* alpha_l = reinterpret_cast<float*>(smem + 16 * SLOT + 8 * kXabsSpStride * 4 + 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;            // (split, slot) from the workgroup id: see xabs_attn_dma_kernel
+    const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
+    const int S = kXabsSplits, H = a.n_head;
+    if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);
+    if (b >= a.batch) return;
+    constexpr int NT = (kCtx + 15) / 16;
+    const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
+    const int bc = a.cross_div > 1 ? b / a.cross_div : b;
+    const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
+
+    const int key = lane & 15, kg = lane >> 4;
+    const int voff = key * ROWB + (wave * CW * 32 + kg * 8) * 2;            // this lane's first piece inside a tile's rows
+    // per-tile buffer resource: rows past position 1499 are out of range and read as zero (their keys are masked below)
+    auto load_tile = [&](int i, u32x4 (&buf)[CW]) {
+        const int t16 = (tile_lo + i) * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(enc) + (size_t)t16 * ROWB, 0, (kCtx - t16) * ROWB, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) buf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + j * 64, 0, NTL ? 2 : 0);
+#else
+        (void)t16; (void)buf;
+#endif
+    };
+    const SeqState* sq = a.seq + b;
+    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
+    const int o_key = lane & 15, o_head = 4 * wave + (lane >> 4);
+    const bool owner = o_head < 16 * NHT;
+    int al_slot = -1;
+    if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
+    XabsQFrag<CW, NHT> qf;
+    xabs_load_qfrag<CW, NHT>(a, b, wave, lane, qf);
+    u32x4 bufA[CW], bufB[CW];
+    load_tile(0, bufA);
+    if (n > 1) load_tile(1, bufB);
+    if (tid < 32) alpha_l[tid] = 1.0f;
+    pfrag[tid] = (f16)0.0f;
+    if (!(s_act && !s_done)) return;     // workgroup-uniform: a finished slot streams nothing more
+    const int pos = min(max(s_ti, 0), kMaxTok - 1);
+    float* raw = nullptr;
+    if (al_slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + al_slot) * kCtx;
+
+    f32x16 acc[CW];
+#pragma unroll
+    for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    unsigned char* myslot = smem + wave * 2 * SLOT;
+    // write side: lane = key | k group << 4, piece j -> chunk (4 j + kg) ^ ((key >> 1) & 3) of row `key`
+    const int w_off = key * WROW, w_sw = (key >> 1) & 3;
+    // transpose-read side: 16-lane group g16, supplier index sl
+    const int g16 = lane >> 4, sl = lane & 15;
+    const int t_key0 = (g16 >> 1) * 8 + (sl >> 2), t_key1 = t_key0 + 4;
+    const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
+    const int t_off0 = t_key0 * WROW + t_b, t_off1 = t_key1 * WROW + t_b, t_sw0 = (t_key0 >> 1) & 3, t_sw1 = (t_key1 >> 1) & 3;
+
+    auto s_and_stage = [&](u32x4 (&buf)[CW], unsigned char* slot, float (&sreg)[NHT * 4]) {
+        f16x8 af[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) af[j] = __builtin_bit_cast(f16x8, buf[j]);
+        xabs_s_tile<CW, NHT>(af, qf, lane, sreg);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) *reinterpret_cast<u32x4*>(slot + w_off + (((4 * j + kg) ^ w_sw) << 4)) = buf[j];
+    };
+    auto write_partials = [&](const float (&sreg)[NHT * 4]) {
+        float* wpart = spart + wave * kXabsSpStride;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = sreg[ht * 4 + r];
+    };
+    auto softmax = [&](int i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) s += spart[v * kXabsSpStride + o_head * 17 + o_key];
+        const int t = (tile_lo + i) * 16 + o_key;
+        const bool valid = t < kCtx;
+        if (raw && valid) raw[t] = s;                 // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
+        s = valid ? s : -INFINITY;
+        float mt_ = s;
+        mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
+        mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
+        const float m_new = fmaxf(m_run, mt_);
+        const float m_use = (m_new > m_run + kXabsDefer) ? m_new : m_run;
+        const float al = __expf(m_run - m_use);
+        float p = valid ? __expf(s - m_use) : 0.0f;
+        if (o_head >= H) p = 0.0f;
+        const f16 ph = (f16)p;
+        float ps = (float)ph;
+        ps += dpp_mov<kDppXor1>(ps);
+        ps += dpp_mov<kDppXor2>(ps);
+        ps += dpp_mov<kDppHalfMirror>(ps);
+        ps += dpp_mov<kDppMirror>(ps);
+        l_run = fmaf(l_run, al, ps);
+        m_run = m_use;
+        pfrag[(o_head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
+        if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
+    };
+    auto pv = [&](const unsigned char* slot) {
+        const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
+        const float al = alpha_l[lane & 31];
+        if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {
+#pragma unroll
+            for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
+        }
+#pragma unroll
+        for (int mt = 0; mt < CW; ++mt) {
+            const int c = mt * 4 + t_c;
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slot + t_off0 + ((c ^ t_sw0) << 4)));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slot + t_off1 + ((c ^ t_sw1) << 4)));
+            const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
+            const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
+        }
+    };
+    // One tile of the software pipeline (two barriers): Y = S(i + 1) from the registers of tile i + 1 (-> its private LDS slot; the
+    // freed registers request tile i + 3) beside softmax(i); Z = partials(i + 1) -> LDS, P V(i) from the slot of tile i.
+    float sreg[NHT * 4];
+    auto step = [&](int i, u32x4 (&nb)[CW]) {
+        if (i + 1 < n) {
+            s_and_stage(nb, myslot + ((i + 1) & 1) * SLOT, sreg);
+            if (i + 3 < n) load_tile(i + 3, nb);
+        }
+        if (owner) softmax(i);
+        __syncthreads();                                  // C: P^T(i) and the rescale factors are in LDS; partials(i) are consumed
+        if (i + 1 < n) write_partials(sreg);
+        pv(myslot + (i & 1) * SLOT);
+        __syncthreads();                                  // D: partials(i + 1) are in LDS
+    };
+    s_and_stage(bufA, myslot, sreg);
+    if (n > 2) load_tile(2, bufA);
+    write_partials(sreg);
+    __syncthreads();
+    for (int i = 0; i < n; i += 2) {
+        step(i, bufB);                                    // odd tiles travel in bufB, even tiles in bufA
+        if (i + 1 < n) step(i + 1, bufA);
+    }
+    // ---- this split's partial (as in xabs_attn_dma_kernel)
+    if (owner && o_key == 0 && o_head < H) a.ml[((size_t)sp * H + o_head) * a.max_batch + b] = float2{m_run, l_run};
+    {
+        const int head = lane & 31, hl = lane >> 5;
+        if (head < H) {
+            float* pb = a.part + (((size_t)sp * H + head) * (D / 8)) * a.max_batch * 8 + (size_t)b * 8 + 4 * hl;
+#pragma unroll
+            for (int mt = 0; mt < CW; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c8 = (wave * CW + mt) * 4 + g;
+                    *reinterpret_cast<float4*>(pb + (size_t)c8 * a.max_batch * 8) = float4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- xabs_vup
@@ -552,20 +753,27 @@ void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
     else xabs_qk_kernel<1><<<grid, 256, 0, st>>>(a);
 }
 
-template <int CW, int NHT, bool HILO, bool DBG, bool NTL>
-static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
+template <int CW, int NHT, bool DBG, bool NTL>
+static void launch_attn_dma(const XabsArgs& a, hipStream_t st) {
     constexpr int lds = xabs_lds_bytes(CW);
     static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, HILO, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    xabs_attn_kernel<CW, NHT, HILO, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_dma_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    xabs_attn_dma_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
+}
+template <int CW, int NHT, bool NTL>
+static void launch_attn_rs(const XabsArgs& a, hipStream_t st) {
+    constexpr int lds = xabs_rs_lds_bytes(CW);
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_rs_kernel<CW, NHT, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    xabs_attn_rs_kernel<CW, NHT, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
 }
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
-    static const int hilo = xabs_env("WH_XABS_QLO", 1);       // A/B: Q' as an f16 hi | lo pair (default) or a single f16 plane
     static const int nt = xabs_env("WH_XABS_NT", 1);          // non-temporal policy on the encoder-output stream (in flight: 19.2 k vs 18.1 k sequence-steps/s, profiles/r04l_*); 0 = A/B side
-    if (a.dbg) { launch_attn_k<CW, NHT, true, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation (tools/xabs_timeline.py)
-    if (hilo) { if (nt) launch_attn_k<CW, NHT, true, false, true>(a, st); else launch_attn_k<CW, NHT, true, false, false>(a, st); }
-    else launch_attn_k<CW, NHT, false, false, false>(a, st);
+    static const int dma = xabs_env("WH_XABS_DMA", 0);        // 1: the LDS-DMA ring form (A/B side; also the form tools/xabs_timeline.py stamps)
+    if (a.dbg) { launch_attn_dma<CW, NHT, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation
+    if (dma) { if (nt) launch_attn_dma<CW, NHT, false, true>(a, st); else launch_attn_dma<CW, NHT, false, false>(a, st); return; }
+    if (nt) launch_attn_rs<CW, NHT, true>(a, st); else launch_attn_rs<CW, NHT, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
