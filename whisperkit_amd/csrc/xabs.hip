@@ -187,7 +187,7 @@ constexpr float kXabsDefer = 8.0f;           // the running maximum moves only w
 __host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsHalves * cw * 4096 + 8 * kXabsSpStride * 4 + 1024 + 128; }
 
 template <int CW, int NHT, bool DBG, bool NTL>
-__global__ __launch_bounds__(512, 2) void xabs_attn_dma_kernel(const XabsArgs a) {
+__global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     constexpr int D = CW * 256, ROWB = D * 2, HALF = 8 * ROWB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float* spart = reinterpret_cast<float*>(smem + kXabsHalves * HALF);
@@ -340,6 +340,10 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_dma_kernel(const XabsArgs a)
         if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
     };
     // O'^T[channel][head] += enc^T[channel][key] P^T[key][head]: A = enc^T tile (M = 32 channels, K = 16 keys), two transpose reads
+    // O'^T[channel][head] += enc^T[channel][key] P^T[key][head]: A = enc^T tile (M = 32 channels, K = 16 keys), two transpose reads.
+    // (Measured and rejected, profiles/r04z_*: issuing the transpose reads of tile i in the Y interval - they do not depend on P - costs
+    // 57 -> 60 us: the barrier's lgkmcnt(0) waits for them anyway; softmax ahead of the S-phase MFMAs costs 57 -> 68 us: an in-order
+    // wave stalls on the softmax's LDS round trip before it has queued its matrix work.)
     auto pv = [&](const unsigned char* tile) {
         const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
         const float al = alpha_l[lane & 31];
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_dma_kernel(const XabsArgs a)
         a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2 + (i - 10)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int i = 0; i < n; ++i) {
         XSTAMP(0);
-        if (i + 1 < n) s_phase(s_base(i + 1), sreg);
+        if (i + 1 < n) s_phase(s_base(i + 1), sreg);      // MFMAs first: they execute while the owner lanes walk the softmax chain
         XSTAMP(1);
         if (owner) softmax(i);
         XSTAMP(2);
@@ -418,185 +422,11 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_dma_kernel(const XabsArgs a)
 #undef XPHASE
 }
 
-// ---------------------------------------------------------------------------------------------- xabs_attn, register-staged form
-// The same mathematics with the encoder rows fetched by ordinary buffer loads into REGISTERS instead of LDS-DMA.  Why: the LDS-DMA path of
-// a CU lands about 11 B / clk (22 - 25 GB/s) whatever the chip is doing - the ring kernel above streams at that ceiling with 256 workgroups
-// and leaves the chip idle with fewer (8 slots: 43 us for 31 MB) - while register loads are bounded by what a wave keeps in flight.
-// Each wave fetches, per 16-key tile, exactly its own channel slice [wave CW 32, +CW 32) as CW 16-byte pieces per lane
-// (lane = key | k group << 4): those registers ARE the A fragments of the S phase (no LDS read at all), and afterwards they are written to
-// a wave-PRIVATE LDS slot (16 keys x CW 64 bytes, two slots per wave) from which the same wave reads the enc^T operand of its P V tiles
-// with ds_read_b64_tr_b16 - the channel slice of a wave's S phase is the channel slice of its P V tiles, so no encoder byte crosses
-// waves and the slots need no barrier.  Row stride 320 bytes tiles the 64 banks exactly for the transpose reads (4 keys x 64 bytes);
-// the 16-byte chunk index is XORed with (key >> 1) & 3 so that the 8-lane groups of ds_write_b128 spread over all banks as well
-// (both checked on the CPU, tests/test_kernel_index_math.py).  Two tiles (40 registers) are in flight per wave: 80 KB per CU.
-constexpr int xabs_rs_lds_bytes(int cw) { return 8 * 2 * 16 * cw * 64 + 8 * kXabsSpStride * 4 + 1024 + 128; }
-
-template <int CW, int NHT, bool NTL>
-__global__ __launch_bounds__(512, 2) void xabs_attn_rs_kernel(const XabsArgs a) {
-    constexpr int D = CW * 256, ROWB = D * 2, WROW = CW * 64, SLOT = 16 * WROW;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    float* spart = reinterpret_cast<float*>(smem + 16 * SLOT);
-    f16* pfrag = reinterpret_cast<f16*>(smem + 16 * SLOT + 8 * kXabsSpStride * 4);
-    float* alpha_l = reinterpret_cast<float*>(smem + 16 * SLOT + 8 * kXabsSpStride * 4 + 1024);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;            // (split, slot) from the workgroup id: see xabs_attn_dma_kernel
-    const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
-    const int S = kXabsSplits, H = a.n_head;
-    if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);
-    if (b >= a.batch) return;
-    constexpr int NT = (kCtx + 15) / 16;
-    const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
-    const int bc = a.cross_div > 1 ? b / a.cross_div : b;
-    const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
-
-    const int key = lane & 15, kg = lane >> 4;
-    const int voff = key * ROWB + (wave * CW * 32 + kg * 8) * 2;            // this lane's first piece inside a tile's rows
-    // per-tile buffer resource: rows past position 1499 are out of range and read as zero (their keys are masked below)
-    auto load_tile = [&](int i, u32x4 (&buf)[CW]) {
-        const int t16 = (tile_lo + i) * 16;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(enc) + (size_t)t16 * ROWB, 0, (kCtx - t16) * ROWB, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < CW; ++j) buf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + j * 64, 0, NTL ? 2 : 0);
-#else
-        (void)t16; (void)buf;
-#endif
-    };
-    const SeqState* sq = a.seq + b;
-    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
-    const int o_key = lane & 15, o_head = 4 * wave + (lane >> 4);
-    const bool owner = o_head < 16 * NHT;
-    int al_slot = -1;
-    if (a.align && owner && o_head < H) al_slot = a.align_slot[a.layer * H + o_head];
-    XabsQFrag<CW, NHT> qf;
-    xabs_load_qfrag<CW, NHT>(a, b, wave, lane, qf);
-    u32x4 bufA[CW], bufB[CW];
-    load_tile(0, bufA);
-    if (n > 1) load_tile(1, bufB);
-    if (tid < 32) alpha_l[tid] = 1.0f;
-    pfrag[tid] = (f16)0.0f;
-    if (!(s_act && !s_done)) return;     // workgroup-uniform: a finished slot streams nothing more
-    const int pos = min(max(s_ti, 0), kMaxTok - 1);
-    float* raw = nullptr;
-    if (al_slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + al_slot) * kCtx;
-
-    f32x16 acc[CW];
-#pragma unroll
-    for (int mt = 0; mt < CW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-    unsigned char* myslot = smem + wave * 2 * SLOT;
-    // write side: lane = key | k group << 4, piece j -> chunk (4 j + kg) ^ ((key >> 1) & 3) of row `key`
-    const int w_off = key * WROW, w_sw = (key >> 1) & 3;
-    // transpose-read side: 16-lane group g16, supplier index sl
-    const int g16 = lane >> 4, sl = lane & 15;
-    const int t_key0 = (g16 >> 1) * 8 + (sl >> 2), t_key1 = t_key0 + 4;
-    const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
-    const int t_off0 = t_key0 * WROW + t_b, t_off1 = t_key1 * WROW + t_b, t_sw0 = (t_key0 >> 1) & 3, t_sw1 = (t_key1 >> 1) & 3;
-
-    auto s_and_stage = [&](u32x4 (&buf)[CW], unsigned char* slot, float (&sreg)[NHT * 4]) {
-        f16x8 af[CW];
-#pragma unroll
-        for (int j = 0; j < CW; ++j) af[j] = __builtin_bit_cast(f16x8, buf[j]);
-        xabs_s_tile<CW, NHT>(af, qf, lane, sreg);
-#pragma unroll
-        for (int j = 0; j < CW; ++j) *reinterpret_cast<u32x4*>(slot + w_off + (((4 * j + kg) ^ w_sw) << 4)) = buf[j];
-    };
-    auto write_partials = [&](const float (&sreg)[NHT * 4]) {
-        float* wpart = spart + wave * kXabsSpStride;
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = sreg[ht * 4 + r];
-    };
-    auto softmax = [&](int i) {
-        float s = 0.0f;
-#pragma unroll
-        for (int v = 0; v < 8; ++v) s += spart[v * kXabsSpStride + o_head * 17 + o_key];
-        const int t = (tile_lo + i) * 16 + o_key;
-        const bool valid = t < kCtx;
-        if (raw && valid) raw[t] = s;                 // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
-        s = valid ? s : -INFINITY;
-        float mt_ = s;
-        mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
-        mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
-        mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
-        mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
-        const float m_new = fmaxf(m_run, mt_);
-        const float m_use = (m_new > m_run + kXabsDefer) ? m_new : m_run;
-        const float al = __expf(m_run - m_use);
-        float p = valid ? __expf(s - m_use) : 0.0f;
-        if (o_head >= H) p = 0.0f;
-        const f16 ph = (f16)p;
-        float ps = (float)ph;
-        ps += dpp_mov<kDppXor1>(ps);
-        ps += dpp_mov<kDppXor2>(ps);
-        ps += dpp_mov<kDppHalfMirror>(ps);
-        ps += dpp_mov<kDppMirror>(ps);
-        l_run = fmaf(l_run, al, ps);
-        m_run = m_use;
-        pfrag[(o_head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
-        if (o_key == 0) alpha_l[o_head] = (o_head < H) ? al : 1.0f;
-    };
-    auto pv = [&](const unsigned char* slot) {
-        const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
-        const float al = alpha_l[lane & 31];
-        if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {
-#pragma unroll
-            for (int mt = 0; mt < CW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
-        }
-#pragma unroll
-        for (int mt = 0; mt < CW; ++mt) {
-            const int c = mt * 4 + t_c;
-            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slot + t_off0 + ((c ^ t_sw0) << 4)));
-            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(slot + t_off1 + ((c ^ t_sw1) << 4)));
-            const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
-            const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
-        }
-    };
-    // One tile of the software pipeline (two barriers): Y = S(i + 1) from the registers of tile i + 1 (-> its private LDS slot; the
-    // freed registers request tile i + 3) beside softmax(i); Z = partials(i + 1) -> LDS, P V(i) from the slot of tile i.
-    float sreg[NHT * 4];
-    auto step = [&](int i, u32x4 (&nb)[CW]) {
-        if (i + 1 < n) {
-            s_and_stage(nb, myslot + ((i + 1) & 1) * SLOT, sreg);
-            if (i + 3 < n) load_tile(i + 3, nb);
-        }
-        if (owner) softmax(i);
-        __syncthreads();                                  // C: P^T(i) and the rescale factors are in LDS; partials(i) are consumed
-        if (i + 1 < n) write_partials(sreg);
-        pv(myslot + (i & 1) * SLOT);
-        __syncthreads();                                  // D: partials(i + 1) are in LDS
-    };
-    s_and_stage(bufA, myslot, sreg);
-    if (n > 2) load_tile(2, bufA);
-    write_partials(sreg);
-    __syncthreads();
-    for (int i = 0; i < n; i += 2) {
-        step(i, bufB);                                    // odd tiles travel in bufB, even tiles in bufA
-        if (i + 1 < n) step(i + 1, bufA);
-    }
-    // ---- this split's partial (as in xabs_attn_dma_kernel)
-    if (owner && o_key == 0 && o_head < H) a.ml[((size_t)sp * H + o_head) * a.max_batch + b] = float2{m_run, l_run};
-    {
-        const int head = lane & 31, hl = lane >> 5;
-        if (head < H) {
-            float* pb = a.part + (((size_t)sp * H + head) * (D / 8)) * a.max_batch * 8 + (size_t)b * 8 + 4 * hl;
-#pragma unroll
-            for (int mt = 0; mt < CW; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c8 = (wave * CW + mt) * 4 + g;
-                    *reinterpret_cast<float4*>(pb + (size_t)c8 * a.max_batch * 8) = float4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                }
-        }
-    }
-}
+// (A register-staged form of this kernel - ordinary buffer loads whose registers are the S-phase A fragments, then a wave-private LDS slot
+// for the transpose reads: no encoder byte crosses waves, no LDS-DMA - was built in round 4, is bit-identical and SLOWER at every batch
+// size: 63.7 vs 57.2 us at 64 slots, 53.8 vs 45.3 us at 8 (profiles/r04y_*).  The tile period of this kernel is not set by the fetch
+// path: about 3 900 cycles per 16-key tile against 830 cycles of MFMA work per SIMD and 3 450 cycles of HBM time at 6.2 TB/s - the rest
+// is the lock-step S -> reduce -> softmax -> P -> P V chain between two workgroup barriers.  Code removed; git history has it.)
 
 // ---------------------------------------------------------------------------------------------- xabs_vup
 // att[slot][n] = (W_v[n][:] . sum_s w_s O'_s[head(n)][:]) / l + b_v[n],  w_s = exp(m_s - max m),  l = sum_s w_s l_s.
@@ -754,26 +584,17 @@ void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
 }
 
 template <int CW, int NHT, bool DBG, bool NTL>
-static void launch_attn_dma(const XabsArgs& a, hipStream_t st) {
+static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
     constexpr int lds = xabs_lds_bytes(CW);
     static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_dma_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    xabs_attn_dma_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
-}
-template <int CW, int NHT, bool NTL>
-static void launch_attn_rs(const XabsArgs& a, hipStream_t st) {
-    constexpr int lds = xabs_rs_lds_bytes(CW);
-    static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_rs_kernel<CW, NHT, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    xabs_attn_rs_kernel<CW, NHT, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
 }
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     static const int nt = xabs_env("WH_XABS_NT", 1);          // non-temporal policy on the encoder-output stream (in flight: 19.2 k vs 18.1 k sequence-steps/s, profiles/r04l_*); 0 = A/B side
-    static const int dma = xabs_env("WH_XABS_DMA", 0);        // 1: the LDS-DMA ring form (A/B side; also the form tools/xabs_timeline.py stamps)
-    if (a.dbg) { launch_attn_dma<CW, NHT, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation
-    if (dma) { if (nt) launch_attn_dma<CW, NHT, false, true>(a, st); else launch_attn_dma<CW, NHT, false, false>(a, st); return; }
-    if (nt) launch_attn_rs<CW, NHT, true>(a, st); else launch_attn_rs<CW, NHT, false>(a, st);
+    if (a.dbg) { launch_attn_k<CW, NHT, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation (tools/xabs_timeline.py)
+    if (nt) launch_attn_k<CW, NHT, false, true>(a, st); else launch_attn_k<CW, NHT, false, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
