@@ -421,234 +421,14 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
 #undef XPHASE
 }
 
-// ---------------------------------------------------------------------------------------------- xabs_attn, role-split form
-// The symmetric kernel above runs every wave through S -> reduce -> softmax -> P V in lock step: about 3 900 cycles per 16-key tile for
-// 830 cycles of MFMA work per SIMD - the tile period is the latency chain, not the fetch (profiles/r04i_*, r04y_*).  Here the two waves of
-// a SIMD take different roles and work on different tiles:
-//   waves 0-3 (S waves)    S^T(i + 1) = enc Q'^T over a quarter of the channels each (2 CW k-steps, the Q' slice in 24 CW registers),
-//                          partials -> LDS, then the owner lanes (one key x NHT heads per lane) sum, softmax, write P^T(i + 1);
-//   waves 4-7 (P V waves)  O'^T += enc^T P^T(i) over a quarter of the channels each (2 CW tiles of 32, 32 CW accumulator registers).
-// Two barriers per tile as before, but each interval now holds one group's matrix burst beside the other's LDS / VALU latency:
-//   A_i   S waves: S(i + 1), partials        |  P V waves: transpose reads + MFMAs of tile i
-//   B_i   S waves: reduce, softmax, P(i + 1)  |  P V waves: (nothing)                                   - LDS-DMA requests for the tile freed by A_i
-// The ring, the swizzle, the request scheme (waves 0-3 first halves, 4-7 second halves) and every result bit are those of the symmetric
-// kernel: the k-steps a partial sum covers differ (4 partials of 2 CW k-steps instead of 8 of CW), so S differs in the last bits.
-template <int CW, int NHT, bool NTL>
-__global__ __launch_bounds__(512, 2) void xabs_attn_split_kernel(const XabsArgs a) {
-    constexpr int D = CW * 256, ROWB = D * 2, HALF = 8 * ROWB, KSW = 2 * CW, MTW = 2 * CW, OH = NHT;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    float* spart = reinterpret_cast<float*>(smem + kXabsHalves * HALF);
-    f16* pfrag = reinterpret_cast<f16*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4);
-    float* alpha_l = reinterpret_cast<float*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4 + 1024);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;            // (split, slot) from the workgroup id: see xabs_attn_kernel
-    const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
-    const int S = kXabsSplits, H = a.n_head;
-    if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);
-    if (b >= a.batch) return;
-    constexpr int NT = (kCtx + 15) / 16;
-    const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
-    const int bc = a.cross_div > 1 ? b / a.cross_div : b;
-    const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
-    const int half_w = wave >> 2, wq = wave & 3;
-    const bool s_wave = half_w == 0;
-    int p_off[CW];
-#pragma unroll
-    for (int p = 0; p < CW; ++p) {
-        const int o = (wq * CW + p) * 1024 + lane * 16;
-        const int row = o / ROWB, slot = (o - row * ROWB) >> 4;
-        p_off[p] = (half_w * 8 + row) * ROWB + ((slot ^ xswz(half_w * 8 + row)) << 4);
-    }
-    int hi_mine = -1;
-    auto issue = [&](int i) {
-        unsigned char* dst = smem + ((2 * i + half_w) % kXabsHalves) * HALF + wq * (CW * 1024);
-        const int t16 = (tile_lo + i) * 16;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(enc) + (size_t)t16 * ROWB, 0, (kCtx - t16) * ROWB, 0x00020000);
-#pragma unroll
-        for (int p = 0; p < CW; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, p_off[p], 0, 0, NTL ? 2 : 0);
-#else
-        (void)dst; (void)t16; (void)p_off;
-#endif
-        hi_mine = i;
-    };
-    auto wait_tile = [&](int k) {
-        switch (hi_mine - k) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
-        }
-    };
-    const SeqState* sq = a.seq + b;
-    const int s_act = sq->active, s_done = sq->done, s_ti = sq->token_index;
-    issue(0);
-    if (n > 1) issue(1);
-    if (n > 2) issue(2);
-    if (n > 3 && half_w == 0) issue(3);
-    if (tid < 32) alpha_l[tid] = 1.0f;
-    pfrag[tid] = (f16)0.0f;
-    if (!(s_act && !s_done)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    // DMA bookkeeping shared by both roles: `turn(i)` = the end of interval A_i .. the end of interval B_i
-    auto refill = [&](int i) {                            // after barrier 1 of tile i: tile i's two half slots are free
-        const int nx = i + 3 + (1 - half_w);              // waves 4-7: second half of tile i + 3; waves 0-3: first half of tile i + 4
-        if (nx < n) issue(nx);
-    };
-
-    if (s_wave) {
-        // ================================================================================================ S waves
-        const int o_key = lane & 15, o_h0 = OH * (4 * wq + (lane >> 4));      // owner lane = key | head group << 4; heads o_h0 .. o_h0 + OH - 1
-        const int pos = min(max(s_ti, 0), kMaxTok - 1);
-        float* raw[OH];
-#pragma unroll
-        for (int e = 0; e < OH; ++e) {
-            const int al_slot = (a.align && o_h0 + e < H) ? a.align_slot[a.layer * H + o_h0 + e] : -1;
-            raw[e] = (al_slot >= 0 && pos + 1 < kMaxTok) ? a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + al_slot) * kCtx : nullptr;
-        }
-        XabsQFrag<KSW, NHT> qf;
-        xabs_load_qfrag<KSW, NHT>(a, b, wq * KSW * 32, lane, qf);
-        float m_run[OH], l_run[OH];
-#pragma unroll
-        for (int e = 0; e < OH; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.0f; }
-        const int s_key = lane & 15, s_kg = lane >> 4, s_sw = xswz(s_key);
-        auto s_base = [&](int i) { return smem + ((2 * i + (s_key >> 3)) % kXabsHalves) * HALF + (s_key & 7) * ROWB; };
-        auto s_phase = [&](const unsigned char* row) {       // partial S^T of one tile over this wave's 2 CW k-steps -> LDS
-            f16x8 af[KSW];
-#pragma unroll
-            for (int j = 0; j < KSW; ++j) {
-                const int c = (wq * KSW + j) * 4 + s_kg;
-                af[j] = *reinterpret_cast<const f16x8*>(row + ((c ^ s_sw) << 4));
-            }
-            float sreg[NHT * 4];
-            xabs_s_tile<KSW, NHT>(af, qf, lane, sreg);
-            float* wpart = spart + wq * kXabsSpStride;
-#pragma unroll
-            for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wpart[(ht * 16 + (lane & 15)) * 17 + 4 * (lane >> 4) + r] = sreg[ht * 4 + r];
-        };
-        auto softmax = [&](int i) {                           // the owner lane of (key, heads o_h0 ..): 4 partials, online softmax
-            const int t = (tile_lo + i) * 16 + o_key;
-            const bool valid = t < kCtx;
-#pragma unroll
-            for (int e = 0; e < OH; ++e) {
-                const int head = o_h0 + e;
-                float sc = 0.0f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sc += spart[v * kXabsSpStride + head * 17 + o_key];
-                if (raw[e] && valid) raw[e][t] = sc;          // alignment heads: DecodingCache.alignmentWeights row tokenIndex + 1 (raw scores)
-                sc = valid ? sc : -INFINITY;
-                float mt_ = sc;
-                mt_ = fmaxf(mt_, dpp_mov<kDppXor1>(mt_));
-                mt_ = fmaxf(mt_, dpp_mov<kDppXor2>(mt_));
-                mt_ = fmaxf(mt_, dpp_mov<kDppHalfMirror>(mt_));
-                mt_ = fmaxf(mt_, dpp_mov<kDppMirror>(mt_));
-                const float m_new = fmaxf(m_run[e], mt_);
-                const float m_use = (m_new > m_run[e] + kXabsDefer) ? m_new : m_run[e];
-                const float al = __expf(m_run[e] - m_use);
-                float p = valid ? __expf(sc - m_use) : 0.0f;
-                if (head >= H) p = 0.0f;
-                const f16 ph = (f16)p;
-                float ps = (float)ph;
-                ps += dpp_mov<kDppXor1>(ps);
-                ps += dpp_mov<kDppXor2>(ps);
-                ps += dpp_mov<kDppHalfMirror>(ps);
-                ps += dpp_mov<kDppMirror>(ps);
-                l_run[e] = fmaf(l_run[e], al, ps);
-                m_run[e] = m_use;
-                pfrag[(head | ((o_key >> 3) << 5)) * 8 + (o_key & 7)] = ph;
-                if (o_key == 0) alpha_l[head] = (head < H) ? al : 1.0f;
-            }
-        };
-        wait_tile(0);
-        __syncthreads();
-        s_phase(s_base(0));
-        if (n > 1) wait_tile(1);
-        __syncthreads();                                      // partials(0) in LDS, tile 1 landed
-        softmax(0);
-        __syncthreads();                                      // P^T(0) in LDS
-        for (int i = 0; i < n; ++i) {
-            if (i + 1 < n) s_phase(s_base(i + 1));
-            __syncthreads();                                  // 1: partials(i + 1) in LDS; P V(i) done: tile i is free, P^T / rescale factors may be rewritten
-            refill(i);
-            if (i + 1 < n) softmax(i + 1);
-            if (i + 2 < n) wait_tile(i + 2);
-            __syncthreads();                                  // 2: P^T(i + 1) in LDS; tile i + 2 landed for every wave
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (o_key == 0) {
-#pragma unroll
-            for (int e = 0; e < OH; ++e)
-                if (o_h0 + e < H) a.ml[((size_t)sp * H + o_h0 + e) * a.max_batch + b] = float2{m_run[e], l_run[e]};
-        }
-    } else {
-        // ================================================================================================ P V waves
-        f32x16 acc[MTW];
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-        const int g16 = lane >> 4, sl = lane & 15;
-        const int t_key0 = (g16 >> 1) * 8 + (sl >> 2), t_key1 = t_key0 + 4;
-        const int t_c = (g16 & 1) * 2 + ((sl & 3) >> 1), t_b = (sl & 1) * 8;
-        const int t_off0 = (t_key0 & 7) * ROWB + t_b, t_off1 = (t_key1 & 7) * ROWB + t_b, t_sw0 = xswz(t_key0), t_sw1 = xswz(t_key1);
-        auto t_base = [&](int i) { return smem + ((2 * i + (g16 >> 1)) % kXabsHalves) * HALF; };
-        auto pv = [&](const unsigned char* tile) {            // this wave's 2 CW channel tiles of 32
-            const f16x8 pf = *reinterpret_cast<const f16x8*>(pfrag + lane * 8);
-            const float al = alpha_l[lane & 31];
-            if (__builtin_amdgcn_ballot_w64(al != 1.0f)) {
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][r] *= al;
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                const int c = (wq * MTW + mt) * 4 + t_c;
-                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off0 + ((c ^ t_sw0) << 4)));
-                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + t_off1 + ((c ^ t_sw1) << 4)));
-                const f16x4 f0 = __builtin_bit_cast(f16x4, a0), f1 = __builtin_bit_cast(f16x4, a1);
-                const f16x8 af = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf, acc[mt], 0, 0, 0);
-            }
-        };
-        wait_tile(0);
-        __syncthreads();
-        if (n > 1) wait_tile(1);
-        __syncthreads();
-        __syncthreads();                                      // P^T(0) in LDS
-        for (int i = 0; i < n; ++i) {
-            pv(t_base(i));
-            __syncthreads();                                  // 1
-            refill(i);
-            if (i + 2 < n) wait_tile(i + 2);
-            __syncthreads();                                  // 2
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int head = lane & 31, hl = lane >> 5;
-        if (head < H) {
-            float* pb = a.part + (((size_t)sp * H + head) * (D / 8)) * a.max_batch * 8 + (size_t)b * 8 + 4 * hl;
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c8 = (wq * MTW + mt) * 4 + g;
-                    *reinterpret_cast<float4*>(pb + (size_t)c8 * a.max_batch * 8) = float4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                }
-        }
-    }
-}
-
 // (A register-staged form of this kernel - ordinary buffer loads whose registers are the S-phase A fragments, then a wave-private LDS slot
 // for the transpose reads: no encoder byte crosses waves, no LDS-DMA - was built in round 4, is bit-identical and SLOWER at every batch
 // size: 63.7 vs 57.2 us at 64 slots, 53.8 vs 45.3 us at 8 (profiles/r04y_*).  The tile period of this kernel is not set by the fetch
 // path: about 3 900 cycles per 16-key tile against 830 cycles of MFMA work per SIMD and 3 450 cycles of HBM time at 6.2 TB/s - the rest
-// is the lock-step S -> reduce -> softmax -> P -> P V chain between two workgroup barriers.  Code removed; git history has it.)
+// is the lock-step S -> reduce -> softmax -> P -> P V chain between two workgroup barriers.  A role-split form (waves 0-3: S + softmax of
+// tile i + 1, waves 4-7: P V of tile i, so that one group's matrix burst runs beside the other's latency chain) is correct as well and
+// slower too: 63.2 / 51.4 us (profiles/r04aa_*); so are two re-orderings of the Y interval (profiles/r04z_*).  Code removed; git history
+// has all of it.)
 
 // ---------------------------------------------------------------------------------------------- xabs_vup
 // att[slot][n] = (W_v[n][:] . sum_s w_s O'_s[head(n)][:]) / l + b_v[n],  w_s = exp(m_s - max m),  l = sum_s w_s l_s.
@@ -812,20 +592,11 @@ static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
     once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
 }
-template <int CW, int NHT, bool NTL>
-static void launch_attn_split(const XabsArgs& a, hipStream_t st) {
-    constexpr int lds = xabs_lds_bytes(CW);
-    static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_split_kernel<CW, NHT, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    xabs_attn_split_kernel<CW, NHT, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
-}
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     static const int nt = xabs_env("WH_XABS_NT", 1);          // non-temporal policy on the encoder-output stream (in flight: 19.2 k vs 18.1 k sequence-steps/s, profiles/r04l_*); 0 = A/B side
-    static const int sym = xabs_env("WH_XABS_SYM", 0);        // 1: the symmetric (lock-step) kernel: A/B side, and the form tools/xabs_timeline.py stamps
-    if (a.dbg) { launch_attn_k<CW, NHT, true, false>(a, st); return; }
-    if (sym) { if (nt) launch_attn_k<CW, NHT, false, true>(a, st); else launch_attn_k<CW, NHT, false, false>(a, st); return; }
-    if (nt) launch_attn_split<CW, NHT, true>(a, st); else launch_attn_split<CW, NHT, false>(a, st);
+    if (a.dbg) { launch_attn_k<CW, NHT, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation (tools/xabs_timeline.py)
+    if (nt) launch_attn_k<CW, NHT, false, true>(a, st); else launch_attn_k<CW, NHT, false, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
     ProfScope ps_(KK_DEC_CROSS_ATTN, st);
