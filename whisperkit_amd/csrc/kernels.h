@@ -269,6 +269,7 @@ struct XabsArgs {
     const SeqState* seq;
     float* kpart; int* ticket;       // K-slice scratch of xabs_vup (the projection kernels' part / ticket buffers)
     unsigned long long* dbg;         // WH_DBG=1 timeline stamps of xabs_attn
+    int ablate;                      // WH_XABS_ABLATE (timing probe, results are garbage): bit 0 no LDS-DMA, bit 1 no S / softmax / P V work
     int* gate;                       // cross-attention gate (dec_shared.h, WH_XATT_GATE=1): xabs_qk takes it, xabs_attn's last workgroup returns it
 };
 bool xabs_supported(int d, int n_head);

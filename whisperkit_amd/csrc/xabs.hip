@@ -379,22 +379,23 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
         a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2 + (i - 10)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     for (int i = 0; i < n; ++i) {
         XSTAMP(0);
-        if (i + 1 < n) s_phase(s_base(i + 1), sreg);      // MFMAs first: they execute while the owner lanes walk the softmax chain
+        const bool work = !DBG || !(a.ablate & 2), fetch = !DBG || !(a.ablate & 1);      // (ablation probe: stamped instantiation only)
+        if (work && i + 1 < n) s_phase(s_base(i + 1), sreg);      // MFMAs first: they execute while the owner lanes walk the softmax chain
         XSTAMP(1);
-        if (owner) softmax(i);
+        if (work && owner) softmax(i);
         XSTAMP(2);
         __syncthreads();                                  // C: P^T(i) and the rescale factors are in LDS; partials(i) are consumed
         XSTAMP(3);
-        if (i + 1 < n) write_partials(sreg);
+        if (work && i + 1 < n) write_partials(sreg);
         XSTAMP(4);
-        pv(t_base(i));
+        if (work) pv(t_base(i));
         XSTAMP(5);
-        if (i + 2 < n) wait_tile(i + 2);
+        if (fetch && i + 2 < n) wait_tile(i + 2);
         XSTAMP(6);
         __syncthreads();                                  // D: partials(i + 1) in LDS; tile i + 2 landed; everybody is done with tile i
         XSTAMP(7);
         const int nx = i + 3 + (1 - half_w);              // waves 4-7: second half of tile i + 3; waves 0-3: first half of tile i + 4
-        if (nx < n) issue(nx);
+        if (fetch && nx < n) issue(nx);
         XSTAMP(8);
     }
 #undef XSTAMP
@@ -595,7 +596,8 @@ static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     static const int nt = xabs_env("WH_XABS_NT", 1);          // non-temporal policy on the encoder-output stream (in flight: 19.2 k vs 18.1 k sequence-steps/s, profiles/r04l_*); 0 = A/B side
-    if (a.dbg) { launch_attn_k<CW, NHT, true, false>(a, st); return; }      // WH_DBG=1: the stamped instantiation (tools/xabs_timeline.py)
+    static const int ablate = xabs_env("WH_XABS_ABLATE", 0);  // timing probe (garbage results): 1 no LDS-DMA in the loop, 2 no S / softmax / P V work, 3 both
+    if (a.dbg || ablate) { XabsArgs b = a; b.ablate = ablate; launch_attn_k<CW, NHT, true, false>(b, st); return; }      // the stamped instantiation (tools/xabs_timeline.py)
     if (nt) launch_attn_k<CW, NHT, false, true>(a, st); else launch_attn_k<CW, NHT, false, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
