@@ -53,10 +53,7 @@ def log(msg):
     print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-XABS_SPLITS = 4      # csrc/kernels.h kXabsSplits
-
-
-def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: bool = True, absorbed: bool = False):
+def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: bool = True, absorbed: bool = False, splits: int = 4):
     """(bound, amount) one launch of each kernel kind must do: HBM bytes for the bandwidth-bound kernels, FLOPs for the
     MFMA-bound ones.  fp16 weights / KV / GEMM operands, fp32 residuals; decoder
     activations travel as f16 hi|lo plane pairs (4 B per element)."""
@@ -97,13 +94,13 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
     if kind == "dec_cross_attn" and absorbed:
         # weight-absorbed form (csrc/xabs.hip): the slot's encoder output [1500][d] f16 ONCE, absorbed queries (f16 hi | lo) in,
         # every key split's unnormalised O' [H][d] f32 + (m, l) out
-        return "hbm", B * T * d * 2 + B * H * d * 4 + XABS_SPLITS * B * H * (d * 4 + 8)
+        return "hbm", B * T * d * 2 + B * H * d * 4 + splits * B * H * (d * 4 + 8)
     if kind == "dec_cross_attn":  # 1500 K and V rows per slot, q in, att planes out
         return "hbm", B * 2 * T * d * 2 + 2 * act
     if kind == "dec_xabs_qk":    # W_k^T tiles + q in, absorbed queries [H][d] per slot (f16 hi | lo) out
         return "hbm", d * d * 2 + act + B * H * d * 4
     if kind == "dec_xabs_vup":   # W_v tiles + the split partials in, att planes out
-        return "hbm", d * d * 2 + XABS_SPLITS * B * H * (d * 4 + 8) + act
+        return "hbm", d * d * 2 + splits * B * H * (d * 4 + 8) + act
     if kind == "dec_proj_fc1":   # W[4d][d] + planes in, hidden hi|lo plane pair out
         return "hbm", 4 * d * d * 2 + act + B * 4 * d * 4
     if kind == "dec_proj_fc2":   # W[d][4d] + hidden plane pair in, x read + written, planes out
@@ -126,11 +123,12 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
     api._check(lib.wh_measure_kernels(sess.handle, B, n_meas, avg, cnt))
     avg_len = (n_meas + 1) / 2.0
     absorbed = lib.wh_session_cross_attention_mode(sess.handle) == 1     # the session's cross-attention streams the encoder output (csrc/xabs.hip)
+    splits = int(lib.wh_session_cross_attention_splits(sess.handle)) if absorbed else 0     # key splits per slot (partials written and re-read)
     table, step_us = {}, {}
     for k, name in enumerate(names):
         if cnt[k] == 0:
             continue
-        bound, amount = algorithmic_work(name, dims, B, avg_len, absorbed=absorbed)
+        bound, amount = algorithmic_work(name, dims, B, avg_len, absorbed=absorbed, splits=splits)
         is_dec = name.startswith("dec_") or name == "sampler"
         per_step = cnt[k] / n_meas * decode_steps if is_dec else cnt[k]      # launches in one full hot-path step
         step_us[name] = avg[k] * per_step
@@ -147,7 +145,7 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
     traffic = {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-        if tj.get("model") == model_name and tj.get("chunks_per_step") == B:
+        if tj.get("model") == model_name and tj.get("chunks_per_step") == B and (not absorbed or tj.get("cross_attention_splits", 4) == splits):
             traffic = tj["bytes_per_launch"]
     except (OSError, ValueError):
         pass
@@ -156,7 +154,7 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
         table[name]["traffic"] = traffic.get(name)
     dom = max(step_us, key=step_us.get)
     t = table[dom]
-    return {"kernel": dom, "cross_attention": "absorbed (encoder output streamed once per layer, csrc/xabs.hip)" if absorbed else "per-layer K / V rows",
+    return {"kernel": dom, "cross_attention": f"absorbed (encoder output streamed once per layer, {splits} key splits per slot, csrc/xabs.hip)" if absorbed else "per-layer K / V rows",
             "bound": t["bound"], "achieved": t["achieved"],
             "peak": HBM_PEAK_GBS if t["bound"] == "hbm" else MFMA_F16_PEAK_TF, "unit": t["unit"], "frac": t["frac"], "traffic": t["traffic"],
             "avg_us": t["avg_us"], "alg_per_launch": t["alg_per_launch"], "share_of_step_time": t["share_of_step"],
@@ -201,7 +199,8 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     cap = max(B, n_local)                                        # device batch capacity = the 1-GPU batch
     G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch
     slots = max(1, G * n_local)
-    sessions = [api.Session(model, slots) for _ in range(F)]
+    xsplits = args.cross_attention_splits if args.cross_attention_splits >= 0 else (2 if F > 1 else 0)
+    sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None) for _ in range(F)]
     sess = sessions[0]
     chunks = [np.ascontiguousarray(synthetic_chunk(1234 + first + b), dtype=np.float32) for b in range(n_local)]   # host float32 PCM
     opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
@@ -300,6 +299,8 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     lat = [l for _, l in durs]
     durs = [d for d, _ in durs]
     out = {"value": audio_s / elapsed, "elapsed": elapsed, "audio_s": audio_s, "dec_steps": dec_steps[0], "B": B, "inflight": F,
+           "cross_attention": (f"absorbed, {sess.crossAttentionSplits} key splits per slot ({slots * sess.crossAttentionSplits} workgroups = CUs per launch)"
+                               if sess.crossAttentionMode == 1 else "per-layer K / V rows"),
            "total": total, "n_local": n_local, "steps_per_batch": G, "slots": slots,
            "median_step_latency_ms": float(np.median(lat)) * 1e3, "median_ms_per_step": float(np.median(durs)) * 1e3 / Fe, "n_median": int(len(durs))}
     if rank == 0 and F > 1 and args.serial_reference:
@@ -335,7 +336,30 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                          "us_per_decoder_step": med[4] * 1e6 / max(r2[0].steps, 1)}
         log(f"{model_name}: stages {json.dumps({k: round(v, 3) for k, v in out['stages'].items()})}")
     if rank == 0 and want_roofline:
-        out["roofline"] = measure_kernels(sess, dims, slots, 16, dec_steps[0], model_name)
+        rf = out["roofline"] = measure_kernels(sess, dims, slots, 16, dec_steps[0], model_name)
+        ns = sess.crossAttentionSplits
+        if ns:
+            # the cross-attention takes slots x splits workgroups, one per CU: with several sessions in flight it is configured to leave CUs to
+            # the other sessions' kernels.  The same kernel with 4 splits (the whole chip at 64 slots) is timed beside it, alone on the GPU.
+            rf["workgroups"] = slots * ns
+            rf["cu_share"] = round(min(1.0, slots * ns / 256.0), 3)
+            if ns != 4:
+                s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=4)
+                for k in range(G):
+                    for b, x in enumerate(chunks):
+                        s4.padOrTrim(x, k * n_local + b)
+                s4.logMelSpectrogram(slots); s4.encodeFeatures(slots); s4.prepareDecoderInputs(slots)
+                r4 = measure_kernels(s4, dims, slots, 16, dec_steps[0], model_name)
+                s4.close()
+                k4 = r4["kernels"]["dec_cross_attn"]
+                rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "workgroups": slots * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
+                                                              "achieved": k4["achieved"], "unit": k4["unit"], "frac": k4["frac"]}
+        # whole step: algorithmic HBM bytes of every bandwidth-bound launch of one step / the step's share of the timed region
+        hbm_bytes = sum(k["alg_per_launch"] * k["launches_per_step"] for k in rf["kernels"].values() if k["bound"] == "hbm")
+        ms_step = elapsed / steps * 1e3
+        rf["whole_step"] = {"hbm_bound_algorithmic_bytes": int(hbm_bytes), "ms_per_step": round(ms_step, 3),
+                            "achieved": round(hbm_bytes / (ms_step * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(hbm_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "the matrix-core-bound encoder launches of the step run inside the same time and are not counted"}
         log(f"{model_name}: roofline leg done")
 
     # ---- CPU baseline: the oracle (port of the same algorithm) on the host cores, bounded sample
@@ -449,6 +473,9 @@ def main():
                     "over the ranks (SURVEY 8d c4; the default); weak = --batch chunks per step and GPU")
     ap.add_argument("--gather", choices=["wh_comm", "torch"], default="wh_comm", help="N > 1: result-record all-gather through the C-ABI communicator "
                     "(RCCL, or the library's TCP transport in a --single-device rehearsal) or through torch.distributed")
+    ap.add_argument("--cross-attention-splits", type=int, default=-1, help="key splits per slot of the absorbed cross-attention = the share of the CUs one "
+                    "session's cross-attention takes (wh_session_create_tuned): -1 = 2 when several device batches are in flight (the other sessions' "
+                    "kernels keep half of the chip; profiles/r04ad_*, r04ae_*), the library's choice (4) for one")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")
@@ -519,7 +546,7 @@ def main():
     def brief(o, n):
         return {"value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / n * 1e3, 3),
                 "median_ms_per_step": round(o["median_ms_per_step"], 3), "chunks_per_step": o["B"], "steps_in_flight": o["inflight"],
-                "decoder_steps": o["dec_steps"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
+                "decoder_steps": o["dec_steps"], "cross_attention": o["cross_attention"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
     if extra and headline:
         o = run_config(args, "large-v3", 8, 3, 9, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
         other["round-1 headline configuration: whisper-large-v3, 8 x 30 s chunks per step, 3 steps in flight, greedy, 1 GPU"] = brief(o, 9)
@@ -553,7 +580,7 @@ def main():
                                    f"greedy (T=0), {main_cfg['dec_steps']} decoder steps/chunk, "
                                    "random-init weights, PCM handed over in host memory, segments built on the host",
                        "chunks_per_step": total, "chunks_per_gpu": nl, "steps_per_device_batch": G, "device_batch_slots": main_cfg["slots"],
-                       "parallelism": f"chunk-dp{world}", "decoder_steps": main_cfg["dec_steps"],
+                       "parallelism": f"chunk-dp{world}", "decoder_steps": main_cfg["dec_steps"], "cross_attention": main_cfg["cross_attention"],
                        "steps_in_flight": main_cfg["inflight"] * G, "device_batches_in_flight": main_cfg["inflight"], "result_gather": gather_kind,
                        "serial_ms_per_step": round(main_cfg.get("serial_ms_per_step", 0.0), 3) or None,
                        "arith": "fp16 operands (decoder activations as f16 hi|lo pairs), fp32 accumulate/residual/softmax; mel fp32"},

@@ -206,9 +206,17 @@ int wh_session_max_batch(const wh_session* s);
    wh_prepare_decoder_inputs.  Fixed at creation (width supported and max_batch >= 48, or WH_XABS=0 / 1); results agree within the
    parity tolerance, bit-identity across batch sizes holds within a mode. */
 int wh_session_cross_attention_mode(const wh_session* s);
+/* key splits per slot of the absorbed cross-attention (0 in K / V-row mode): slots x splits workgroups, one per CU, stream the
+   encoder output; fixed at creation (bench.py prices the kernel's algorithmic bytes with it) */
+int wh_session_cross_attention_splits(const wh_session* s);
 /* wh_session_create with the cross-attention mode chosen by the caller: -1 automatic (= wh_session_create), 0 K / V rows, 1 absorbed
    (WH_ERR_INVALID_ARGUMENT when the model width does not support it) */
 int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out);
+/* ... and the key splits per slot of the absorbed form: 0 automatic, 1 .. 4.  One workgroup per (slot, split) owns a CU while it
+   streams, so slots x splits is the share of the chip one session's cross-attention takes: 4 is fastest for a session running alone
+   (64 slots: 256 workgroups), 2 when several sessions are in flight on the GPU (the other sessions' kernels keep the other half;
+   profiles/r04ad_*).  Ignored in K / V-row mode. */
+int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
 /* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...) */
 int wh_debug_peek(wh_session* s, const char* name, void* out_host, size_t nbytes);
 int wh_session_synchronize(wh_session* s);

@@ -135,3 +135,49 @@ def test_window_hooks_of_the_native_orchestrator():
     sess.setWindowHooks()
     assert sess.transcribe([audio], opts)[0].tokens == plain.tokens
     sess.close(); model.close()
+
+
+@pytest.mark.parametrize("splits", [1, 2, 3, 4])
+def test_absorbed_cross_attention_key_split_counts_vs_oracle(splits):
+    """wh_session_create_tuned: the absorbed cross-attention with 1 .. 4 key splits per slot (slots x splits workgroups, one per CU:
+    the share of the chip a session's cross-attention takes).  Every count against the oracle (logits <= 1e-3, alignment rows
+    <= 1e-4) at large-v3's width and 20 heads (two head tiles), 9 slots (a ragged last group of 4 slots); the getter reports the count;
+    counts outside 0 .. 4 are refused."""
+    import numpy as np
+    from oracle import decoding as OD
+    from oracle.model import OracleWhisper
+    from whisperkit_amd import api, weights
+    from whisperkit_amd.synth import synthetic_chunk
+    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    sd = weights.synthetic_state_dict(dims, seed=11)
+    model = api.Model(dims, sd)
+    if splits == 4:
+        import ctypes
+        for bad in (-1, 5):
+            h = ctypes.c_void_p()
+            with pytest.raises(api.WhisperError):
+                api._check(model.lib.wh_session_create_tuned(model.handle, 4, 1, bad, ctypes.byref(h)))
+        s0 = api.Session(model, 4, crossAttentionMode=0, crossAttentionSplits=2)
+        assert s0.crossAttentionMode == 0 and s0.crossAttentionSplits == 0
+    B = 9
+    sess = api.Session(model, B, crossAttentionMode=1, crossAttentionSplits=splits)
+    assert sess.crossAttentionMode == 1 and sess.crossAttentionSplits == splits
+    xs = [synthetic_chunk(4000 + 17 * b) for b in range(B)]
+    for b in range(B):
+        sess.padOrTrim(xs[b], b)
+    sess.logMelSpectrogram(B); sess.encodeFeatures(B); sess.prepareDecoderInputs(B)
+    om = OracleWhisper(dims, sd)
+    st, _ = OD.special_tokens_for_vocab(dims.n_vocab)
+    check = [0, 4, B - 1]
+    states = {b: om.new_state(sess.getEncoderOutput(b).astype(np.float16).astype(np.float32)) for b in check}
+    steps = [(st.startOfTranscriptToken, 0), (st.englishToken, 1), (st.transcribeToken, 2), (1029, 3), (400, 150), (77, 222)]
+    for t, pos in steps:
+        got = sess.predictLogits([(t + 3 * b) % 50000 if pos > 2 else t for b in range(B)], [pos] * B)
+        for b in check:
+            ref = states[b].step(int((t + 3 * b) % 50000 if pos > 2 else t), pos)
+            e = float(np.abs(got[b] - ref).max())
+            assert e <= 1e-3, (splits, b, pos, e)
+    rows = [p + 1 for _, p in steps if p + 1 < 224]
+    for b in check:
+        al = sess.getAlignmentWeights(b)
+        assert np.abs(al[rows] - states[b].alignment[rows]).max() <= 1e-4, (splits, b)

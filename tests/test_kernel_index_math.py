@@ -86,3 +86,101 @@ def test_beam_row_owner_table_never_reads_a_row_another_history_overwrote():
                     new_owner[d_, : t + 1] = owner[s_, : t + 1]
                     new_hist[d_] = history[s_]
             owner, history = new_owner, new_hist
+
+
+# ---------------------------------------------------------------------------------------------- xabs.hip (round 4)
+def _xswz(key):
+    return ((key & 3) << 2) | ((0x78 >> (2 * ((key >> 2) & 3))) & 3)
+
+
+def test_xabs_workgroup_map_covers_every_slot_and_split_once():
+    """xabs_attn_kernel: workgroup id -> (split, slot) for a runtime split count.  Every (split, slot) of the batch exactly once, a
+    group of 4 consecutive slots of one split on ONE XCD (id % 8: their 32-byte partial sectors share 128-byte lines), XCDs balanced to
+    within one group, and the launcher's grid is the smallest multiple of 32 ids that holds the groups."""
+    for batch in (1, 3, 4, 8, 20, 48, 63, 64, 100, 128):
+        for S in (2, 3, 4):
+            n_grp = (batch + 3) // 4
+            grid = (n_grp * S + 7) // 8 * 32
+            seen, per_xcd = {}, [set() for _ in range(8)]
+            for wg in range(grid):
+                xr, xq = wg & 7, wg >> 3
+                grp = (xq >> 2) * 8 + xr
+                sp = grp // n_grp
+                b = ((grp - sp * n_grp) << 2) + (xq & 3)
+                if sp >= S or b >= batch:
+                    continue
+                assert (sp, b) not in seen
+                seen[(sp, b)] = wg
+                per_xcd[xr].add((sp, b >> 2))
+            assert len(seen) == S * batch, (batch, S)
+            for (sp, b), wg in seen.items():
+                assert seen[(sp, b & ~3)] & 7 == wg & 7
+            sizes = [len(x) for x in per_xcd]
+            assert max(sizes) - min(sizes) <= 1, (batch, S, sizes)
+            assert grid % 32 == 0 and grid - 32 < n_grp * S * 4 <= grid
+
+
+def test_xabs_key_splits_tile_the_1500_positions():
+    for S in (2, 3, 4):
+        NT = (1500 + 15) // 16
+        edges = [sp * NT // S for sp in range(S + 1)]
+        assert edges[0] == 0 and edges[-1] == NT and all(b - a >= 4 for a, b in zip(edges, edges[1:]))      # the prologue requests tiles 0 .. 3
+
+
+def test_xabs_swizzle_is_conflict_free_for_both_lds_read_patterns():
+    """LDS tile row = D * 2 bytes (a multiple of 512: every row starts at bank 0), 16-byte chunk c of row `key` stored at chunk
+    c ^ xswz(key).  (1) S phase, ds_read_b128: lane = key | k group << 4 reads chunk (k-step * 4 + k group) of row key; the hardware
+    serves the wave as 4 groups of 16 lanes (MI355X_MICROARCH.md), each must touch 16 distinct 16-byte bank
+    groups (64 banks x 4 B = 16 chunks).  (2) P V phase, ds_read_b64_tr_b16: 32-lane halves, each lane 8 bytes: 32 distinct 8-byte bank
+    pairs.  Both for every k-step / channel tile."""
+    for D in (512, 768, 1024, 1280):
+        rowb = D * 2
+        assert rowb % 256 == 0
+        # (1) lanes 0..15 of a group share the k group, differ in key
+        for kstep in range(D // 32):
+            for kg in range(4):
+                chunks = set()
+                for key in range(16):
+                    c = kstep * 4 + kg
+                    addr = (key & 7) * rowb + ((c ^ _xswz(key)) << 4)      # key >> 3 selects the half slot (4096-byte multiple: same bank)
+                    chunks.add((addr >> 4) & 15)
+                assert len(chunks) == 16, (D, kstep, kg)
+        # (2) supplier lane: 16-lane group g16, index sl: key = (g16 >> 1) * 8 + (sl >> 2) (+ 4), chunk 4 c4 + (g16 & 1) * 2 + ((sl & 3) >> 1), byte (sl & 1) * 8
+        for c4 in range(D // 32):
+            for second in (0, 4):
+                for half in (0, 1):                      # lanes 0..31, 32..63
+                    pairs = set()
+                    for lane in range(half * 32, half * 32 + 32):
+                        g16, sl = lane >> 4, lane & 15
+                        key = (g16 >> 1) * 8 + (sl >> 2) + second
+                        c = c4 * 4 + (g16 & 1) * 2 + ((sl & 3) >> 1)
+                        addr = (key & 7) * rowb + ((c ^ _xswz(key)) << 4) + (sl & 1) * 8
+                        pairs.add((addr >> 3) & 31)
+                    assert len(pairs) == 32, (D, c4, second, half)
+
+
+def test_xabs_ring_of_seven_half_tiles_never_overwrites_a_resident_tile():
+    """Half tile k = 2 tile + {0, 1} lives in ring slot k % 7.  At the end of loop iteration i (after barrier D) waves 4-7 request the
+    second half of tile i + 3 and waves 0-3 the first half of tile i + 4; tiles i + 1 (P V next) and i + 2 (S next) and the in-flight
+    halves of tile i + 3 must not share a slot with what is requested."""
+    for n in (5, 23, 24, 31, 32, 47):
+        live = {}                                               # ring slot -> half id
+        def put(h):
+            s = h % 7
+            live[s] = h
+        for h in (0, 1, 2, 3, 4, 5, 6):                         # prologue: tiles 0, 1, 2 and the first half of tile 3
+            if h // 2 < n:
+                put(h)
+        for i in range(n):
+            for t in (i, i + 1):                                # resident during iteration i: tile i (P V), tile i + 1 (S)
+                if t < n:
+                    assert live.get((2 * t) % 7) == 2 * t and live.get((2 * t + 1) % 7) == 2 * t + 1, (n, i, t)
+            needed = {h for t in (i + 1, i + 2) if t < n for h in (2 * t, 2 * t + 1)}
+            if i + 3 < n:
+                needed.add(2 * (i + 3))
+            new = [h for h in (2 * (i + 3) + 1, 2 * (i + 4)) if h // 2 < n]
+            for h in new:
+                victim = live.get(h % 7)
+                assert victim is None or victim not in needed, (n, i, h, victim)
+                assert victim is None or victim // 2 <= i, (n, i, h, victim)     # only tile i (or older) is overwritten
+                put(h)

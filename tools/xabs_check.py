@@ -22,7 +22,7 @@ dims = weights.MODEL_DIMS[name]
 sd = weights.synthetic_state_dict(dims, seed=11)
 model = api.Model(dims, sd)
 d, H, Lyr = dims.n_text_state, dims.n_text_head, dims.n_text_layer
-S = 4
+S = 4            # key splits per slot: replaced by the session's count below
 
 
 def peek(sess, nm, shape, dtype):
@@ -50,6 +50,7 @@ def planes(sess, nm):       # [n_bt][d/16][2][32][8] hi | lo -> [R][d]
 
 
 s0, s1 = make(0), make(1)
+S = s1.crossAttentionSplits
 st = model.specialTokens
 steps = [(st.start_of_transcript_token, 0), (st.english_token, 1), (st.transcribe_token, 2), (1029, 3), (400, 150)]
 for tok, pos in steps:

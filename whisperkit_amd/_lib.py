@@ -130,9 +130,11 @@ SYMBOLS = {
     "wh_session_destroy": (None, [VP]),
     "wh_session_max_batch": (I, [VP]),
     "wh_session_cross_attention_mode": (I, [VP]),
+    "wh_session_cross_attention_splits": (I, [VP]),
     "wh_session_set_window_hooks": (I, [VP, C.POINTER(WhWindowHooks)]),
     "wh_transcription_set_segment_times": (I, [VP, I, F, F]),
     "wh_session_create_with_mode": (I, [VP, I, I, PVP]),
+    "wh_session_create_tuned": (I, [VP, I, I, I, PVP]),
     "wh_debug_peek": (I, [VP, C.c_char_p, VP, C.c_size_t]),
     "wh_session_synchronize": (I, [VP]),
     "wh_session_stream": (VP, [VP]),

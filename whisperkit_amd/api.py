@@ -446,19 +446,27 @@ class Model:
 class Session:
     """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
 
-    def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None):
+    def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None, crossAttentionSplits: Optional[int] = None):
         """crossAttentionMode: None = the library's choice (absorbed from 48 slots at the widths that support it), 0 = per-layer
-        cross K / V rows, 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip)."""
+        cross K / V rows, 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
+        crossAttentionSplits: key splits per slot of the absorbed form (None = the library's choice): slots x splits workgroups each own a CU
+        while they stream, so this is the share of the GPU the session's cross-attention takes - 4 for a session running alone, 2 when
+        several sessions share the GPU."""
         self.model, self.lib, self.B = model, model.lib, maxBatch
         self.handle = C.c_void_p()
-        if crossAttentionMode is None:
+        if crossAttentionMode is None and crossAttentionSplits is None:
             _check(self.lib.wh_session_create(model.handle, maxBatch, C.byref(self.handle)))
         else:
-            _check(self.lib.wh_session_create_with_mode(model.handle, maxBatch, int(crossAttentionMode), C.byref(self.handle)))
+            _check(self.lib.wh_session_create_tuned(model.handle, maxBatch, -1 if crossAttentionMode is None else int(crossAttentionMode),
+                                                    int(crossAttentionSplits or 0), C.byref(self.handle)))
 
     @property
     def crossAttentionMode(self) -> int:
         return int(self.lib.wh_session_cross_attention_mode(self.handle))
+
+    @property
+    def crossAttentionSplits(self) -> int:
+        return int(self.lib.wh_session_cross_attention_splits(self.handle))
 
     def close(self):
         if self.handle:

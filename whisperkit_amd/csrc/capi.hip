@@ -398,16 +398,21 @@ static int dalloc(T** p, size_t n, bool zero = true) {
 }
 #define DALLOC(ptr, n) do { int _r = dalloc(&(ptr), (size_t)(n)); if (_r) { wh_session_destroy(s); return _r; } } while (0)
 
-static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out);
-extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) { return session_create_impl(m, max_batch, -1, out); }
-extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
+extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) { return session_create_impl(m, max_batch, -1, 0, out); }
+extern "C" int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out) {
     if (cross_attention_mode < -1 || cross_attention_mode > 1)
-        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create_with_mode: cross_attention_mode %d (expected -1 auto, 0 K / V rows, 1 absorbed)", cross_attention_mode);
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_mode %d (expected -1 auto, 0 K / V rows, 1 absorbed)", cross_attention_mode);
+    if (cross_attention_splits < 0 || cross_attention_splits > kXabsSplits)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_splits %d (expected 0 auto, 1 .. %d)", cross_attention_splits, kXabsSplits);
     if (cross_attention_mode == 1 && m && m->xabs.empty())
-        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create_with_mode: the absorbed cross-attention needs a model width of 512 / 768 / 1024 / 1280 (this model: %d)", m->dims.n_text_state);
-    return session_create_impl(m, max_batch, cross_attention_mode, out);
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: the absorbed cross-attention needs a model width of 512 / 768 / 1024 / 1280 (this model: %d)", m->dims.n_text_state);
+    return session_create_impl(m, max_batch, cross_attention_mode, cross_attention_splits, out);
 }
-static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
+extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
+    return wh_session_create_tuned(m, max_batch, cross_attention_mode, 0, out);
+}
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
     if (max_batch < 1 || max_batch > 128) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 128]", max_batch);
     WH_HIP(hipSetDevice(m->device));
@@ -441,6 +446,7 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
         }
         Carver c; c.base = (char*)s->xabs_blob;
         s->xabs.layers_host = m->xabs.data();
+        s->xabs.n_split = cross_attention_splits > 0 ? cross_attention_splits : xabs_splits(max_batch);
         s->xabs.qf_hi = c.take<f16>(B * nht * (d / 32) * 512); s->xabs.qf_lo = c.take<f16>(B * nht * (d / 32) * 512);
         s->xabs.part = c.take<float>(S * H * (d / 8) * B * 8);
         s->xabs.ml = c.take<float2>(S * H * B);
@@ -500,6 +506,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
 }
 extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1; }
 extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ? (s->use_xabs ? 1 : 0) : -1; }
+extern "C" int wh_session_cross_attention_splits(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.n_split : 0) : -1; }
 // Development aid: copy the first `nbytes` of a named decode-step buffer to the host (after the session's stream has drained).
 extern "C" int wh_debug_peek(wh_session* s, const char* name, void* out, size_t nbytes) {
     CHECK_SESSION(s);

@@ -841,7 +841,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         if (db.xabs) {          // weight-absorbed cross-attention over the encoder output (xabs.hip): no per-layer K / V rows
             const Xabs& X = *db.xabs;
             XabsArgs xa{};
-            xa.batch = B; xa.max_batch = db.max_batch; xa.d = d; xa.n_head = H; xa.layer = l; xa.n_split = kXabsSplits; xa.cross_div = db.cross_div;
+            xa.batch = B; xa.max_batch = db.max_batch; xa.d = d; xa.n_head = H; xa.layer = l; xa.n_split = X.n_split; xa.cross_div = db.cross_div;
             xa.enc = X.enc; xa.q = D.q; xa.wkT = X.layers_host[l].wkT; xa.wv_t = X.layers_host[l].wv_t; xa.bv = X.layers_host[l].bv;
             xa.qf_hi = X.qf_hi; xa.qf_lo = X.qf_lo; xa.part = X.part; xa.ml = X.ml; xa.att_hi = D.zb_hi; xa.att_lo = D.zb_lo;
             xa.align = db.align; xa.align_slot = db.align_slot; xa.n_align = db.n_align; xa.seq = db.seq; xa.kpart = D.part; xa.ticket = D.ticket;

@@ -246,7 +246,10 @@ void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const fl
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
-constexpr int kXabsSplits = 4;      // key splits per slot: a constant of the build (the combine order fixes the bits)
+constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); a session uses Xabs::n_split of them, fixed at creation
+// key splits of a session: one workgroup per (slot, split) owns a whole CU (LDS, registers), so slots x splits is the number of CUs the
+// kernel takes.  WH_XABS_SPLITS overrides (A/B).
+int xabs_splits(int max_batch);
 struct XabsLayerW {
     const f16* wkT;      // W_k^T tiles [H][d / 32][4][64][8] (A fragments of the Q' projection)
     const f16* wv_t;     // W_v in the decoder projection tiling [d / 32][d / 16][64][8]
@@ -258,6 +261,7 @@ struct Xabs {
     f16 *qf_hi, *qf_lo;  // [Bmax][heads padded to 16 / 32][d] absorbed queries Q' = W_k^T q, f16 hi | lo
     float* part;         // [splits][H][d / 8][Bmax][8] unnormalised O' of every key split
     float2* ml;          // [splits][H][Bmax] (running maximum, sum)
+    int n_split;         // key splits per slot (1 .. kXabsSplits), a constant of the session (the combine order fixes the bits)
 };
 struct XabsArgs {
     int batch, max_batch, d, n_head, layer, n_split, cross_div;

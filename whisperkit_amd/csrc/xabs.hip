@@ -194,13 +194,14 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     float* alpha_l = reinterpret_cast<float*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4 + 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: no waterfall loops around the buffer resource / M0
-    // workgroup id -> (split, slot): id % 8 is the XCD; an XCD takes ONE split index (two XCDs per split) and whole groups of 4 consecutive
-    // slots, whose 32-byte partial sectors share 128-byte lines (part[split][head][c / 8][slot][8]): the lines are assembled in one L2
+    // workgroup id -> (split, slot): id % 8 is the XCD; an XCD takes whole groups of 4 consecutive slots of one split, whose 32-byte
+    // partial sectors share 128-byte lines (part[split][head][c / 8][slot][8]): the lines are assembled in one L2
     const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;
-    const int sp = xr & 3, b = (((xq >> 2) * 2 + (xr >> 2)) << 2) + (xq & 3);
-    const int S = kXabsSplits, H = a.n_head;
+    const int S = a.n_split, H = a.n_head;
+    const int n_grp = (a.batch + 3) >> 2, grp = (xq >> 2) * 8 + xr;        // group = (split, 4 consecutive slots); group % 8 = its XCD
+    const int sp = grp / n_grp, b = ((grp - sp * n_grp) << 2) + (xq & 3);
     if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);     // the grid is draining from here on
-    if (b >= a.batch) return;
+    if (sp >= S || b >= a.batch) return;
     // WH_DBG=1: shader-clock stamps (tools/xabs_timeline.py): 9 entry, 10 slot state known, 11 loop entry, 12 loop exit, 13 partials stored
 #define XPHASE(k) do { if constexpr (DBG) if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 64) \
         a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -579,6 +580,13 @@ static int xabs_env(const char* name, int dflt) { const char* e = getenv(name); 
 
 bool xabs_supported(int d, int n_head) { return d % 256 == 0 && d >= 512 && d <= 1280 && n_head <= 32; }
 
+int xabs_splits(int max_batch) {
+    const int e = xabs_env("WH_XABS_SPLITS", 0);
+    if (e >= 1 && e <= kXabsSplits) return e;
+    (void)max_batch;
+    return kXabsSplits;
+}
+
 void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
     ProfScope ps_(KK_DEC_XQK, st);
     const dim3 grid(a.d / 256, a.n_head, n_bt);
@@ -591,7 +599,8 @@ static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
     constexpr int lds = xabs_lds_bytes(CW);
     static PerDeviceOnce once;
     once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((a.batch + 7) / 8 * 8 * kXabsSplits)), 512, lds, st>>>(a);
+    const int n_grp = (a.batch + 3) / 4 * a.n_split;         // (split, 4 slots) groups, 8 of them (one per XCD) to every 32 workgroup ids
+    xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((n_grp + 7) / 8 * 32)), 512, lds, st>>>(a);
 }
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
@@ -617,12 +626,18 @@ void launch_xabs_vup(const XabsArgs& a, int n_bt, hipStream_t st) {
     constexpr int ks = 4;
     const int nx = a.n_head * ks;
     const unsigned grid = (unsigned)(((nx + 7) / 8) * 8 * n_bt);
-    switch (a.d / 256) {
-        case 2: xabs_vup_kernel<kXabsSplits, 2><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
-        case 3: xabs_vup_kernel<kXabsSplits, 3><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
-        case 4: xabs_vup_kernel<kXabsSplits, 4><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
-        default: xabs_vup_kernel<kXabsSplits, 5><<<grid, 256, 0, st>>>(a, ks, n_bt); break;
+#define XVUP(S_) do { switch (a.d / 256) { \
+        case 2: xabs_vup_kernel<S_, 2><<<grid, 256, 0, st>>>(a, ks, n_bt); break; \
+        case 3: xabs_vup_kernel<S_, 3><<<grid, 256, 0, st>>>(a, ks, n_bt); break; \
+        case 4: xabs_vup_kernel<S_, 4><<<grid, 256, 0, st>>>(a, ks, n_bt); break; \
+        default: xabs_vup_kernel<S_, 5><<<grid, 256, 0, st>>>(a, ks, n_bt); break; } } while (0)
+    switch (a.n_split) {
+        case 1: XVUP(1); break;
+        case 2: XVUP(2); break;
+        case 3: XVUP(3); break;
+        default: XVUP(4); break;
     }
+#undef XVUP
 }
 
 }  // namespace wh
