@@ -199,7 +199,9 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     cap = max(B, n_local)                                        # device batch capacity = the 1-GPU batch
     G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch
     slots = max(1, G * n_local)
-    xsplits = args.cross_attention_splits if args.cross_attention_splits >= 0 else (2 if F > 1 else 0)
+    # sessions in flight: the cross-attention of one session takes about half of the 256 CUs (slots x splits = 128 workgroups), the other
+    # sessions' kernels keep the rest (64 slots x 3: 2049 -> 2270 audio-s/s against 4 splits, 128 slots x 3: 2240 -> 2537; profiles/r04ad..af)
+    xsplits = args.cross_attention_splits if args.cross_attention_splits >= 0 else (max(1, min(4, 128 // max(slots, 1))) if F > 1 else 0)
     sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None) for _ in range(F)]
     sess = sessions[0]
     chunks = [np.ascontiguousarray(synthetic_chunk(1234 + first + b), dtype=np.float32) for b in range(n_local)]   # host float32 PCM
@@ -349,6 +351,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                     for b, x in enumerate(chunks):
                         s4.padOrTrim(x, k * n_local + b)
                 s4.logMelSpectrogram(slots); s4.encodeFeatures(slots); s4.prepareDecoderInputs(slots)
+                s4.decodeText(prompt, opts, batch=slots)          # (wh_measure_kernels re-arms the slot state the last decodeText left)
                 r4 = measure_kernels(s4, dims, slots, 16, dec_steps[0], model_name)
                 s4.close()
                 k4 = r4["kernels"]["dec_cross_attn"]
@@ -474,8 +477,8 @@ def main():
     ap.add_argument("--gather", choices=["wh_comm", "torch"], default="wh_comm", help="N > 1: result-record all-gather through the C-ABI communicator "
                     "(RCCL, or the library's TCP transport in a --single-device rehearsal) or through torch.distributed")
     ap.add_argument("--cross-attention-splits", type=int, default=-1, help="key splits per slot of the absorbed cross-attention = the share of the CUs one "
-                    "session's cross-attention takes (wh_session_create_tuned): -1 = 2 when several device batches are in flight (the other sessions' "
-                    "kernels keep half of the chip; profiles/r04ad_*, r04ae_*), the library's choice (4) for one")
+                    "session's cross-attention takes (wh_session_create_tuned): -1 = 128 / slots (2 at 64 slots) when several device batches are in "
+                    "flight (the other sessions' kernels keep half of the chip; profiles/r04ad_*, r04ae_*), the library's choice (4) for one")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")

@@ -144,7 +144,7 @@ def test_absorbed_cross_attention_key_split_counts_vs_oracle(splits):
     <= 1e-4) at large-v3's width and 20 heads (two head tiles), 9 slots (a ragged last group of 4 slots); the getter reports the count;
     counts outside 0 .. 4 are refused."""
     import numpy as np
-    from oracle import decoding as OD
+    from oracle import decode as OD
     from oracle.model import OracleWhisper
     from whisperkit_amd import api, weights
     from whisperkit_amd.synth import synthetic_chunk
