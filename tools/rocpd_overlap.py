@@ -20,7 +20,7 @@ def main(path, f0=0.0, f1=1.0):
     rows = [r for r in rows if r[1] >= a and r[2] <= b]
     ev = []
     for name, s, e, q in rows:
-        kind = "xattn" if "cross_attn" in name else "gemm" if ("gemm256" in name or "gemm_kernel" in name or "encoder_attention" in name) else "other"
+        kind = "xattn" if ("cross_attn" in name or "xabs_attn" in name) else "gemm" if ("gemm256" in name or "gemm_kernel" in name or "encoder_attention" in name) else "other"
         ev.append((s, 1, kind)); ev.append((e, -1, kind))
     ev.sort()
     run = defaultdict(int)
@@ -36,6 +36,21 @@ def main(path, f0=0.0, f1=1.0):
             if run["xattn"] > 0 and run["gemm"] > 0: t_xg += dt
         n += d; run[kind] += d; prev = t
     span = ev[-1][0] - ev[0][0]
+    # how many cross-attention kernels run at once (each takes slots x key splits CUs: 128 of 256 at 64 slots x 2 splits)
+    xh, nx, prev = defaultdict(int), 0, ev[0][0]
+    for t, d, kind in ev:
+        if t > prev:
+            xh[nx] += t - prev
+        prev = t
+        if kind == "xattn":
+            nx += d
+    print("  cross-attention kernels running at once: " + ", ".join(f"{k}: {100.0 * v / span:.1f} %" for k, v in sorted(xh.items())))
+    dur = defaultdict(list)
+    for name, s_, e_, q in rows:
+        dur[name.split("(")[0][-60:]].append(e_ - s_)
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:12]:
+        v.sort()
+        print(f"  {k:60s} n {len(v):6d}  avg {sum(v) / len(v) / 1e3:8.1f} us  p50 {v[len(v) // 2] / 1e3:8.1f}  p90 {v[int(len(v) * 0.9)] / 1e3:8.1f}  total {sum(v) / 1e6:8.1f} ms")
     print(f"queue column: {qcol}; kernels {len(rows)}; span {span / 1e6:.2f} ms")
     for k in sorted(hist):
         print(f"  {k}{'+' if k == 4 else ' '} kernels running: {hist[k] / 1e6:9.2f} ms  {100.0 * hist[k] / span:5.1f} %")
