@@ -219,6 +219,9 @@ int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_
 int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
 /* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...) */
 int wh_debug_peek(wh_session* s, const char* name, void* out_host, size_t nbytes);
+/* captured step graphs the session holds (one per configuration = (batch, alignment, sampler fusion) and 8 decoder positions; the cache is
+   capped at WH_GRAPH_CAP, default 112, graphs: the configuration used longest ago is dropped first) */
+int wh_session_step_graph_count(const wh_session* s);
 int wh_session_synchronize(wh_session* s);
 void* wh_session_stream(wh_session* s);                 /* hipStream_t of the session */
 

@@ -181,3 +181,43 @@ def test_absorbed_cross_attention_key_split_counts_vs_oracle(splits):
     for b in check:
         al = sess.getAlignmentWeights(b)
         assert np.abs(al[rows] - states[b].alignment[rows]).max() <= 1e-4, (splits, b)
+
+
+_CAP = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from whisperkit_amd import api, weights
+from whisperkit_amd.synth import synthetic_chunk
+dims = weights.MODEL_DIMS["test-small-l2"]
+model = api.Model(dims, weights.synthetic_state_dict(dims, seed=3))
+sess = api.Session(model, 4)
+for b in range(4):
+    sess.padOrTrim(synthetic_chunk(900 + b), b)
+sess.logMelSpectrogram(4); sess.encodeFeatures(4); sess.prepareDecoderInputs(4)
+opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
+                           temperatureFallbackCount=0, sampleLength=20)          # 19 decoder steps = 3 step graphs per configuration
+prompt = sess.prefillPrompt(opts)
+first, counts = {}, []
+for batch in (1, 2, 3, 4, 1, 2, 4, 3, 1):
+    res = sess.decodeText(prompt, opts, batch=batch)
+    got = [(list(r.tokens), [float(x) for x in r.tokenLogProbs]) for r in res]
+    if batch in first:
+        assert got == first[batch], ("a configuration re-captured after eviction must give the same results", batch)
+    first[batch] = got
+    counts.append(sess.stepGraphCount)
+print("COUNTS", counts)
+assert max(counts) <= 6, counts            # WH_GRAPH_CAP=6: two configurations of three graphs
+assert counts[0] >= 2 and counts[1] > counts[0] and counts[-1] == 6, counts     # grows to the cap, stays there
+"""
+
+
+def test_step_graph_cache_is_capped_least_recently_used_configuration_first(tmp_path):
+    """a session holds up to 28 step graphs per (batch, alignment, sampler) configuration.  The cache is capped
+    (WH_GRAPH_CAP, default 112): beyond it the configuration used longest ago is dropped whole, after the stream has drained; a
+    configuration captured again later gives bit-identical results."""
+    script = tmp_path / "cap.py"
+    script.write_text(_CAP % ROOT)
+    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, WH_GRAPH_CAP="6"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "COUNTS" in p.stdout

@@ -468,6 +468,10 @@ class Session:
     def crossAttentionSplits(self) -> int:
         return int(self.lib.wh_session_cross_attention_splits(self.handle))
 
+    @property
+    def stepGraphCount(self) -> int:
+        return int(self.lib.wh_session_step_graph_count(self.handle))
+
     def close(self):
         if self.handle:
             self.lib.wh_session_destroy(self.handle)

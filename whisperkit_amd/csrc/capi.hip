@@ -506,6 +506,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
 }
 extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1; }
 extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ? (s->use_xabs ? 1 : 0) : -1; }
+extern "C" int wh_session_step_graph_count(const wh_session* s) { return s ? (int)s->graphs.size() : -1; }
 extern "C" int wh_session_cross_attention_splits(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.n_split : 0) : -1; }
 // Development aid: copy the first `nbytes` of a named decode-step buffer to the host (after the session's stream has drained).
 extern "C" int wh_debug_peek(wh_session* s, const char* name, void* out, size_t nbytes) {

@@ -268,7 +268,30 @@ static int get_step_graph(wh_session* s, int batch, int first_step, hipGraphExec
     DecodeBuffers db = whi::decode_buffers(s, batch, first_step + kStepsPerGraph - 1);
     const WhGraphKey key{batch, s->align_enabled ? 1 : 0, s->fused_greedy ? 1 : 0, s->align_enabled ? s->n_align_alloc : 0, db.self_rows, db.xattn_gate ? 1 : 0};
     auto it = s->graphs.find(key);
-    if (it != s->graphs.end()) { *out = it->second; return WH_OK; }
+    if (it != s->graphs.end()) { s->graph_use[key] = ++s->graph_tick; *out = it->second; return WH_OK; }
+    // The cache is capped (a large-v3 step graph holds ~2.5 k kernel nodes; a configuration = everything of the key but the row bound has up
+    // to 28 graphs): when it is full, the configuration that was used longest ago goes - never the one being extended.  The stream is
+    // drained first: no executable graph is destroyed while a launch of it may still be running.
+    static const size_t cap = [] { const char* e = getenv("WH_GRAPH_CAP"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 4 * 28); }();
+    while (s->graphs.size() >= cap) {
+        auto same_cfg = [](const WhGraphKey& a, const WhGraphKey& b) {
+            return a.batch == b.batch && a.align == b.align && a.fused == b.fused && a.n_align == b.n_align && a.gate == b.gate;
+        };
+        const WhGraphKey* victim = nullptr;
+        unsigned long long victim_last = ~0ull;
+        for (const auto& kv : s->graphs) {
+            if (same_cfg(kv.first, key)) continue;
+            unsigned long long last = 0;                       // a configuration's age = its most recent use
+            for (const auto& u : s->graph_use) if (same_cfg(u.first, kv.first)) last = std::max(last, u.second);
+            if (last < victim_last) { victim_last = last; victim = &kv.first; }
+        }
+        if (!victim) break;                                    // only the current configuration is cached: let it grow to its 28
+        const WhGraphKey v = *victim;
+        WH_HIP(hipStreamSynchronize(s->st));
+        for (auto g = s->graphs.begin(); g != s->graphs.end();) {
+            if (same_cfg(g->first, v)) { hipGraphExecDestroy(g->second); s->graph_use.erase(g->first); g = s->graphs.erase(g); } else ++g;
+        }
+    }
     hipGraph_t graph;
     WH_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < kStepsPerGraph; ++i) launch_decoder_step(db, s->cfg_dev, s->suppress_dev, true, s->st);
@@ -277,6 +300,7 @@ static int get_step_graph(wh_session* s, int batch, int first_step, hipGraphExec
     WH_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
     s->graphs[key] = exec;
+    s->graph_use[key] = ++s->graph_tick;
     *out = exec;
     return WH_OK;
 }
@@ -285,6 +309,7 @@ namespace whi {
 void drop_session_graphs(wh_session* s) {
     for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
     s->graphs.clear();
+    s->graph_use.clear();
 }
 }
 

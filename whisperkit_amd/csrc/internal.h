@@ -79,6 +79,8 @@ struct wh_session {
     int align_znorm = 0, align_median = 0;   // optional openai/whisper-style post-processing (wh_session_set_alignment_postprocess)
     float* align_tmp = nullptr; int align_tmp_heads = 0;   // [224][n_align][1500] softmax rows + [2][n_align][1500] statistics + 224 flags
     std::map<WhGraphKey, hipGraphExec_t> graphs;   // captured 8-step decode graphs of THIS session (no process-wide state)
+    std::map<WhGraphKey, unsigned long long> graph_use;   // last use (a counter) per graph: the cache is capped, least recently used configuration first
+    unsigned long long graph_tick = 0;
     const volatile int32_t* cancel_flag = nullptr; // polled between step graphs and pipeline stages (Task.checkCancellation)
     bool use_xabs = false;                // cross-attention path of this session (fixed at creation: never a function of the live batch)
     wh::Xabs xabs{};                      // absorbed queries + split partials (one allocation: xabs_blob)
