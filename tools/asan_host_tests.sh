@@ -14,7 +14,7 @@ for f in host capi; do   # host side of the HIP files that carry host logic (dev
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$CS -Wno-unused-result -Wno-unused-value \
     -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -c $CS/$f.hip -o $OUT/$f.o
 done
-(cd $CS && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 mel.o gemm.o layernorm.o attention.o decoder.o decoder32.o beam.o comm.o $OUT/capi.o $OUT/host.o \
+(cd $CS && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 mel.o gemm.o layernorm.o attention.o decoder.o decoder32.o xabs.o beam.o comm.o $OUT/capi.o $OUT/host.o \
   $OUT/tokenizer.o $OUT/words.o $OUT/results.o -o $OUT/libwhisperhip.so -lz -ldl -fsanitize=address,undefined -shared-libsan)
 cp $ROOT/whisperkit_amd/libwhisperhip.so $OUT/libwhisperhip.orig.so
 trap 'cp $OUT/libwhisperhip.orig.so $ROOT/whisperkit_amd/libwhisperhip.so' EXIT
