@@ -11,6 +11,7 @@ import pytest
 
 from oracle import decode as od
 from oracle import tokenizer as otok
+from whisperkit_amd import _lib as L
 from whisperkit_amd import api, synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -345,3 +346,28 @@ def test_kat_compression_ratio_string_and_trimming():
              "endoftext|>": "endoftext"}
     for src, want in cases.items():
         assert api.trimmingSpecialTokenCharacters(src) == want and otok.trimming_special_token_characters(src) == want
+
+
+def test_set_segment_times_is_what_a_window_postprocess_hook_edits(toks):
+    """wh_transcription_set_segment_times (the edit a windowPostProcess hook makes, Core/TranscribeTask.swift:49-55) on a host-only result:
+    the segment's times change in the object and in every writer's output, nothing else moves; an index out of range is an error."""
+    rng = random.Random(9)
+    res, _ = _result_with_words(toks, rng)
+    lib = L.load()
+    n = len(res.segments)
+    assert n >= 1
+    before = json.loads(res.toJSON())
+    api._check(lib.wh_transcription_set_segment_times(res._handle, n - 1, 1.25, 2.5))
+    after = json.loads(res.toJSON())
+    assert after["segments"][n - 1]["start"] == 1.25 and after["segments"][n - 1]["end"] == 2.5
+    for k in range(n):
+        a, b = dict(after["segments"][k]), dict(before["segments"][k])
+        if k == n - 1:
+            a.pop("start"); a.pop("end"); b.pop("start"); b.pop("end")
+        assert a == b
+    assert {k: v for k, v in after.items() if k != "segments"} == {k: v for k, v in before.items() if k != "segments"}
+    for bad in (-1, n, n + 7):
+        with pytest.raises(api.WhisperError):
+            api._check(lib.wh_transcription_set_segment_times(res._handle, bad, 0.0, 1.0))
+    with pytest.raises(api.WhisperError):
+        api._check(lib.wh_transcription_set_segment_times(None, 0, 0.0, 1.0))
