@@ -125,7 +125,9 @@ __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, flo
 // __launch_bounds__(256, 2): capping the wave at 256 unified registers keeps the accumulators in arch VGPRs (with 512 allowed the
 // compiler parked them in AccVGPRs and copied all 32 of them out and back in every loop iteration: 160 v_accvgpr moves per launch);
 // every instantiation fits (88 - 204 VGPRs, no scratch), two workgroups can share a CU.
-template <int MODE, bool HILO, int TC>
+// NTW: non-temporal weight loads.  A slab is read by n_bt workgroups of ONE XCD (ids x + 8 t): with a single batch tile it is streamed
+// once (nt keeps it from displacing the activations in L2); with two or more, the later readers are meant to hit the first one's lines.
+template <int MODE, bool HILO, int TC, bool NTW>
 __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
     __shared__ float red[4][16][64];                 // the four waves' partial tiles
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
         u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
         auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i) w[i] = __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64);     // streamed once: nt
+            for (int i = 0; i < TC; ++i) w[i] = NTW ? __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64) : wp[(size_t)(c * TC + i) * 64];
 #pragma unroll
             for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
             if constexpr (HILO) {
@@ -432,16 +434,22 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
     return want;
 }
 
-template <int MODE, bool HILO>
-static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
+template <int MODE, bool HILO, bool NTW>
+static void launch_tc_w(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
     static const int tc_cap = env_int32("WH_D32_TC", 5);     // A/B knob: smaller chunks = fewer registers (TC 2: ~100) = room beside a cross-attention wave
     // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
-    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5><<<grid, 256, 0, st>>>(a);
-    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4><<<grid, 256, 0, st>>>(a);
-    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3><<<grid, 256, 0, st>>>(a);
-    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2><<<grid, 256, 0, st>>>(a);
-    else dec32_proj_kernel<MODE, HILO, 1><<<grid, 256, 0, st>>>(a);
+    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1, NTW><<<grid, 256, 0, st>>>(a);
+}
+template <int MODE, bool HILO>
+static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
+    static const int ntw = env_int32("WH_D32_NTW", -1);      // -1: nt for a single batch tile only; 0 never; 1 always (the behaviour before round 4's last change)
+    const bool nt = ntw < 0 ? a.n_bt == 1 : ntw != 0;
+    if (nt) launch_tc_w<MODE, HILO, true>(a, grid, st); else launch_tc_w<MODE, HILO, false>(a, grid, st);
 }
 
 unsigned long long* debug_buffer();
