@@ -2,6 +2,7 @@
 without a GPU, and its host-side logic (C++ restatement of the reference's Swift) agrees with the reference's KATs and
 with the oracle.  No compute kernels are launched here."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -281,3 +282,31 @@ def test_bench_work_formulas_reproduce_the_survey_figures():
     per_step = all_decoder - L_ * 2 * d * d * 2                             # ... which run once per window (gemm_cross_kv), not per token
     assert got == pytest.approx(per_step, rel=0.01)
     assert w("mel_power", weights.MODEL_DIMS["large-v3"]) + 0 >= 480000 * 4                              # PCM read is in the bill
+
+
+def test_bench_absorbed_cross_attention_bytes_follow_the_key_split_count():
+    """bench.py prices the absorbed cross-attention by the session's key split count (wh_session_cross_attention_splits): the encoder rows
+    of every slot once (SURVEY 8d's 245.8 MB per token and sequence over 32 layers = half of it per slot and layer: the K and the V stream
+    became one), the absorbed queries, and every split's unnormalised partial + (m, l).  The figures DESIGN section 4 and the committed bench
+    lines quote: 265.4 MB per launch at 64 slots and 2 splits, 278.6 MB at 4."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dims = weights.MODEL_DIMS["large-v3"]
+    d, H, B = dims.n_text_state, dims.n_text_head, 64
+    enc_rows = B * 1500 * d * 2
+    assert enc_rows == 245_760_000
+    for splits, want in ((1, None), (2, 265_441_280), (3, None), (4, 278_568_960)):
+        bound, got = bench.algorithmic_work("dec_cross_attn", dims, B, 8.5, absorbed=True, splits=splits)
+        assert bound == "hbm" and got == enc_rows + B * H * d * 4 + splits * B * H * (d * 4 + 8)
+        if want:
+            assert got == want
+        _, vup = bench.algorithmic_work("dec_xabs_vup", dims, B, 8.5, absorbed=True, splits=splits)
+        assert vup >= d * d * 2 + splits * B * H * d * 4          # W_v once + every split's partial read back
+    line = json.loads(open(os.path.join(root, "profiles", "r04ag_bench_final_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    r = line["roofline"]
+    assert r["alg_per_launch"] == 265_441_280 and r["same_kernel_alone_on_the_whole_chip"]["alg_per_launch"] == 278_568_960
+    assert r["frac"] == pytest.approx(r["alg_per_launch"] / (r["avg_us"] * 1e-6) / 8e12, rel=1e-3)
+    assert r["traffic"] >= r["alg_per_launch"]                  # PMC traffic is never below the algorithmic bytes
