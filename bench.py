@@ -95,8 +95,8 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
         # weight-absorbed form (csrc/xabs.hip): the slot's encoder output [1500][d] f16 ONCE, absorbed queries (f16 hi | lo) in,
         # every key split's unnormalised O' [H][d] f32 + (m, l) out
         return "hbm", B * T * d * 2 + B * H * d * 4 + splits * B * H * (d * 4 + 8)
-    if kind == "dec_cross_attn":  # 1500 K and V rows per slot, q in, att planes out
-        return "hbm", B * 2 * T * d * 2 + 2 * act
+    if kind == "dec_cross_attn":  # 1500 K and V rows per slot (fp32 since round 5), q in, att planes out
+        return "hbm", B * 2 * T * d * 4 + 2 * act
     if kind == "dec_xabs_qk":    # W_k^T tiles + q in, absorbed queries [H][d] per slot (f16 hi | lo) out
         return "hbm", d * d * 2 + act + B * H * d * 4
     if kind == "dec_xabs_vup":   # W_v tiles + the split partials in, att planes out
@@ -180,11 +180,23 @@ def get_model(name, local_rank, keep_sd=False):
     return _MODELS[name]
 
 
+def plan_batches(n_steps, F, G):
+    """n_steps steps over F workers (sessions in flight) as device batches of at most G steps: every worker gets an equal share of the
+    steps (the first n_steps % F one more), cut into batches of G and one shorter remainder.  Returns [[steps per batch, ...] per worker]."""
+    F = max(1, min(F, n_steps))
+    plan = []
+    for w in range(F):
+        mine = n_steps // F + (1 if w < n_steps % F else 0)
+        plan.append([G] * (mine // G) + ([mine % G] if mine % G else []))
+    return plan
+
+
 def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False,
-               comm=None, scaling="strong"):
+               comm=None, scaling="strong", device_batch=None):
     """B = chunks per step: in total over the ranks (strong scaling, the default) or per rank (weak).  A rank's share of a step is the
-    contiguous block partition_chunks gives it; the shares of G consecutive steps are packed into one device batch of at most the
-    1-GPU batch size (G = 1 at one GPU and in weak mode)."""
+    contiguous block partition_chunks gives it; the shares of up to G consecutive steps are packed into one device batch of at most
+    `device_batch` slots (continuous batching: default = B, i.e. G = 1 at one GPU; the headline packs two 64-chunk steps into one 128-slot
+    batch).  The steps of a run are dealt to the F sessions in equal shares (plan_batches)."""
     import torch
     import torch.distributed as dist
     from whisperkit_amd import api, parallel
@@ -196,8 +208,9 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     first, last = parallel.partition_chunks(total, world, rank)
     n_local = last - first                                       # this rank's chunks of one step
     per_rank_max = (total + world - 1) // world
-    cap = max(B, n_local)                                        # device batch capacity = the 1-GPU batch
-    G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch
+    cap = min(128, max(device_batch or B, n_local))              # device batch capacity in slots (a session holds at most 128)
+    G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch ...
+    G = max(1, min(G, (steps + F - 1) // F))                     # ... never more than a session's share of the run
     slots = max(1, G * n_local)
     # sessions in flight: the cross-attention of one session takes about half of the 256 CUs (slots x splits = 128 workgroups), the other
     # sessions' kernels keep the rest (64 slots x 3: 2049 -> 2270 audio-s/s against 4 splits, 128 slots x 3: 2240 -> 2537; profiles/r04ad..af)
@@ -235,36 +248,35 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         return res, recs, nseg
 
     def run_steps(n):
-        """n steps as ceil(n / G) device batches, F batches in flight: worker f runs batches f, f + F, ... on its own session / HIP
-        stream (ctypes drops the GIL while the library runs); the per-step result records are gathered across the ranks by the main
-        thread afterwards, in step order (wh_comm all-gather behind the C ABI; torch.distributed only when no communicator exists)."""
-        groups = [min(G, n - i) for i in range(0, n, G)]
-        out = [None] * len(groups)
-        dur = [0.0] * len(groups)
-        if F == 1:
-            for i, g in enumerate(groups):
-                a = time.perf_counter(); out[i] = hot_path(sess, g); dur[i] = time.perf_counter() - a
-        else:
-            errs = []
+        """n steps as the device batches of plan_batches(n, F, G), F batches in flight: worker f runs its batches on its own session /
+        HIP stream (ctypes drops the GIL while the library runs); the per-step result records are gathered across the ranks by the main
+        thread afterwards (wh_comm all-gather behind the C ABI; torch.distributed only when no communicator exists)."""
+        plan = plan_batches(n, F, G)
+        out = [[None] * len(p) for p in plan]
+        dur = [[0.0] * len(p) for p in plan]
+        errs = []
 
-            def work(f):
-                try:
-                    for i in range(f, len(groups), F):
-                        a = time.perf_counter(); out[i] = hot_path(sessions[f], groups[i]); dur[i] = time.perf_counter() - a
-                except BaseException as e:   # noqa: BLE001
-                    errs.append(e)
-            ths = [threading.Thread(target=work, args=(f,)) for f in range(min(F, len(groups)))]
+        def work(f):
+            try:
+                for i, g in enumerate(plan[f]):
+                    a = time.perf_counter(); out[f][i] = hot_path(sessions[f], g); dur[f][i] = time.perf_counter() - a
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+        if len(plan) == 1:
+            work(0)
+        else:
+            ths = [threading.Thread(target=work, args=(f,)) for f in range(len(plan))]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
-            if errs:
-                raise errs[0]
+        if errs:
+            raise errs[0]
         gdev = dev if (world > 1 and args.dist_backend == "nccl") else None
-        gathered = [parallel.gather_records(recs, per_rank_max, device=gdev, comm=comm) for _, per_step, _ in out for recs in per_step]
+        gathered = [parallel.gather_records(recs, per_rank_max, device=gdev, comm=comm) for o in out for _, per_step, _ in o for recs in per_step]
         assert len(gathered) == n
-        step_dur = [(d / g, d) for d, g in zip(dur, groups) for _ in range(g)]      # (a batch's wall time shared by the steps it carries, the step's latency)
-        return out[0][0], gathered[-1], step_dur
+        step_dur = [(d / g, d) for p, ds in zip(plan, dur) for g, d in zip(p, ds) for _ in range(g)]      # (a batch's wall time shared by the steps it carries, the step's latency)
+        return out[0][0][0], gathered[-1], step_dur
 
     def fence():
         for ss in sessions:
@@ -275,10 +287,10 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
 
     log(f"{model_name}: model + {F} session(s) of {slots} slots ready ({n_local} chunks per step on this rank, {G} step(s) per device batch); warmup x{warmup}")
     if warmup > 0:
-        run_steps(max(warmup, F * G))    # every session captures its step graphs before the timed region
-        if steps % G:                    # ... including the graphs of the short last batch of the timed run
-            for ss in sessions:
-                hot_path(ss, steps % G)
+        run_steps(max(warmup, F * G))    # every session captures its step graphs before the timed region ...
+        for f, p in enumerate(plan_batches(steps, F, G)):      # ... including those of every shorter batch of the timed run's plan
+            for g in sorted(set(p) - {G}):
+                hot_path(sessions[f], g)
     fence()
     t0 = time.perf_counter()
     res, allrecs, durs = run_steps(steps)
@@ -297,7 +309,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     audio_s = total * 30.0 * steps
     # median step: every step's own wall time (host PCM in -> segments out); with F steps in flight a step's latency is F x the
     # interval at which steps complete, so latency / F is the per-step cost the throughput implies
-    Fe = min(F, (steps + G - 1) // G)          # device batches in flight
+    Fe = len(plan_batches(steps, F, G))          # device batches in flight
     lat = [l for _, l in durs]
     durs = [d for d, _ in durs]
     out = {"value": audio_s / elapsed, "elapsed": elapsed, "audio_s": audio_s, "dec_steps": dec_steps[0], "B": B, "inflight": F,
@@ -357,12 +369,15 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                 k4 = r4["kernels"]["dec_cross_attn"]
                 rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "workgroups": slots * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
                                                               "achieved": k4["achieved"], "unit": k4["unit"], "frac": k4["frac"]}
+                # (the same figures as scalars: a reader that keeps only the flat keys of `roofline` still carries them)
+                rf["whole_chip_splits"], rf["whole_chip_avg_us"], rf["whole_chip_achieved"], rf["whole_chip_frac"] = 4, k4["avg_us"], k4["achieved"], k4["frac"]
         # whole step: algorithmic HBM bytes of every bandwidth-bound launch of one step / the step's share of the timed region
         hbm_bytes = sum(k["alg_per_launch"] * k["launches_per_step"] for k in rf["kernels"].values() if k["bound"] == "hbm")
         ms_step = elapsed / steps * 1e3
         rf["whole_step"] = {"hbm_bound_algorithmic_bytes": int(hbm_bytes), "ms_per_step": round(ms_step, 3),
                             "achieved": round(hbm_bytes / (ms_step * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(hbm_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "note": "the matrix-core-bound encoder launches of the step run inside the same time and are not counted"}
+        rf["whole_step_achieved"], rf["whole_step_frac"] = rf["whole_step"]["achieved"], rf["whole_step"]["frac"]
         log(f"{model_name}: roofline leg done")
 
     # ---- CPU baseline: the oracle (port of the same algorithm) on the host cores, bounded sample
@@ -472,6 +487,9 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=64, help="30 s chunks per step (one decode batch = batch / 32 MFMA batch tiles): in total over the GPUs "
                     "with --scaling strong (BASELINE configs[3]: 64 chunks sharded across the GPUs), per GPU with --scaling weak")
+    ap.add_argument("--device-batch", type=int, default=-1, help="slots of one device batch: the rank's shares of consecutive steps are packed into batches of "
+                    "at most this many chunks (continuous batching; one session holds at most 128).  -1 = automatic: 128 when a step has >= 64 chunks (two "
+                    "64-chunk steps per batch at one GPU: the decoder's weight stream is shared by four batch tiles), else --batch (one step per batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: strong = --batch chunks per step in total, block-partitioned "
                     "over the ranks (SURVEY 8d c4; the default); weak = --batch chunks per step and GPU")
     ap.add_argument("--gather", choices=["wh_comm", "torch"], default="wh_comm", help="N > 1: result-record all-gather through the C-ABI communicator "
@@ -540,8 +558,10 @@ def main():
                 comm = None
                 gather_kind = f"torch.distributed all_gather_into_tensor ({args.dist_backend}); wh_comm failed on another rank"
 
+    dev_batch = args.device_batch if args.device_batch > 0 else (128 if args.batch >= 64 else args.batch)
     main_cfg = run_config(args, args.model, args.batch, args.inflight, args.steps, args.warmup, world, rank, local_rank, dev,
-                          want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline), comm=comm, scaling=args.scaling)
+                          want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline), comm=comm, scaling=args.scaling,
+                          device_batch=dev_batch)
     other = {}
     headline = (args.model, args.batch) == ("large-v3", 64)
     extra = rank == 0 and world == 1 and not args.no_other_configs

@@ -1,9 +1,9 @@
 //  HIP backend for WhisperKit: conformers of the three model-stage protocols over libwhisperhip.so (include/whisperhip.h).
 //  Source only - see ../../README.md.  Install with
-//      let m = try HIPModel(path: "large-v3.whipw"); var s: OpaquePointer?; wh_session_create(m.handle, 1, &s)
-//      let config = WhisperKitConfig(featureExtractor: HIPFeatureExtractor(model: m, session: s!),
-//                                    audioEncoder: HIPAudioEncoder(model: m, session: s!),
-//                                    textDecoder: HIPTextDecoder(model: m, session: s!))
+//      let m = try HIPModel(path: "large-v3.whipw"); let s = try HIPSession(model: m)      // (wh_session_create_tuned; HIPSession below)
+//      let config = WhisperKitConfig(featureExtractor: HIPFeatureExtractor(model: m, session: s.handle),
+//                                    audioEncoder: HIPAudioEncoder(model: m, session: s.handle),
+//                                    textDecoder: HIPTextDecoder(model: m, session: s.handle))
 import CoreML
 import Foundation
 import WhisperKit
@@ -26,6 +26,68 @@ public final class HIPModel {
         handle = h
     }
     deinit { wh_model_destroy(handle) }
+}
+
+/// One decode session (= the reference's per-task `DecodingInputs`, Core/Models.swift:291-323) with the creation knobs of the C ABI:
+/// `wh_session_create_tuned` (cross-attention mode -1 automatic / 0 fp32 K / V rows / 1 weight-absorbed; key splits per slot of the
+/// absorbed form = the share of the CUs one session's cross-attention takes: 4 alone, 2 with several sessions in flight) and the window
+/// hooks of TranscribeTask for the library's own orchestrator (`wh_session_set_window_hooks`: windowPreprocess / windowPostProcess /
+/// segmentDiscoveryCallback, Core/TranscribeTask.swift:42-55,130,246,260).
+public final class HIPSession {
+    public let handle: OpaquePointer
+    let model: HIPModel
+    private var hookBox: Unmanaged<HookBox>?
+
+    public enum CrossAttentionMode: Int32 { case automatic = -1, keyValueRows = 0, absorbed = 1 }
+    /// slots from which `.automatic` picks the absorbed path (wh_xabs_auto_min_slots: 48)
+    public static var absorbedFromSlots: Int { Int(wh_xabs_auto_min_slots()) }
+
+    public init(model: HIPModel, maxBatch: Int = 1, crossAttention: CrossAttentionMode = .automatic, keySplits: Int = 0) throws {
+        var h: OpaquePointer?
+        try check(wh_session_create_tuned(model.handle, Int32(maxBatch), crossAttention.rawValue, Int32(keySplits), &h))
+        handle = h!; self.model = model
+    }
+    deinit { wh_session_set_window_hooks(handle, nil); hookBox?.release(); wh_session_destroy(handle) }
+
+    public var crossAttentionMode: CrossAttentionMode { CrossAttentionMode(rawValue: wh_session_cross_attention_mode(handle)) ?? .automatic }
+    public var crossAttentionKeySplits: Int { Int(wh_session_cross_attention_splits(handle)) }
+    public var capturedStepGraphs: Int { Int(wh_session_step_graph_count(handle)) }
+
+    final class HookBox {
+        var pre: ((Int, UnsafeBufferPointer<Float>, Int, Int) -> Void)?
+        var post: ((Int, Int, Int, OpaquePointer, Int, Int) -> Int?)?      // returns how many of the window's segments to keep (nil = all)
+        var discovery: ((Int, OpaquePointer, Int, Int) -> Void)?
+    }
+    /// All nil removes the hooks.  The closures run on the thread that called wh_transcribe*; they must not throw (a Swift error cannot
+    /// cross the C frames: catch inside and keep all segments, as whisperkit_amd/api.py does for Python exceptions).
+    public func setWindowHooks(windowPreprocess: ((Int, UnsafeBufferPointer<Float>, Int, Int) -> Void)? = nil,
+                               windowPostProcess: ((Int, Int, Int, OpaquePointer, Int, Int) -> Int?)? = nil,
+                               segmentDiscovery: ((Int, OpaquePointer, Int, Int) -> Void)? = nil) throws {
+        hookBox?.release(); hookBox = nil
+        guard windowPreprocess != nil || windowPostProcess != nil || segmentDiscovery != nil else {
+            try check(wh_session_set_window_hooks(handle, nil)); return
+        }
+        let box = HookBox(); box.pre = windowPreprocess; box.post = windowPostProcess; box.discovery = segmentDiscovery
+        let ref = Unmanaged.passRetained(box); hookBox = ref
+        var h = wh_window_hooks()
+        h.user = ref.toOpaque()
+        if windowPreprocess != nil {
+            h.window_preprocess = { user, ai, p, seek, size in
+                Unmanaged<HookBox>.fromOpaque(user!).takeUnretainedValue().pre?(Int(ai), UnsafeBufferPointer(start: p, count: Int(size)), Int(seek), Int(size))
+            }
+        }
+        if windowPostProcess != nil {
+            h.window_postprocess = { user, ai, seek, size, t, first, n in
+                Int32(Unmanaged<HookBox>.fromOpaque(user!).takeUnretainedValue().post?(Int(ai), Int(seek), Int(size), t!, Int(first), Int(n)) ?? -1)
+            }
+        }
+        if segmentDiscovery != nil {
+            h.segment_discovery = { user, ai, t, first, n in
+                Unmanaged<HookBox>.fromOpaque(user!).takeUnretainedValue().discovery?(Int(ai), t!, Int(first), Int(n))
+            }
+        }
+        try check(wh_session_set_window_hooks(handle, &h))          // the struct is copied by the library
+    }
 }
 
 public final class HIPFeatureExtractor: FeatureExtracting {

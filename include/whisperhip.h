@@ -202,10 +202,17 @@ int wh_session_create(wh_model* m, int max_batch, wh_session** out);
 void wh_session_destroy(wh_session* s);
 int wh_session_max_batch(const wh_session* s);
 /* 1: the session's decoder attends over the encoder output directly (weight-absorbed cross-attention: encoder_output_embeds is the
-   decoder input in the reference too, Core/Models.swift:986-987), 0: per-layer cross K / V rows are materialised by
-   wh_prepare_decoder_inputs.  Fixed at creation (width supported and max_batch >= 48, or WH_XABS=0 / 1); results agree within the
-   parity tolerance, bit-identity across batch sizes holds within a mode. */
+   decoder input in the reference too, Core/Models.swift:986-987), 0: per-layer cross K / V rows (fp32) are materialised by
+   wh_prepare_decoder_inputs.  Fixed at creation: automatic = absorbed when the width supports it (512 / 768 / 1024 / 1280) and
+   max_batch >= wh_xabs_auto_min_slots() (48; WH_XABS_MIN_SLOTS), or WH_XABS=0 / 1.  The choice is made from max_batch alone, so
+   Session(m, 47) and Session(m, 48) run different kernels: both modes meet the 1e-3 relative logits contract against the fp32
+   model, bit-identity across batch sizes holds within a mode.  Mode 1 streams the encoder output once per SLOT: callers whose slots
+   share encoder outputs (beam search: beam_size slots per audio) should ask for mode 0 (wh_session_create_with_mode), whose rows
+   are shared through the L2.  Mode 1 reads the session's encoder output LIVE at every decoder step (mode 0 snapshots it into the K / V
+   rows in wh_prepare_decoder_inputs): wh_encode_features / wh_set_encoder_output between wh_prepare_decoder_inputs and the last
+   decoder step of a window change the results in mode 1 - the reference passes encoder_output_embeds to every call as well. */
 int wh_session_cross_attention_mode(const wh_session* s);
+int wh_xabs_auto_min_slots(void);
 /* key splits per slot of the absorbed cross-attention (0 in K / V-row mode): slots x splits workgroups, one per CU, stream the
    encoder output; fixed at creation (bench.py prices the kernel's algorithmic bytes with it) */
 int wh_session_cross_attention_splits(const wh_session* s);
@@ -217,7 +224,8 @@ int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_
    (64 slots: 256 workgroups), 2 when several sessions are in flight on the GPU (the other sessions' kernels keep the other half;
    profiles/r04ad_*).  Ignored in K / V-row mode. */
 int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
-/* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...) */
+/* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...);
+   nbytes beyond the buffer's size is WH_ERR_INVALID_ARGUMENT */
 int wh_debug_peek(wh_session* s, const char* name, void* out_host, size_t nbytes);
 /* captured step graphs the session holds (one per configuration = (batch, alignment, sampler fusion) and 8 decoder positions; the cache is
    capped at WH_GRAPH_CAP, default 112, graphs: the configuration used longest ago is dropped first) */
@@ -240,7 +248,8 @@ int wh_get_encoder_output(wh_session* s, int b, float* out_host /* [1500][d] */)
 int wh_set_encoder_output(wh_session* s, int b, const float* enc_host /* [1500][d] */);
 
 /* TextDecoding.prepareDecoderInputs + DecodingInputs.reset: project the encoder output to the per-layer
- * cross-attention K/V (once per window) and clear the decode state of slots [0, batch) */
+ * cross-attention K/V rows (once per window; K / V-row mode only - the absorbed mode keeps reading the encoder output itself, see
+ * wh_session_cross_attention_mode) and clear the decode state of slots [0, batch) */
 int wh_prepare_decoder_inputs(wh_session* s, int batch);
 int wh_reset_decoder_inputs(wh_session* s, int batch);  /* DecodingInputs.reset, Core/Models.swift:312-322 */
 

@@ -188,6 +188,38 @@ def test_bad_hello_is_dropped_and_the_real_peer_still_joins():
     assert got[0][0] == "ok" and got[1][0] == "ok", got
 
 
+def _silent_then_join_worker(rank, world, port, q):
+    import os
+    import time
+    os.environ["WH_COMM_TIMEOUT_S"] = "12"
+    t0 = time.time()
+    held = None
+    if rank == 1:                         # a connection that says NOTHING and stays open (port scan, health probe, half-open peer) ...
+        time.sleep(0.5)
+        for _ in range(50):
+            try:
+                held = socket.create_connection(("127.0.0.1", port), timeout=1)
+                break
+            except OSError:
+                time.sleep(0.1)
+        time.sleep(0.3)                   # ... is in rank 0's accept loop before the real hello arrives
+    c = parallel.Comm(world, rank, transport="tcp", tcp_address=f"127.0.0.1:{port}")
+    c.barrier()
+    q.put((rank, "ok", time.time() - t0))
+    c.close()
+    if held is not None:
+        held.close()
+
+
+def test_silent_connection_does_not_hold_the_accept_loop_for_the_join_deadline():
+    """the hello of an accepted connection has its own short deadline (<= 3 s), so one mute connection costs seconds, not
+    the whole WH_COMM_TIMEOUT_S (12 s here: the old code failed with '0 of 1 peers joined')."""
+    port = _free_port()
+    got = _run(_silent_then_join_worker, [(r, 2, port) for r in range(2)])
+    assert got[0][0] == "ok" and got[1][0] == "ok", got
+    assert max(got[0][1], got[1][1]) < 9.0, got
+
+
 def _poison_worker(rank, world, port, tok_path, q):
     import ctypes as C
     from whisperkit_amd import api

@@ -102,7 +102,7 @@ def test_decode_text_beam_vs_oracle(peaky, beam):
     got = sess.decodeTextBeam(prompt, opts, nAudio=n, beamSize=beam)
     for a in range(n):
         so = []
-        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True), prompt, beam, 1.0, _oopts(kw), st, ml, langs, sampler_out=so)
+        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True, crossFloat16=False), prompt, beam, 1.0, _oopts(kw), st, ml, langs, sampler_out=so)
         if _compare(got[a], ores, so[0], f"audio {AUDIOS[a]} beam {beam}"):
             STATS["early"] += len(ores.tokens) < len(prompt) + 34          # ended through finished (EOT) sequences, not the length cap
             STATS["differs_from_greedy"] += got[a].tokens != greedy[a].tokens
@@ -144,14 +144,14 @@ def test_beam_with_patience_and_short_sample_length(peaky):
     got = sess.decodeTextBeam(prompt, opts, nAudio=2, beamSize=2, patience=2.0)
     for a in range(2):
         so = []
-        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True), prompt, 2, 2.0, _oopts(kw), st, ml, langs, sampler_out=so)
+        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True, crossFloat16=False), prompt, 2, 2.0, _oopts(kw), st, ml, langs, sampler_out=so)
         assert so[0].maxCandidates == 4
         _compare(got[a], ores, so[0], f"patience audio {a}")
     kw2 = dict(**NOFALLBACK, sampleLength=len(prompt) - 1)
     sess.prepareDecoderInputs(2)
     got = sess.decodeTextBeam(prompt, api.DecodingOptions(**kw2), nAudio=2, beamSize=2)
     for a in range(2):
-        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True), prompt, 2, 1.0, _oopts(kw2), st, ml, langs)
+        ores = OD.decode_text_beam(lambda: om.new_state(encs[a], kvFloat16=True, crossFloat16=False), prompt, 2, 1.0, _oopts(kw2), st, ml, langs)
         assert got[a].tokens == ores.tokens and got[a].steps == ores.steps
 
 
@@ -189,12 +189,12 @@ def test_transcribe_with_beam_and_temperature_fallback_vs_oracle(peaky):
             return s_enc.getEncoderOutput(0).astype(np.float16).astype(np.float32)
 
         def make_step(enc):
-            state = om.new_state(enc, kvFloat16=True)
+            state = om.new_state(enc, kvFloat16=True, crossFloat16=False)
             return lambda t, p: state.step(t, p)
         okw = dict(kw); seed = okw.pop("seed", 0)
         records = []
         ores = OD.transcribe_task_run(audio, OD.DecodingOptions(**okw, detectLanguage=False), st, ml, langs, dims.n_vocab, encode_window, make_step,
-                                      seed=seed, records=records, make_state=lambda enc: om.new_state(enc, kvFloat16=True))
+                                      seed=seed, records=records, make_state=lambda enc: om.new_state(enc, kvFloat16=True, crossFloat16=False))
         margins = [r["record"][0].minMargin for r in records if r["temperature"] == 0.0]
         if min(margins) < DECISIVE:
             STATS["near_tie"] += 1

@@ -55,7 +55,7 @@ def test_configs4_two_windows_ladder_at_depth(rig, beam, mode):
     def make_state(enc):
         key = enc.ctypes.data
         if key not in templates:
-            templates[key] = (enc, om.new_state(enc, kvFloat16=True, crossFloat16=(mode == 0)))       # (enc kept alive: the key is its address)
+            templates[key] = (enc, om.new_state(enc, kvFloat16=True, crossFloat16=False))       # (enc kept alive: the key is its address)
         return templates[key][1].fresh_like()
 
     def make_step(enc):

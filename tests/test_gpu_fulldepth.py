@@ -19,16 +19,20 @@ Per configuration and checked slot:
                        fed with the teacher-forced logits; a difference passes only as a near-tie PROVEN from the oracle's own
                        filtered logits (tests/neartie.py), after which the oracle follows the device's token;
   3. end to end      - the oracle runs its OWN fp64 mel + fp32 encoder from the same PCM: max |delta| of the encoder output and of the
-                       logits is MEASURED, written to gpurun_out/r04_fulldepth_errors.json (committed copy: profiles/r04_fulldepth_errors.json), and asserted
+                       logits is MEASURED, written to gpurun_out/r05_fulldepth_errors.json (committed copy: profiles/r05_fulldepth_errors.json), and asserted
                        at <= 2 x the value measured when the test was written (E2E_MEASURED below).  Measured on MI355X (profiles/
                        r03d_fulldepth_errors.json): the encoder output differs from the fp32 oracle by <= 2.4e-3 (mean 3.3e-4; fp16 GEMM
                        operands over 32 layers) and the logits END TO END by 7.3e-4 at large-v3 - inside the contract's 1e-3, which is
                        also asserted as such.  (With the fc1 -> fc2 activations in ONE f16 plane, as in round 2, the same measurement
                        was 1.1e-3: the first run of this test found that, profiles/r03b_*, r03c; they travel as an f16 hi|lo pair now.)
   4. batch invariance - the last slot decodes to the same ids / log-probs alone (1-slot session) as among the others.
+  5. concurrency      - (round 5; VERDICT r04 "what's weak" 3) the regime bench.py TIMES: three sessions of ONE model driven from three host
+                       threads (WhisperKit.swift:735-812's TaskGroup analogue), each running the whole hot path on its own audio order; every
+                       session's encoder output, tokens, log-probs and alignment rows must be bit-identical to the same session run alone.
 """
 import json
 import os
+import threading
 import time
 
 import numpy as np
@@ -79,7 +83,7 @@ _REPORT = {}
 def _write_report():
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_fulldepth_errors.json"), "w") as f:
+    with open(os.path.join(out, "r05_fulldepth_errors.json"), "w") as f:
         json.dump(_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -194,7 +198,7 @@ def test_fulldepth_stage_isolated_logits_greedy_tokens_and_alignment(rig):
         res = rig.res[b]
         enc16 = rig.enc[b].astype(np.float16).astype(np.float32)
         inputs = res.tokens[: rig.n_in]
-        full16 = rig.om.new_state(enc16, kvFloat16=True).forward_full(inputs)
+        full16 = rig.om.new_state(enc16, kvFloat16=True, crossFloat16=False).forward_full(inputs)
         state = rig.om.new_state(enc16)
         full = state.forward_full(inputs)
         sig = float(np.std([full[p] for p in POSITIONS]))
@@ -269,3 +273,55 @@ def test_fulldepth_batch_invariance(rig):
     if rig.word_ts:
         np.testing.assert_array_equal(s1.getAlignmentWeights(0)[:223], rig.align[last][:223])
     s1.close()
+
+
+def test_fulldepth_three_sessions_on_three_threads_equal_alone(rig):
+    """The configuration the benchmark times - F = 3 sessions of one model, one host thread and HIP stream each, kernels of all three in
+    flight on the GPU at once (at large-v3 with the bench's 2 key splits per slot) - against the same sessions run ALONE, one after the
+    other: per-session `part` / `ticket` / `qf` buffers, the shared (read-only) weights and the model's gate word must not let one
+    session's launches leak into another's results.  Compared bit for bit: encoder output of two slots, every slot's token ids and
+    log-probs, and (word-timestamp configurations) the alignment rows of the checked slots.  Two concurrent rounds, the second with the
+    thread start order reversed, so the interleavings differ."""
+    F = 3
+    ids = [[(b + 5 * f) % rig.B for b in range(rig.B)] for f in range(F)]            # session f's audio order (slot b <- chunk ids[f][b])
+    sessions = [api.Session(rig.model, rig.B, crossAttentionMode=rig.sess.crossAttentionMode, crossAttentionSplits=rig.splits) for _ in range(F)]
+    probe = sorted({0, rig.B - 1})
+
+    def hot_path(f):
+        s = sessions[f]
+        for b, i in enumerate(ids[f]):
+            s.padOrTrim(rig.xs[i], b)
+        s.logMelSpectrogram(rig.B); s.encodeFeatures(rig.B); s.prepareDecoderInputs(rig.B)
+        res = s.decodeText(rig.prompt, rig.opts, batch=rig.B)
+        enc = [s.getEncoderOutput(b) for b in probe]
+        al = [s.getAlignmentWeights(b)[:223] for b in probe] if rig.word_ts else []
+        return [r.tokens for r in res], [r.tokenLogProbs for r in res], enc, al
+
+    alone = [hot_path(f) for f in range(F)]
+    # (a session decodes slot b from chunk ids[f][b]: session 0 reproduces the module rig's run)
+    assert alone[0][0] == [r.tokens for r in rig.res] and alone[0][1] == [r.tokenLogProbs for r in rig.res]
+    for rnd in range(2):
+        out, errs = [None] * F, []
+
+        def work(f):
+            try:
+                out[f] = hot_path(f)
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+        order = list(range(F)) if rnd == 0 else list(reversed(range(F)))
+        ths = [threading.Thread(target=work, args=(f,)) for f in order]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        for f in range(F):
+            assert out[f][0] == alone[f][0], (rig.name, rnd, f, "tokens")
+            assert out[f][1] == alone[f][1], (rig.name, rnd, f, "log-probs")                  # bit-exact floats
+            for a, b in zip(out[f][2] + out[f][3], alone[f][2] + alone[f][3]):
+                np.testing.assert_array_equal(a, b)
+    rig.report["concurrency"] = {"sessions": F, "threads": F, "rounds": 2, "slots_per_session": rig.B,
+                                 "bit_identical_to_alone": ["encoder output", "tokens", "log-probs"] + (["alignment rows"] if rig.word_ts else [])}
+    _write_report()
+    for s in sessions:
+        s.close()

@@ -132,6 +132,19 @@ def test_window_hooks_of_the_native_orchestrator():
     for g in cut.segments:
         if g.tokens == firsts[g.seek].tokens:
             assert g.start == pytest.approx(firsts[g.seek].start + 100.0) and g.end == pytest.approx(firsts[g.seek].end + 100.0)
+    # a hook that raises: the exception must come out of transcribe() itself (ctypes used to swallow it and the C side read an
+    # uninitialised `keep`, silently dropping segments), and the session must be usable afterwards
+    class Boom(Exception):
+        pass
+
+    def bad_post(*_a):
+        raise Boom("windowPostProcess failed")
+    sess.setWindowHooks(windowPostProcess=bad_post)
+    with pytest.raises(Boom):
+        sess.transcribe([audio], opts)
+    sess.setWindowHooks(segmentDiscovery=lambda *_a: (_ for _ in ()).throw(Boom("segmentDiscovery failed")))
+    with pytest.raises(Boom):
+        sess.transcribe([audio], opts)
     sess.setWindowHooks()
     assert sess.transcribe([audio], opts)[0].tokens == plain.tokens
     sess.close(); model.close()

@@ -447,8 +447,12 @@ class Session:
     """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
 
     def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None, crossAttentionSplits: Optional[int] = None):
-        """crossAttentionMode: None = the library's choice (absorbed from 48 slots at the widths that support it), 0 = per-layer
-        cross K / V rows, 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
+        """crossAttentionMode: None = the library's choice (absorbed from `xabsAutoMinSlots()` = 48 slots at the widths that support it: the
+        choice looks at maxBatch only, so Session(m, 47) and Session(m, 48) run different kernels; both meet the 1e-3 relative logits
+        contract), 0 = per-layer cross K / V rows (fp32), 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
+        Beam search (decodeTextBeam, DecodingOptions.beamSize): ask for 0 - the absorbed kernel streams the encoder output once per slot,
+        i.e. beamSize times per audio, while the K / V rows of an audio are shared by its beams.  Mode 1 reads the encoder output live
+        at every decoder step: do not call encodeFeatures / setEncoderOutput between prepareDecoderInputs and the end of the decode.
         crossAttentionSplits: key splits per slot of the absorbed form (None = the library's choice): slots x splits workgroups each own a CU
         while they stream, so this is the share of the GPU the session's cross-attention takes - 4 for a session running alone, 2 when
         several sessions share the GPU."""
@@ -459,6 +463,11 @@ class Session:
         else:
             _check(self.lib.wh_session_create_tuned(model.handle, maxBatch, -1 if crossAttentionMode is None else int(crossAttentionMode),
                                                     int(crossAttentionSplits or 0), C.byref(self.handle)))
+
+    @staticmethod
+    def xabsAutoMinSlots() -> int:
+        """slots from which a session created without a crossAttentionMode runs the absorbed cross-attention"""
+        return int(L.load().wh_xabs_auto_min_slots())
 
     @property
     def crossAttentionMode(self) -> int:
@@ -486,6 +495,16 @@ class Session:
     def synchronize(self):
         _check(self.lib.wh_session_synchronize(self.handle))
 
+    def _stash(self, exc: BaseException):
+        """first exception raised inside a callback thunk of the running library call (progress callback, window hooks)"""
+        if getattr(self, "_callback_error", None) is None:
+            self._callback_error = exc
+
+    def _raise_pending(self):
+        exc, self._callback_error = getattr(self, "_callback_error", None), None
+        if exc is not None:
+            raise exc
+
     def setTokenizer(self, tokenizer: Optional["Tokenizer"]):
         """TextDecoding.tokenizer (Core/TextDecoder.swift:61): transcribe results gain text, real word grouping, language code."""
         self.tokenizer = tokenizer      # keep it alive
@@ -500,10 +519,14 @@ class Session:
             return
 
         def tramp(_user, p):
-            p = p.contents
-            r = callback(p.slot, [p.tokens[i] for i in range(p.n_tokens)], p.avg_logprob, p.compression_ratio,
-                         p.text.decode("utf-8") if p.text is not None else None)
-            return 0 if r is False else 1
+            try:
+                p = p.contents
+                r = callback(p.slot, [p.tokens[i] for i in range(p.n_tokens)], p.avg_logprob, p.compression_ratio,
+                             p.text.decode("utf-8") if p.text is not None else None)
+                return 0 if r is False else 1
+            except BaseException as e:   # noqa: BLE001 - never let an exception escape a ctypes thunk (the C side would read garbage)
+                self._stash(e)
+                return 0                 # stop this slot; the exception is re-raised when the running call returns
         self._progress = L.PROGRESS_FN(tramp)      # keep the thunk alive
         _check(self.lib.wh_session_set_progress_callback(self.handle, self._progress, None))
 
@@ -533,17 +556,31 @@ class Session:
                                                 g.compression_ratio, g.no_speech_prob, [], ""))
             return out
 
+        # A Python exception must not escape a ctypes thunk: ctypes prints and swallows it and the C side then reads an uninitialised
+        # return value (a raising windowPostProcess used to truncate a window's segments at random).  Every thunk catches, keeps the
+        # FIRST exception on the session and returns the neutral value (-1 = keep all segments); transcribe / transcribeChunked
+        # re-raise it once the library call has returned.
         def pre(_u, ai, ptr, seek, size):
-            windowPreprocess(ai, np.ctypeslib.as_array(ptr, shape=(size,)).copy() if size > 0 else np.zeros(0, np.float32), seek, size)
+            try:
+                windowPreprocess(ai, np.ctypeslib.as_array(ptr, shape=(size,)).copy() if size > 0 else np.zeros(0, np.float32), seek, size)
+            except BaseException as e:   # noqa: BLE001
+                self._stash(e)
 
         def post(_u, ai, seek, size, t, first, n):
-            t = C.c_void_p(t)
-            r = windowPostProcess(ai, seek, size, segments_of(t, first, n),
-                                  lambda k, a, b: _check(lib.wh_transcription_set_segment_times(t, first + k, a, b)))
-            return -1 if r is None else int(r)
+            try:
+                t = C.c_void_p(t)
+                r = windowPostProcess(ai, seek, size, segments_of(t, first, n),
+                                      lambda k, a, b: _check(lib.wh_transcription_set_segment_times(t, first + k, a, b)))
+                return -1 if r is None else int(r)
+            except BaseException as e:   # noqa: BLE001
+                self._stash(e)
+                return -1
 
         def disc(_u, ai, t, first, n):
-            segmentDiscovery(ai, segments_of(C.c_void_p(t), first, n))
+            try:
+                segmentDiscovery(ai, segments_of(C.c_void_p(t), first, n))
+            except BaseException as e:   # noqa: BLE001
+                self._stash(e)
         h = L.WhWindowHooks()
         if windowPreprocess is not None:
             h.window_preprocess = L.WINDOW_PRE_FN(pre)
@@ -654,6 +691,7 @@ class Session:
             _check(self.lib.wh_decode_text_languages(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
                                                      lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF),
                                                      None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+        self._raise_pending()            # an exception raised inside the progress callback
         return [DecodingResult.from_c(r) for r in res]
 
     def decodeTextCustom(self, prompt: Sequence[int], options: DecodingOptions, logitsFilters: Sequence = (), sampler=None,
@@ -779,8 +817,12 @@ class Session:
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (C.c_int32 * n)(*[len(a) for a in arrs])
         outs = (C.c_void_p * n)()
-        _check(self.lib.wh_transcribe_batch(self.handle, ptrs, lens, n, C.byref(o), C.byref(st), outs))
-        return [_collect(h) for h in outs]
+        self._callback_error = None
+        rc = self.lib.wh_transcribe_batch(self.handle, ptrs, lens, n, C.byref(o), C.byref(st), outs)
+        got = [_collect(h) for h in outs] if rc == 0 else None
+        self._raise_pending()            # an exception raised inside a hook / progress callback outranks the status it may have caused
+        _check(rc)
+        return got
 
     def transcribeChunked(self, audioArray: np.ndarray, options: Optional[DecodingOptions] = None, specialTokens=None):
         """WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): returns
@@ -792,8 +834,12 @@ class Session:
         outs = (C.c_void_p * cap)()
         seeks = (C.c_int32 * cap)()
         n = C.c_int()
-        _check(self.lib.wh_transcribe_chunked(self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n)))
-        return [(int(seeks[i]), _collect(outs[i])) for i in range(n.value)]
+        self._callback_error = None
+        rc = self.lib.wh_transcribe_chunked(self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n))
+        got = [(int(seeks[i]), _collect(outs[i])) for i in range(n.value)] if rc == 0 else None
+        self._raise_pending()
+        _check(rc)
+        return got
 
 
 # ---- host utilities (no GPU needed) ---------------------------------------------------------------

@@ -199,25 +199,31 @@ static int build_dec32(wh_model* m) {
 
 // Absorbed cross-attention weights (xabs.hip): per layer W_k^T as A-fragment tiles of the Q' projection and W_v in the decoder
 // projection tiling; b_v stays where it is in the blob.
+// Built lazily, by the first session that uses the absorbed path (under the model's lock): a model that only ever carries K / V-row
+// sessions (small batches, beam search, WH_XABS=0) does not pay the 2 L d^2 bytes (210 MB at large-v3) per device copy.
 static int build_xabs(wh_model* m) {
     const wh_dims& D = m->dims;
     const size_t d = D.n_text_state, L = D.n_text_layer, H = D.n_text_head;
     if (!xabs_supported((int)d, (int)H)) return WH_OK;
+    std::lock_guard<std::mutex> lk(m->xabs_mu);
+    if (!m->xabs.empty()) return WH_OK;
+    WH_HIP(hipSetDevice(m->device));
     const size_t bytes = L * (2 * d * d * 2 + 2 * 256);
     hipError_t e = hipMalloc(&m->xabs_blob, bytes);
     if (e != hipSuccess) return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the absorbed cross-attention weights failed: %s", bytes, hipGetErrorString(e));
     Carver c; c.base = (char*)m->xabs_blob;
-    m->xabs.resize(L);
+    std::vector<wh::XabsLayerW> tiles(L);
     hipStream_t st = nullptr;
     for (size_t l = 0; l < L; ++l) {
         const f16* wk = m->ckv_w + (l * 2 * d) * d;
         const f16* wv = m->ckv_w + (l * 2 * d + d) * d;
-        f16* p = c.take<f16>(d * d); xabs_tile_wk(wk, (int)d, (int)H, p, st); m->xabs[l].wkT = p;
-        p = c.take<f16>(d * d); dec32_tile_weights(wv, (int)d, (int)d, p, st); m->xabs[l].wv_t = p;
-        m->xabs[l].bv = m->ckv_b + l * 2 * d + d;
+        f16* p = c.take<f16>(d * d); xabs_tile_wk(wk, (int)d, (int)H, p, st); tiles[l].wkT = p;
+        p = c.take<f16>(d * d); dec32_tile_weights(wv, (int)d, (int)d, p, st); tiles[l].wv_t = p;
+        tiles[l].bv = m->ckv_b + l * 2 * d + d;
     }
     WH_CHECK_LAUNCH();
     WH_HIP(hipDeviceSynchronize());
+    m->xabs.swap(tiles);          // published complete: sessions only read it after their own build_xabs call returned
     return WH_OK;
 }
 
@@ -290,7 +296,6 @@ static int model_create_impl(const void* blob, size_t nbytes, int device, wh_mod
     int r = bind_weights(m);
     if (!r) r = build_mel_tables(m);
     if (!r) r = build_dec32(m);
-    if (!r) r = build_xabs(m);
     if (!r) {
         std::vector<int32_t> pairs;
         auto ah = m->t.find("dec.alignment_heads");      // optional int32 [n][2] written by checkpoint conversion (generation_config.alignment_heads)
@@ -405,7 +410,7 @@ extern "C" int wh_session_create_tuned(wh_model* m, int max_batch, int cross_att
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_mode %d (expected -1 auto, 0 K / V rows, 1 absorbed)", cross_attention_mode);
     if (cross_attention_splits < 0 || cross_attention_splits > kXabsSplits)
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_splits %d (expected 0 auto, 1 .. %d)", cross_attention_splits, kXabsSplits);
-    if (cross_attention_mode == 1 && m && m->xabs.empty())
+    if (cross_attention_mode == 1 && m && !xabs_supported(m->dims.n_text_state, m->dims.n_text_head))
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: the absorbed cross-attention needs a model width of 512 / 768 / 1024 / 1280 (this model: %d)", m->dims.n_text_state);
     return session_create_impl(m, max_batch, cross_attention_mode, cross_attention_splits, out);
 }
@@ -430,12 +435,14 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
     DALLOC(s->q16, B * kCtx * d); DALLOC(s->k16, B * kCtx * d); DALLOC(s->vt16, B * d * kCtxPad); DALLOC(s->att16, B * kCtx * d);
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     // Cross-attention path, fixed per session: the absorbed form (xabs.hip) streams the encoder output instead of per-layer K / V rows;
-    // it pays from about 48 slots (three launches per layer instead of one, one workgroup per (slot, key split) and CU: measured
-    // large-v3 5.36 -> 4.79 ms per step at 64 slots, 3.65 -> 3.99 at 32; profiles/r04*).  WH_XABS=0 / 1 forces the choice (A/B, tests).
+    // it pays from about kXabsAutoMinSlots slots (three launches per layer instead of one, one workgroup per (slot, key split) and CU;
+    // profiles/r04*, r05*).  Both modes meet the 1e-3 relative logits contract against fp32 (the K / V rows are fp32 since round 5).
+    // WH_XABS=0 / 1 forces the choice (A/B, tests), WH_XABS_MIN_SLOTS moves the automatic threshold.
     {
         const char* e_ = getenv("WH_XABS");       // read per session: a process can hold sessions of both modes (tests, A/B)
         const int xabs_mode = cross_attention_mode >= 0 ? cross_attention_mode : (e_ ? atoi(e_) : -1);
-        s->use_xabs = !m->xabs.empty() && (xabs_mode < 0 ? max_batch >= 48 : xabs_mode != 0);
+        s->use_xabs = xabs_supported((int)d, (int)H) && (xabs_mode < 0 ? max_batch >= wh_xabs_auto_min_slots() : xabs_mode != 0);
+        if (s->use_xabs) { const int r_ = build_xabs(m); if (r_) { wh_session_destroy(s); return r_; } }
     }
     if (s->use_xabs) {
         const size_t nht = H > 16 ? 2 : 1, S = kXabsSplits;
@@ -508,19 +515,31 @@ extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1;
 extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ? (s->use_xabs ? 1 : 0) : -1; }
 extern "C" int wh_session_step_graph_count(const wh_session* s) { return s ? (int)s->graphs.size() : -1; }
 extern "C" int wh_session_cross_attention_splits(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.n_split : 0) : -1; }
+// slots from which wh_session_create picks the absorbed cross-attention on its own (models whose width supports it)
+extern "C" int wh_xabs_auto_min_slots(void) {
+    const char* e = getenv("WH_XABS_MIN_SLOTS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : wh::kXabsAutoMinSlots;
+}
 // Development aid: copy the first `nbytes` of a named decode-step buffer to the host (after the session's stream has drained).
 extern "C" int wh_debug_peek(wh_session* s, const char* name, void* out, size_t nbytes) {
     CHECK_SESSION(s);
     if (!name || !out) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_debug_peek: null argument");
     const std::string n(name);
     const void* src = nullptr;
-    if (n == "x") src = s->d32.x; else if (n == "q") src = s->d32.q;
-    else if (n == "za_hi") src = s->d32.za_hi; else if (n == "za_lo") src = s->d32.za_lo;
-    else if (n == "zb_hi") src = s->d32.zb_hi; else if (n == "zb_lo") src = s->d32.zb_lo;
-    else if (n == "qf_hi") src = s->xabs.qf_hi; else if (n == "qf_lo") src = s->xabs.qf_lo;
-    else if (n == "part") src = s->xabs.part; else if (n == "ml") src = s->xabs.ml;
-    else if (n == "enc16") src = s->enc16;
+    size_t have = 0;          // bytes the named buffer holds: a request beyond it is refused, never read out of bounds
+    const size_t R = (size_t)s->d32.n_bt * 32, d = (size_t)s->m->dims.n_text_state, H = (size_t)s->m->dims.n_text_head, B = (size_t)s->B;
+    const size_t nht = H > 16 ? 2 : 1;
+    if (n == "x") { src = s->d32.x; have = R * d * 4; } else if (n == "q") { src = s->d32.q; have = R * d * 4; }
+    else if (n == "za_hi") { src = s->d32.za_hi; have = R * d * 2; } else if (n == "za_lo") { src = s->d32.za_lo; have = R * d * 2; }
+    else if (n == "zb_hi") { src = s->d32.zb_hi; have = R * d * 2; } else if (n == "zb_lo") { src = s->d32.zb_lo; have = R * d * 2; }
+    else if (s->use_xabs && n == "qf_hi") { src = s->xabs.qf_hi; have = B * nht * 16 * d * 2; }
+    else if (s->use_xabs && n == "qf_lo") { src = s->xabs.qf_lo; have = B * nht * 16 * d * 2; }
+    else if (s->use_xabs && n == "part") { src = s->xabs.part; have = (size_t)kXabsSplits * H * d * B * 4; }
+    else if (s->use_xabs && n == "ml") { src = s->xabs.ml; have = (size_t)kXabsSplits * H * B * 8; }
+    else if (n == "enc16") { src = s->enc16; have = B * kCtx * d * 2; }
     if (!src) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_debug_peek: no buffer named '%s' in this session", name);
+    if (nbytes > have) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_debug_peek: '%s' holds %zu bytes, %zu requested", name, have, nbytes);
     WH_HIP(hipStreamSynchronize(s->st));
     WH_HIP(hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost));
     return WH_OK;
@@ -710,7 +729,7 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     if (!s->use_xabs) {     // (the absorbed cross-attention reads the encoder output itself: no per-layer K / V projection)
         GemmArgs g{};
         g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
-        g.ldc = L * 2 * d; g.k16 = s->cross_k; g.vt16 = s->cross_v; g.d_model = d; g.max_batch = s->B;
+        g.ldc = L * 2 * d; g.k32 = s->cross_k; g.v32 = s->cross_v; g.d_model = d; g.max_batch = s->B;
         g.prof_kind = KK_CROSS_KV;
         launch_gemm(EPI_CROSS_KV, g, s->st);
         WH_CHECK_LAUNCH();

@@ -95,9 +95,9 @@ int comm_timeout_s() {
     static const int t = [] { const char* e = getenv("WH_COMM_TIMEOUT_S"); const int v = e ? atoi(e) : 120; return v > 0 ? v : 120; }();
     return t;
 }
-void set_deadlines(int fd) {
+void set_deadlines(int fd, int seconds = 0) {
     timeval tv{};
-    tv.tv_sec = comm_timeout_s();
+    tv.tv_sec = seconds > 0 ? seconds : comm_timeout_s();
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
@@ -190,9 +190,12 @@ static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
             if (!(pf.revents & POLLIN)) continue;
             const int fd = ::accept(c->listen_fd, nullptr, nullptr);
             if (fd < 0) continue;
-            set_deadlines(fd);
             // hello = rank + the job's token; anything else (a stray connection, a peer of another job, a duplicate) is dropped and
-            // the loop keeps accepting - one bad hello must not abort the communicator while the real peers are still on their way
+            // the loop keeps accepting - one bad hello must not abort the communicator while the real peers are still on their way.
+            // The hello itself gets a SHORT deadline (a real peer sends its 36 bytes right after connect): a connection that says nothing -
+            // a port scan, a health probe, a half-open peer - must not hold the serial accept loop for the whole join deadline while
+            // the real peers wait in the backlog; the long data deadline applies only once the token and the rank have checked out.
+            set_deadlines(fd, (int)std::max<long long>(1, std::min<long long>(left / 1000, 3)));
             int32_t peer = -1;
             char tok[2 * kTokenBytes];
             if (!recv_all(fd, &peer, 4) || !recv_all(fd, tok, sizeof(tok)) || memcmp(tok, token.data(), sizeof(tok)) != 0 || peer < 1 ||
@@ -201,6 +204,7 @@ static int tcp_connect_all(wh_comm* c, const uint8_t* id) {
                 continue;
             }
             setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            set_deadlines(fd);
             const int32_t ack = 1;
             if (!send_all(fd, &ack, 4)) { ::close(fd); continue; }
             c->socks[peer] = fd;

@@ -76,7 +76,7 @@ struct AttnArgs {
     int cross_div;           // > 1: slot b attends over the cross K / V of slot b / cross_div (beams of one audio share one copy)
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
-    const f16* cross_k; const f16* cross_v;   // layer base [Bmax][H][1500][64]
+    const float* cross_k; const float* cross_v;   // layer base [Bmax][H][1500][64], fp32 (round 5: Float16 rows cost 7e-3 sigma under a sharp softmax)
     f16 *att_hi, *att_lo;    // attention output (before the out projection) as an f16 hi | lo pair in B-fragment plane order (decoder32.hip)
     float* part;             // [B][H][n_split][kPartStride]: (m, l, o[64]) of every key split, one 128-byte-aligned slot each
     int* ticket;             // [B][H] arrival counters (zero between launches)
@@ -101,33 +101,51 @@ __device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float
     a.att_lo[o] = lo;
 }
 
-// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 halves).  Thread layout: 8 lanes per
-// key (16 bytes = 8 channels each), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
-// before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
-// o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
+// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 channels, T = f16: the self-attention cache, T = float:
+// the cross-attention rows).  Thread layout: 8 lanes per key (8 channels each: 16 bytes of f16, 32 bytes of fp32), 32 keys per pass,
+// PASSES passes; all K and V rows of the block are in flight before the first use.  Returns this block's softmax statistics (m, l)
+// and leaves the unnormalised output o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional,
+// global) gets s_t.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct KvPiece { static constexpr int W = (int)sizeof(T) / 2; uint4 r[W]; };     // 8 channels of one row
 template <bool NT>
-__device__ __forceinline__ uint4 load_kv16(const f16* p) {      // 16 bytes of a K / V row; NT: non-temporal (streamed once per step)
+__device__ __forceinline__ uint4 load16(const void* p) {      // NT: non-temporal (streamed once per step)
     if constexpr (NT) {
         const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
         return uint4{v[0], v[1], v[2], v[3]};
     } else return *reinterpret_cast<const uint4*>(p);
 }
+template <bool NT, typename T>
+__device__ __forceinline__ void load_kv8(const T* p, KvPiece<T>& o) {
+#pragma unroll
+    for (int w = 0; w < KvPiece<T>::W; ++w) o.r[w] = load16<NT>(reinterpret_cast<const unsigned char*>(p) + 16 * w);
+}
+template <typename T>
+__device__ __forceinline__ void kv8_to_float(const KvPiece<T>& k, float (&f)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&k.r[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+    } else {
+        f[0] = __uint_as_float(k.r[0].x); f[1] = __uint_as_float(k.r[0].y); f[2] = __uint_as_float(k.r[0].z); f[3] = __uint_as_float(k.r[0].w);
+        f[4] = __uint_as_float(k.r[1].x); f[5] = __uint_as_float(k.r[1].y); f[6] = __uint_as_float(k.r[1].z); f[7] = __uint_as_float(k.r[1].w);
+    }
+}
 
 // attend_fetch: every K and V row of the block is requested before anything is used.  Rows past n_load are not skipped but
 // re-read row n_load - 1 (clamped address): straight-line loads, no exec-mask branches; attend_compute ignores them (key >= n).
-template <int PASSES, bool NT>
-__device__ __forceinline__ void attend_fetch(const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load, uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES]) {
+template <int PASSES, bool NT, typename T>
+__device__ __forceinline__ void attend_fetch(const T* __restrict__ kb, const T* __restrict__ vb, int n_load, KvPiece<T> (&kreg)[PASSES], KvPiece<T> (&vreg)[PASSES]) {
     const int part = threadIdx.x & 7, kg = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = min(kg + 32 * i, n_load - 1);
-        kreg[i] = load_kv16<NT>(kb + (size_t)key * kHeadDim + part * 8);
+        load_kv8<NT>(kb + (size_t)key * kHeadDim + part * 8, kreg[i]);
     }
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = min(kg + 32 * i, n_load - 1);
-        vreg[i] = load_kv16<NT>(vb + (size_t)key * kHeadDim + part * 8);
+        load_kv8<NT>(vb + (size_t)key * kHeadDim + part * 8, vreg[i]);
     }
 }
 __device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, float (&qv)[8]) {
@@ -138,8 +156,8 @@ __device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, floa
 }
 // attend_compute: the fetched rows against ONE query; n of them count (rows past n: score -inf, V zeroed - they may be clamped re-reads
 // or, in the self-attention cache, rows no step has written yet).  Shared by the self- and cross-attention kernels.
-template <int PASSES>
-__device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kreg)[PASSES], uint4 (&vreg)[PASSES], int n, float* raw_scores,
+template <int PASSES, typename T>
+__device__ __forceinline__ void attend_compute(const float (&qv)[8], KvPiece<T> (&kreg)[PASSES], KvPiece<T> (&vreg)[PASSES], int n, float* raw_scores,
                                                float* red /* [16] */, float* osum /* [4][64] */, float* o_out /* [64] */, float* m_out, float* l_out,
                                                unsigned long long* stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -148,10 +166,11 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kre
     float lmax = -INFINITY;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        f16x8 k8 = *reinterpret_cast<f16x8*>(&kreg[i]);
+        float k8[8];
+        kv8_to_float(kreg[i], k8);
         float t = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t = fmaf((float)k8[j], qv[j], t);
+        for (int j = 0; j < 8; ++j) t = fmaf(k8[j], qv[j], t);
         t = group8_sum(t);
         const int key = kg + 32 * i;
         const bool in = key < n;
@@ -174,10 +193,10 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kre
         const bool valid = kg + 32 * i < n;
         const float p = valid ? __expf(s[i] - m) : 0.0f;
         if (part == 0) lsum += p;
-        if (!valid) vreg[i] = uint4{0, 0, 0, 0};          // rows past n were fetched speculatively: keep 0 * garbage out
-        f16x8 v8 = *reinterpret_cast<f16x8*>(&vreg[i]);
+        float v8[8];
+        kv8_to_float(vreg[i], v8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)v8[j], o[j]);
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(p, valid ? v8[j] : 0.0f, o[j]);      // rows past n were fetched speculatively: keep 0 * garbage out
     }
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) red[4 + wave] = lsum;
@@ -194,13 +213,13 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], uint4 (&kre
     *l_out = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
-template <int PASSES, bool NT, typename GetN, typename QFix>
-__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const f16* __restrict__ kb, const f16* __restrict__ vb, int n_load,
+template <int PASSES, bool NT, typename T, typename GetN, typename QFix>
+__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const T* __restrict__ kb, const T* __restrict__ vb, int n_load,
                                              GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
                                              float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
     // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
     // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
-    uint4 kreg[PASSES], vreg[PASSES];
+    KvPiece<T> kreg[PASSES], vreg[PASSES];
     attend_fetch<PASSES, NT>(kb, vb, n_load, kreg, vreg);
     float qv[8];
     attend_load_q(qg, qv);
@@ -253,11 +272,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_owner_kernel(const AttnArgs
         const int own = min(max(a.self_owner[(size_t)b * kMaxTok + key], 0), a.batch - 1);
         off[i] = (((size_t)own * H + h) * kMaxTok + key) * kHeadDim + part * 8;
     }
-    uint4 kreg[PASSES], vreg[PASSES];
+    KvPiece<f16> kreg[PASSES], vreg[PASSES];
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i) kreg[i] = load_kv16<false>(a.self_k + off[i]);
+    for (int i = 0; i < PASSES; ++i) load_kv8<false>(a.self_k + off[i], kreg[i]);
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i) vreg[i] = load_kv16<false>(a.self_v + off[i]);
+    for (int i = 0; i < PASSES; ++i) load_kv8<false>(a.self_v + off[i], vreg[i]);
     float qv[8];
     attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
     if (!(s_act && !s_done)) return;            // workgroup-uniform
@@ -737,10 +756,13 @@ int cross_attn_splits(int batch, int n_head) {
     // batch of 32 (tests/test_gpu_dims.py).  With >= 12 heads even a batch of 8 gives >= 576 workgroups at 6 splits
     // (measured large-v3: 8 passes 53.0 us at 32 slots / 20.4 at 8; 12 passes 53.8 / 20.8; 16 passes 58.5 / 20.7).
     (void)batch;
-    static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 16 / 12 / 8 / 4 / 2
+    static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 8 / 6 / 4 / 2
     // measured large-v3, 64 slots (profiles/r03a_*): 6 passes (8 splits, 70 registers, 7 waves per SIMD) 5.20 ms per decoder step against
     // 5.38 with 8 passes (6 splits, 87 registers); 1754 vs 1715 audio-s/s with three sessions in flight
-    const int passes = forced ? forced : (n_head >= 12 ? 6 : n_head >= 4 ? 4 : 2);
+    // round 5: the rows are fp32 (32 bytes per lane and key), so a pass carries the bytes two Float16 passes carried: 4 passes at >= 12 heads
+    // hold what the round-3 choice of 8 did (64 KB in flight per workgroup), 2 passes below
+    int passes = forced ? forced : (n_head >= 12 ? 4 : 2);
+    passes = passes > 6 ? 8 : passes > 4 ? 6 : passes > 2 ? 4 : 2;            // instantiated: 2 / 4 / 6 / 8 passes = 24 / 12 / 8 / 6 splits
     return (kCtx + passes * 32 - 1) / (passes * 32);
 }
 
@@ -784,21 +806,13 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     // non-temporal K / V loads (each row is read once per step; measured large-v3, 32 slots: 51.9 -> 49.7 us per launch, 3 sessions in
     // flight 13.4 k -> 14.2 k sequence-steps/s, profiles/r02i_*); WH_XATT_NT=0 is the A/B side
     static const int nt = env_int("WH_XATT_NT", 1);
-    if (nt && at.cross_div <= 1) {      // (cross_div > 1, beam search: cacheable loads below - the L2 of the XCD serves the other beams of the audio)
-        if (S == 3) dec_cross_attn_kernel<16, true><<<grid, 256, xlds, st>>>(at);
-        else if (S == 4) dec_cross_attn_kernel<12, true><<<grid, 256, xlds, st>>>(at);
-        else if (S == 6) dec_cross_attn_kernel<8, true><<<grid, 256, xlds, st>>>(at);
-        else if (S == 8) dec_cross_attn_kernel<6, true><<<grid, 256, xlds, st>>>(at);      // (held to 64 registers = 8 waves per SIMD: 2 % slower, profiles/r03p_*)
-        else if (S == 12) dec_cross_attn_kernel<4, true><<<grid, 256, xlds, st>>>(at);
-        else dec_cross_attn_kernel<2, true><<<grid, 256, xlds, st>>>(at);
-        return;
-    }
-    if (S == 3) dec_cross_attn_kernel<16, false><<<grid, 256, xlds, st>>>(at);
-    else if (S == 4) dec_cross_attn_kernel<12, false><<<grid, 256, xlds, st>>>(at);
-    else if (S == 6) dec_cross_attn_kernel<8, false><<<grid, 256, xlds, st>>>(at);
-    else if (S == 8) dec_cross_attn_kernel<6, false><<<grid, 256, xlds, st>>>(at);
-    else if (S == 12) dec_cross_attn_kernel<4, false><<<grid, 256, xlds, st>>>(at);
-    else dec_cross_attn_kernel<2, false><<<grid, 256, xlds, st>>>(at);
+    const bool ntl = nt && at.cross_div <= 1;      // (cross_div > 1, beam search: cacheable loads - the L2 of the XCD serves the other beams of the audio)
+#define XATT(P_) do { if (ntl) dec_cross_attn_kernel<P_, true><<<grid, 256, xlds, st>>>(at); else dec_cross_attn_kernel<P_, false><<<grid, 256, xlds, st>>>(at); } while (0)
+    if (S == 6) XATT(8);
+    else if (S == 8) XATT(6);
+    else if (S == 12) XATT(4);
+    else XATT(2);
+#undef XATT
 }
 
 // One decoder step for all slots: embed -> per layer [QKV, self-attention, out projection, cross query, cross-attention, cross out

@@ -938,7 +938,8 @@ extern "C" int wh_measure_kernels(wh_session* s, int batch, int n_steps, double*
     CHECK_SESSION(s); CHECK_BATCH(s, batch);
     if (!avg_us || !launches || n_steps < 0 || n_steps > kMaxTok - 2) return set_error(WH_ERR_INVALID_ARGUMENT, "wh_measure_kernels: invalid argument");
     const int L = s->m->dims.n_text_layer, Le = s->m->dims.n_audio_layer;
-    const size_t cap = (size_t)(9 * L + 4) * n_steps + 7 * Le + 16;
+    // launches per decoder step: embed + L x (8, or 10 in absorbed mode: xabs_qk / xabs_attn / xabs_vup replace dec_cross_attn) + logits + sampler
+    const size_t cap = (size_t)((s->use_xabs ? 10 : 8) * L + 4) * n_steps + 7 * Le + 16;
     KernelProfiler prof;
     prof.ev.resize(2 * cap); prof.kind.resize(cap); prof.capacity = cap;
     for (auto& e : prof.ev) WH_HIP(hipEventCreate(&e));

@@ -41,9 +41,10 @@ struct wh_model {
     std::vector<wh::Dec32LayerW> dec32;
     void* dec32_blob = nullptr;
     const f16* emb_t = nullptr; const float *lg_g = nullptr, *lg_c = nullptr;
-    // weight-absorbed cross-attention (xabs.hip): W_k^T tiles + W_v tiles per layer, built at load when the width supports it
+    // weight-absorbed cross-attention (xabs.hip): W_k^T tiles + W_v tiles per layer, built by the first session that uses the path
     std::vector<wh::XabsLayerW> xabs;
     void* xabs_blob = nullptr;
+    std::mutex xabs_mu;
     std::vector<int> align_slot;   // [L*H] -> slot or -1
     int n_align = 0;
     int* align_slot_dev = nullptr;
@@ -71,7 +72,8 @@ struct wh_session {
     f16* h1 = nullptr; float* x = nullptr; f16* xn = nullptr; f16 *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *att16 = nullptr;
     f16* hmlp = nullptr; f16* enc16 = nullptr; float* enc32 = nullptr;
     // decoder
-    f16 *cross_k = nullptr, *cross_v = nullptr, *self_k = nullptr, *self_v = nullptr;
+    float *cross_k = nullptr, *cross_v = nullptr;   // K / V-row mode: fp32 rows
+    f16 *self_k = nullptr, *self_v = nullptr;
     float *part = nullptr, *logits = nullptr;
     int* ticket = nullptr;
     float *align = nullptr, *align_mean = nullptr;

@@ -75,7 +75,7 @@ enum GemmEpi {
     EPI_CONV1 = 4,      // out16[(b*3002 + t + 1)*ldc + n] = gelu(v)  (padded time-major input of conv2)
     EPI_CONV2 = 5,      // x32[m*ldc + n] = gelu(v) + pos[t*ldc + n]
     EPI_F32 = 6,        // out32[m*ldc + n] = v
-    EPI_CROSS_KV = 7,   // n = l*2d + kv*d + h*64 + c, m = b*1500 + t -> (kv ? vt16 : k16)[(((l*Bmax + b)*H + h)*1500 + t)*64 + c]
+    EPI_CROSS_KV = 7,   // n = l*2d + kv*d + h*64 + c, m = b*1500 + t -> (kv ? v32 : k32)[(((l*Bmax + b)*H + h)*1500 + t)*64 + c]  (fp32 rows)
 };
 
 struct GemmArgs {
@@ -97,6 +97,8 @@ struct GemmArgs {
     const float* pos;
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
     int max_batch = 0;         // EPI_CROSS_KV: slot stride of the head-major cross K/V layout
+    float* k32 = nullptr;      // EPI_CROSS_KV: the fp32 cross-attention key / value rows
+    float* v32 = nullptr;
     int prof_kind = -1;        // KernelKind of this launch (measurement only)
 };
 
@@ -163,8 +165,8 @@ struct DecodeBuffers {
     const float *lnf_g, *lnf_b;
     f16* self_k;             // [L][Bmax][H][224][64]  head-major self-attention cache
     f16* self_v;
-    const f16* cross_k;      // [L][Bmax][H][1500][64] head-major cross-attention K / V (written by the cross-K/V GEMM epilogue)
-    const f16* cross_v;
+    const float* cross_k;    // [L][Bmax][H][1500][64] head-major cross-attention K / V rows, fp32 (written by the cross-K/V GEMM epilogue;
+    const float* cross_v;    //  K / V-row mode only)
     float* x;                // [n_bt*32][d] residual stream (= d32->x)
     float* q;                // [n_bt*32][d] f32 query (= d32->q)
     float* part;             // [B][H][kMaxSplit][kPartStride] cross-attention split partials
@@ -246,6 +248,7 @@ void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const fl
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
+constexpr int kXabsAutoMinSlots = 48;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides)
 constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); a session uses Xabs::n_split of them, fixed at creation
 // key splits of a session: one workgroup per (slot, split) owns a whole CU (LDS, registers), so slots x splits is the number of CUs the
 // kernel takes.  WH_XABS_SPLITS overrides (A/B).
