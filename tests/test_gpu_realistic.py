@@ -1,7 +1,7 @@
 """Full-depth GPU parity on weights with the activation statistics of a trained model, in the cross-attention mode the LIBRARY picks for
 every BASELINE configuration (VERDICT r04 "next round" 1a / 1b / 1d):
 
-  * large-v3, 32 + 32 layers, 64 slots (configs[3]: the absorbed cross-attention, the library's choice from 48 slots)
+  * large-v3, 32 + 32 layers, 64 slots (configs[3]: the absorbed cross-attention, the library's choice from 24 slots)
   * small, 12 + 12, 8 slots, word-timestamp alignment rows (configs[2]: the library's choice, per-layer K / V rows) - and the same
     fixture with the absorbed path forced
   * tiny.en, 4 + 4, 1 slot (configs[1]: the library's choice; d = 384 has no absorbed kernel)

@@ -249,7 +249,7 @@ def test_two_ranks_on_one_gpu_rehearsal():
     # and bench.py itself under the driver's launch line, 2 ranks on the one GPU
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29572", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--single-device",
-                        "--dist-backend", "gloo", "--model", "tiny.en", "--batch", "2", "--inflight", "2", "--no-cpu-baseline", "--no-roofline",
+                        "--dist-backend", "gloo", "--model", "tiny.en", "--batch", "2", "--inflight", "1", "--no-cpu-baseline", "--no-roofline",
                         "--no-other-configs"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     import json

@@ -3,7 +3,7 @@
   * the RCCL transport of wh_comm_* at world size = the number of GPUs the box shows (VERDICT r04 "next round" 8): one process per GPU,
     ncclCommInitRank + ncclAllGather through the C ABI.  On the one-GPU boxes of this pool that is world size 1 (the same code path
     with a single rank); the first box with more GPUs runs the real multi-rank collective without a code change;
-  * both cross-attention modes against the fp32 oracle on a sharp cross-attention at two layers (the quick form of
+  * both cross-attention modes against the fp32 oracle on the realistic-statistics recipe at two layers (the quick form of
     tests/test_gpu_realistic.py: K / V rows are fp32 since round 5);
   * wh_debug_peek refuses a request beyond the named buffer; the automatic mode threshold is what the header documents.
 """
@@ -82,21 +82,15 @@ def test_rccl_all_gather_at_world_size_equal_to_the_visible_gpus(tmp_path):
         f.write(f"wh_comm RCCL transport ran at world size {world} (= visible GPUs)\n")
 
 
-def _sharp(dims, seed):
-    """benign weights with a sharp, audio-dependent cross-attention (query / key x 16, output x 32): the regime in which Float16 keys cost
-    7e-3 sigma at depth (tests/realistic.py has the full recipe)"""
-    sd = dict(weights.synthetic_state_dict(dims, seed=seed))
-    sd["decoder.token_embedding.weight"] = sd["decoder.token_embedding.weight"] * np.float32(32)
-    for i in range(dims.n_text_layer):
-        for w, f in ((".cross_attn.out.weight", 32), (".cross_attn.query.weight", 16), (".cross_attn.key.weight", 16)):
-            sd[f"decoder.blocks.{i}" + w] = sd[f"decoder.blocks.{i}" + w] * np.float32(f)
-    return sd
-
-
 @pytest.mark.parametrize("mode", [0, 1], ids=["kv-rows-fp32", "absorbed"])
 def test_both_cross_attention_modes_meet_the_relative_contract_against_fp32(mode):
+    """tests/realistic.py's recipe (sharp audio-dependent cross-attention, x 32 embedding, log-normal LayerNorm gains, outlier channels)
+    on the two-layer width-768 model: the quick form of tests/test_gpu_realistic.py.  With Float16 cross keys / values the ORACLE itself
+    moves by 5e-3 .. 7e-3 sigma on this fixture (measured on the CPU), the Float16 self-attention cache alone by <= 3.2e-4: fp32 rows
+    and the absorbed path both have to land below 1e-3 sigma of the fp32 model."""
+    from realistic import realistic_state_dict
     dims = weights.MODEL_DIMS["test-small-l2"]
-    sd = _sharp(dims, seed=21)
+    sd = realistic_state_dict(dims, seed=21)
     model = api.Model(dims, sd)
     om = OracleWhisper(dims, sd)
     B = 3
@@ -113,7 +107,7 @@ def test_both_cross_attention_modes_meet_the_relative_contract_against_fp32(mode
     for p, t in enumerate(toks):
         got = sess.predictLogits([t] * B, [p] * B)
         worst = max(worst, max(float(np.abs(got[b] - ref[b][p]).max()) for b in range(B)))
-    assert sig > 5.0 and worst / sig <= 1e-3, (mode, worst, sig)
+    assert sig > 10.0 and worst / sig <= 1e-3, (mode, worst, sig)
     sess.close(); model.close()
 
 
@@ -128,5 +122,5 @@ def test_debug_peek_is_bounded_and_auto_threshold_is_documented():
     big = np.zeros(32 * d + 1, np.float32)
     assert lib.wh_debug_peek(sess.handle, b"x", big.ctypes.data, big.nbytes) != 0                      # beyond the buffer: refused
     assert lib.wh_debug_peek(sess.handle, b"part", buf.ctypes.data, 16) != 0                            # no absorbed buffers in this session
-    assert api.Session.xabsAutoMinSlots() == 48 or os.environ.get("WH_XABS_MIN_SLOTS")
+    assert api.Session.xabsAutoMinSlots() == 24 or os.environ.get("WH_XABS_MIN_SLOTS")
     sess.close(); model.close()

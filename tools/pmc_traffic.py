@@ -26,12 +26,23 @@ KIND = [  # (regex on the kernel name, kernel kind of bench.py)
 
 
 def read(path):
-    out = {}
+    out, resid = {}, []
     for row in csv.DictReader(open(path)):
+        m = re.search(r"dec32_proj_kernel<2, true.*@grid(\d+)", row["Kernel"])
+        if m:       # (round 5) tools/rocpd_pmc.py keys the shared RESID instantiation by its launch grid: the largest grid is fc2 (K split 4 ways)
+            resid.append((int(m.group(1)), float(row["AvgValue"]) * 1024.0, int(row["Dispatches"])))
+            continue
         for pat, kind in KIND:
             if re.search(pat, row["Kernel"]):
                 out[kind] = (float(row["AvgValue"]) * 1024.0, int(row["Dispatches"]))
                 break
+    if len(resid) >= 2:
+        resid.sort()
+        out["dec_proj_fc2"] = resid[-1][1:]
+        n = sum(r[2] for r in resid[:-1])
+        out["dec_proj_oproj"] = out["dec_proj_coproj"] = (sum(r[1] * r[2] for r in resid[:-1]) / n, n)
+    elif resid:
+        out["dec_proj_resid_avg"] = resid[0][1:]
     return out
 
 
@@ -56,7 +67,7 @@ def main():
         detail["dec_proj_resid_avg"]["bytes_per_launch_avg"] = avg
     elif avg is not None:
         bpl["dec_proj_oproj"] = bpl["dec_proj_coproj"] = avg
-    json.dump({"config": f"whisper-{model}, {B} chunks per step (tools/pmc_run.py, eager launches, 8 decoder steps at positions 0..8)",
+    json.dump({"config": f"whisper-{model}, {B} chunks per step (tools/pmc_run.py, eager launches, " + os.environ.get("WH_PMC_STEPS", "16") + " decoder steps from position 0: the positions bench.py's algorithmic bytes assume)",
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace only); KB per "
                          "dispatch averaged over all dispatches of the kernel; bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled per the "
                          "gfx950 correction of MI355X_MICROARCH.md; Infinity-Cache hits are counted, so this is traffic at the L2's memory side)",

@@ -248,7 +248,8 @@ void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const fl
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
-constexpr int kXabsAutoMinSlots = 48;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides)
+constexpr int kXabsAutoMinSlots = 24;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides): measured large-v3,
+                                        // one stream, ms per decoder step with fp32 K / V rows vs absorbed: 16 slots 3.60 / 3.91, 24 slots 4.31 / 4.00 (profiles/r05a_*)
 constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); a session uses Xabs::n_split of them, fixed at creation
 // key splits of a session: one workgroup per (slot, split) owns a whole CU (LDS, registers), so slots x splits is the number of CUs the
 // kernel takes.  WH_XABS_SPLITS overrides (A/B).
@@ -278,6 +279,7 @@ struct XabsArgs {
     unsigned long long* dbg;         // WH_DBG=1 timeline stamps of xabs_attn
     int ablate;                      // WH_XABS_ABLATE (timing probe, results are garbage): bit 0 no LDS-DMA, bit 1 no S / softmax / P V work
     int* gate;                       // cross-attention gate (dec_shared.h, WH_XATT_GATE=1): xabs_qk takes it, xabs_attn's last workgroup returns it
+    int pf;                          // xabs_attn: L2 prefetch distance in 16-key tiles (WH_XABS_PF; 0 = off)
 };
 bool xabs_supported(int d, int n_head);
 void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);
