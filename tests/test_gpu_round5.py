@@ -124,3 +124,38 @@ def test_debug_peek_is_bounded_and_auto_threshold_is_documented():
     assert lib.wh_debug_peek(sess.handle, b"part", buf.ctypes.data, 16) != 0                            # no absorbed buffers in this session
     assert api.Session.xabsAutoMinSlots() == 24 or os.environ.get("WH_XABS_MIN_SLOTS")
     sess.close(); model.close()
+
+
+def test_two_batch_tiles_per_projection_workgroup_is_bit_identical_to_a_lone_slot():
+    """Round 5: from two batch tiles on, a decoder projection workgroup multiplies its weight slab with TWO batch tiles (csrc/decoder32.hip,
+    NB = 2).  Per slot nothing may change: at 70 slots (three batch tiles: a group of two and a ragged group whose second tile does not
+    exist) every checked slot's teacher-forced logits, its greedy tokens and log-probs must equal - bit for bit - the same audio decoded
+    alone in a one-slot session (one tile per workgroup, chunks of five k-tiles), in both cross-attention modes."""
+    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=11))
+    B, check = 70, [0, 31, 32, 63, 64, 69]
+    xs = [synthetic_chunk(4000 + 17 * b) for b in range(B)]
+    opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
+                               temperatureFallbackCount=0, sampleLength=20)
+    steps = [(50258, 0), (50259, 1), (50359, 2), (1029, 3), (400, 150), (77, 222)]
+    for mode in (1, 0):
+        big = api.Session(model, B, crossAttentionMode=mode)
+        for b in range(B):
+            big.padOrTrim(xs[b], b)
+        big.logMelSpectrogram(B); big.encodeFeatures(B); big.prepareDecoderInputs(B)
+        got = [big.predictLogits([t] * B, [p] * B).copy() for t, p in steps]
+        big.prepareDecoderInputs(B)
+        prompt = big.prefillPrompt(opts)
+        res = big.decodeText(prompt, opts, batch=B)
+        for b in check:
+            one = api.Session(model, 1, crossAttentionMode=mode)
+            one.padOrTrim(xs[b], 0)
+            one.logMelSpectrogram(1); one.encodeFeatures(1); one.prepareDecoderInputs(1)
+            for k, (t, p) in enumerate(steps):
+                np.testing.assert_array_equal(one.predictLogits([t], [p])[0], got[k][b], err_msg=f"mode {mode} slot {b} step {k}")
+            one.prepareDecoderInputs(1)
+            r1 = one.decodeText(prompt, opts)[0]
+            assert r1.tokens == res[b].tokens and r1.tokenLogProbs == res[b].tokenLogProbs, (mode, b)
+            one.close()
+        big.close()
+    model.close()

@@ -279,7 +279,6 @@ struct XabsArgs {
     unsigned long long* dbg;         // WH_DBG=1 timeline stamps of xabs_attn
     int ablate;                      // WH_XABS_ABLATE (timing probe, results are garbage): bit 0 no LDS-DMA, bit 1 no S / softmax / P V work
     int* gate;                       // cross-attention gate (dec_shared.h, WH_XATT_GATE=1): xabs_qk takes it, xabs_attn's last workgroup returns it
-    int pf;                          // xabs_attn: L2 prefetch distance in 16-key tiles (WH_XABS_PF; 0 = off)
 };
 bool xabs_supported(int d, int n_head);
 void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);

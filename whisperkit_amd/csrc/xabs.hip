@@ -183,22 +183,20 @@ __device__ __forceinline__ void xabs_s_tile(const f16x8 (&af)[KSW], const XabsQF
 constexpr int kXabsHalves = 7;               // LDS ring of half tiles (8 keys): tiles i, i + 1 resident, i + 2 and half of i + 3 in flight
 constexpr int kXabsSpStride = 32 * 17;       // floats per wave partial: [32 heads][16 keys + 1]
 constexpr float kXabsDefer = 8.0f;           // the running maximum moves only when it would grow by more than this (p <= e^8 fits f16)
-__host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsHalves * cw * 4096 + 8 * kXabsSpStride * 4 + 1024 + 128 + 256; }      // (+ 256: landing pad of the L2 prefetch)
+__host__ __device__ constexpr int xabs_lds_bytes(int cw) { return kXabsHalves * cw * 4096 + 8 * kXabsSpStride * 4 + 1024 + 128; }
 
-// PF (round 5, WH_XABS_PF = distance in tiles): an L2 PREFETCH ahead of the LDS ring.  The ring holds two resident tiles and 1.5 tiles = 60 KB in
-// flight per CU - all the LDS there is - and a CU's share of the HBM stream is (bytes in flight) / (loaded memory latency): 26 GB/s per
-// CU, 3.3 TB/s on the 128 CUs one session's launch takes beside two other sessions (5.0 TB/s on 256).  More bytes in flight need a
-// place to land that is not LDS: with every tile request a wave also touches ONE 4-byte word of every 128-byte line of the half tile
-// `pf` tiles further on (one `buffer_load_dword ... lds` gather per wave, 40 lanes at d = 1280, into a 256-byte landing pad nobody
-// reads), so that line is in the XCD's L2 when the ring asks for it and the ring's own requests become L2 hits.  Results cannot change.
-template <int CW, int NHT, bool DBG, bool NTL, bool PF = false>
+// (Round 5, measured and rejected, profiles/r05b_xabs_attn_l2_prefetch_ab_rejected.jsonl: an L2 PREFETCH ahead of the LDS ring - with every
+// tile request a wave also touched one word of every 128-byte line of the half tile 2 or 3 tiles further on, a `buffer_load_dword ... lds`
+// gather into a landing pad nobody reads, so that the ring's own requests become L2 hits and more than the ring's 60 KB per CU are in
+// flight.  82.2 -> 92.3 us at 64 slots x 2 splits, 150.5 -> 172.5 us at 128 slots x 1 split, 2612 -> 2470 audio-s/s in flight: the CU's
+// share of the stream is not bounded by the bytes it has in flight (latency), the extra requests compete for the same fetch path.)
+template <int CW, int NHT, bool DBG, bool NTL>
 __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     constexpr int D = CW * 256, ROWB = D * 2, HALF = 8 * ROWB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float* spart = reinterpret_cast<float*>(smem + kXabsHalves * HALF);
     f16* pfrag = reinterpret_cast<f16*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4);
     float* alpha_l = reinterpret_cast<float*>(smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4 + 1024);
-    unsigned char* pf_pad = smem + kXabsHalves * HALF + 8 * kXabsSpStride * 4 + 1024 + 128;      // PF: 256 bytes every prefetch gather lands in
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: no waterfall loops around the buffer resource / M0
     // workgroup id -> (split, slot): id % 8 is the XCD; an XCD takes whole groups of 4 consecutive slots of one split, whose 32-byte
@@ -230,10 +228,6 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
         const int row = o / ROWB, slot = (o - row * ROWB) >> 4;
         p_off[p] = (half_w * 8 + row) * ROWB + ((slot ^ xswz(half_w * 8 + row)) << 4);
     }
-    // PF: this lane's 128-byte line of the wave's quarter of a half tile (HALF / 128 = D / 8 lines, D / 32 per wave); other lanes point
-    // past every resource (offset HALF >= num_records: nothing is fetched)
-    const int pf_off = lane < D / 32 ? (wq * (D / 32) + lane) * 128 : HALF;
-    constexpr int NPI = CW + (PF ? 1 : 0);      // vector-memory operations of one issue()
     int hi_mine = -1;                    // the last tile this wave has requested (wave-uniform)
     // buffer_load ... lds with a per-tile resource (base = the tile's first row, num_records = bytes to the end of the slot's encoder
     // output): the per-lane offset is loop-invariant, rows past position 1499 are out of range (nothing is fetched; they are masked
@@ -247,27 +241,17 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
 #pragma unroll
         for (int p = 0; p < CW; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, p_off[p], 0, 0, NTL ? 2 : 0);
-        if constexpr (PF) {
-            // ALWAYS one operation (the vmcnt bookkeeping of wait_tile counts NPI per issue): beyond this split's tiles or the slot's
-            // 1500 rows the resource has no records and nothing is fetched
-            const int ip = i + a.pf;
-            const int r0 = (tile_lo + ip) * 16 + half_w * 8;
-            const int rows = ip < n ? min(8, kCtx - r0) : 0;
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(enc) + (rows > 0 ? (size_t)r0 * ROWB : 0), 0,
-                                                                                rows > 0 ? rows * ROWB : 0, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)pf_pad, 4, pf_off, 0, 0, 0);
-        }
 #else
-        (void)dst; (void)t16; (void)p_off; (void)pf_off; (void)pf_pad;
+        (void)dst; (void)t16; (void)p_off;
 #endif
         hi_mine = i;
     };
     auto wait_tile = [&](int k) {        // this wave's pieces of tile k have landed; younger tiles stay in flight (requests return in order)
         switch (hi_mine - k) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPI) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPI) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPI) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CW) : "memory"); break;
         }
     };
     // ---- prologue.  Request order = return order: the slot state first (so that the liveness test does not wait for the tile stream),
@@ -615,13 +599,13 @@ void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
     else xabs_qk_kernel<1><<<grid, 256, 0, st>>>(a);
 }
 
-template <int CW, int NHT, bool DBG, bool NTL, bool PF = false>
+template <int CW, int NHT, bool DBG, bool NTL>
 static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
     constexpr int lds = xabs_lds_bytes(CW);
     static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     const int n_grp = (a.batch + 3) / 4 * a.n_split;         // (split, 4 slots) groups, 8 of them (one per XCD) to every 32 workgroup ids
-    xabs_attn_kernel<CW, NHT, DBG, NTL, PF><<<dim3((unsigned)((n_grp + 7) / 8 * 32)), 512, lds, st>>>(a);
+    xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((n_grp + 7) / 8 * 32)), 512, lds, st>>>(a);
 }
 template <int CW, int NHT>
 static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
@@ -630,8 +614,6 @@ static void launch_attn_t(const XabsArgs& a, hipStream_t st) {
     if (a.dbg || ablate) { XabsArgs b = a; b.ablate = ablate; launch_attn_k<CW, NHT, true, false>(b, st); return; }      // the stamped instantiation (tools/xabs_timeline.py)
     // beam search (cross_div > 1: the beams of an audio read ONE encoder output): cacheable loads - the workgroups of an audio's beams are
     // dispatched back to back onto one XCD (4 consecutive slots per group) and the later ones are meant to hit the first one's lines in its L2
-    static const int pf = xabs_env("WH_XABS_PF", 0);          // L2 prefetch distance in 16-key tiles (0 = off); see the kernel header
-    if (pf > 0 && a.cross_div <= 1) { XabsArgs b = a; b.pf = pf; if (nt) launch_attn_k<CW, NHT, false, true, true>(b, st); else launch_attn_k<CW, NHT, false, false, true>(b, st); return; }
     if (nt && a.cross_div <= 1) launch_attn_k<CW, NHT, false, true>(a, st); else launch_attn_k<CW, NHT, false, false>(a, st);
 }
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st) {
