@@ -8,11 +8,12 @@ it - "PCM in host memory -> token ids + segments on host": padOrTrim from host f
 encoder -> cross-K/V projection -> greedy token loop (WhisperKit decodeText semantics, filters + sampler on device) ->
 findSeekPointAndSegments per chunk on the host -> result records (+ all-gather over RCCL when N > 1).
 
-Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step
-(two 32-slot MFMA batch tiles per decode launch), 3 device batches in flight (one session / HIP stream / host thread each: the encoder
-GEMMs and the latency-bound projection kernels of one batch overlap the HBM-bound cross-attention stream of the others), greedy.
-Measured alternatives on one MI355X (profiles/r02n_*, r02o_*): 32 x 3 in flight 1521 audio-s/s, 64 x 2 1621, 64 x 3 1674, 64 x 4 1715,
-96 x 2 1695, 128 x 1 1615, 128 x 2 1735.  Weights are random-init (no checkpoints in
+Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step, greedy.  The engine
+batches continuously: TWO consecutive 64-chunk steps share one 128-slot device batch (four 32-slot MFMA batch tiles per decode launch: the
+decoder's weight stream and its latency-bound launch chain are paid once per 128 windows), and 3 device batches are in flight (one session / HIP
+stream / host thread each: the encoder GEMMs and the projection kernels of one batch run in the gaps of the HBM-bound cross-attention stream of
+the others).  `--device-batch 64` is the round-4 configuration (one step per batch).  Measured on one MI355X (profiles/r05a_*, r05d_*):
+64-slot batches x 3 in flight 2350 audio-s/s, 128 x 3 2647, 128 x 2 2569, 192 x 3 2470, 256 x 3 2584, 256 x 2 2609.  Weights are random-init (no checkpoints in
 the image), so EOT is never the argmax and the loop runs to the reference's length cap (sampleLength 224 -> 223 decoder forward
 passes per chunk): the decode length is fixed and comparable across runs.  Round 1's configuration (8 chunks per step, 3 in
 flight) and the other BASELINE configs are measured after the headline and reported under "other_configs".
@@ -20,8 +21,8 @@ flight) and the other BASELINE configs are measured after the headline and repor
 N > 1 (configs[3]: "64 x 30 s chunks sharded across 8 x MI355X"): STRONG scaling by default - a step is still 64 chunks in total,
 block-partitioned over the ranks (64 / N per GPU, no data-path collective), the per-chunk result records of every step are
 all-gathered through the C-ABI communicator (wh_comm_*: ncclAllGather over xGMI, librccl dlopen'ed by libwhisperhip).  A GPU packs
-its shares of G = N consecutive steps into one full device batch (continuous batching: the 64 slots / 3 batches in flight of the
-1-GPU line, so the kernels run at the batch size they are tuned for); `--scaling weak` is the old mode (64 chunks per step AND GPU).
+its shares of up to G consecutive steps into one device batch of at most 128 slots (continuous batching, as at one GPU; never more steps
+than a session's share of the run: plan_batches); `--scaling weak` is the old mode (64 chunks per step AND GPU).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   `roofline`      the dominant kernel of the step, HIP-event timed on the session stream (wh_measure_kernels), against the
@@ -45,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
 T_START = time.perf_counter()
 
 
@@ -208,7 +209,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     first, last = parallel.partition_chunks(total, world, rank)
     n_local = last - first                                       # this rank's chunks of one step
     per_rank_max = (total + world - 1) // world
-    cap = min(128, max(device_batch or B, n_local))              # device batch capacity in slots (a session holds at most 128)
+    cap = min(256, max(device_batch or B, n_local))              # device batch capacity in slots (a session holds at most 256)
     G = max(1, cap // max(n_local, 1)) if n_local else 1         # steps packed into one device batch ...
     G = max(1, min(G, (steps + F - 1) // F))                     # ... never more than a session's share of the run
     slots = max(1, G * n_local)
@@ -462,9 +463,9 @@ def long_audio_config(args, local_rank):
     out = run(20)
     out["note"] = ("10 min synthetic audio -> VADAudioChunker (30 s chunks, one device batch) -> decodeWithFallback with the ladder "
                    "forced once per window (T = 0 greedy, then 0.2 with the seeded top-5 sampler) -> segments")
-    # (K / V-row cross-attention for the beam session: the beams of an audio share its rows through the XCD's L2; the absorbed kernel
-    # streams the encoder output once per SLOT, i.e. five times per audio - measured 245 vs 312 audio-s/s)
-    beam = run(100, mode=0, beamSize=5)
+    # (the library's choice at 100 slots: the absorbed cross-attention, which reads the audio's one encoder output with cacheable loads when
+    # slots share it - round 5, profiles/r05b_beam5_cross_attention_mode_ab.jsonl: 241 audio-s/s against 233 with fp32 K / V rows)
+    beam = run(100, beamSize=5)
     beam["note"] = ("NO REFERENCE BEHAVIOUR: the same workload with beam = 5 for the T = 0 pass (20 windows x 5 beams = 100 decoder slots, "
                     "openai/whisper BeamSearchDecoder semantics, host-ranked candidates per step), then the same sampled fallback; the "
                     "reference's BeamSearchTokenSampler is a fatalError stub (Core/Text/TokenSampler.swift:254-290)")

@@ -126,11 +126,11 @@ def test_debug_peek_is_bounded_and_auto_threshold_is_documented():
     sess.close(); model.close()
 
 
-def test_two_batch_tiles_per_projection_workgroup_is_bit_identical_to_a_lone_slot():
-    """Round 5: from two batch tiles on, a decoder projection workgroup multiplies its weight slab with TWO batch tiles (csrc/decoder32.hip,
-    NB = 2).  Per slot nothing may change: at 70 slots (three batch tiles: a group of two and a ragged group whose second tile does not
-    exist) every checked slot's teacher-forced logits, its greedy tokens and log-probs must equal - bit for bit - the same audio decoded
-    alone in a one-slot session (one tile per workgroup, chunks of five k-tiles), in both cross-attention modes."""
+def test_three_batch_tiles_with_a_ragged_last_tile_are_bit_identical_to_a_lone_slot():
+    """Batch invariance beyond the two batch tiles the other tests reach: at 70 slots (three 32-slot batch tiles of the decoder projections,
+    the last one ragged; 18 four-slot groups of the absorbed cross-attention) every checked slot's teacher-forced logits, its greedy
+    tokens and log-probs must equal - bit for bit - the same audio decoded alone in a one-slot session, in both cross-attention modes.
+    (Written for the round-5 experiment that gave a projection workgroup two batch tiles - bit-identical, slower, rejected: csrc/decoder32.hip.)"""
     dims = weights.MODEL_DIMS["test-large-v3-l2"]
     model = api.Model(dims, weights.synthetic_state_dict(dims, seed=11))
     B, check = 70, [0, 31, 32, 63, 64, 69]
@@ -159,3 +159,35 @@ def test_two_batch_tiles_per_projection_workgroup_is_bit_identical_to_a_lone_slo
             one.close()
         big.close()
     model.close()
+
+
+def test_a_session_of_200_slots_decodes_every_slot_like_a_lone_session():
+    """A session holds up to 256 windows since round 5 (kMaxSessionSlots; 128 before): seven batch tiles of the decoder projections at 200
+    slots, the last one ragged.  Slots of the first, a middle and the last tile against one-slot sessions of the same audio, bit for bit
+    (micro model: the K / V-row path; the encoder GEMMs run at M = 300 000 rows); 257 slots are refused."""
+    import ctypes
+    dims = weights.MODEL_DIMS["test-micro"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
+    h = ctypes.c_void_p()
+    with pytest.raises(api.WhisperError):
+        api._check(model.lib.wh_session_create(model.handle, 257, ctypes.byref(h)))
+    B, check = 200, [0, 31, 32, 100, 191, 192, 199]
+    xs = {b: synthetic_chunk(300 + b) for b in check}
+    filler = synthetic_chunk(299)
+    opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
+                               temperatureFallbackCount=0, sampleLength=24)
+    big = api.Session(model, B)
+    for b in range(B):
+        big.padOrTrim(xs.get(b, filler), b)
+    big.logMelSpectrogram(B); big.encodeFeatures(B); big.prepareDecoderInputs(B)
+    prompt = big.prefillPrompt(opts)
+    res = big.decodeText(prompt, opts, batch=B)
+    for b in check:
+        one = api.Session(model, 1)
+        one.padOrTrim(xs[b], 0)
+        one.logMelSpectrogram(1); one.encodeFeatures(1); one.prepareDecoderInputs(1)
+        np.testing.assert_array_equal(one.getEncoderOutput(0), big.getEncoderOutput(b))
+        r1 = one.decodeText(prompt, opts)[0]
+        assert r1.tokens == res[b].tokens and r1.tokenLogProbs == res[b].tokenLogProbs, b
+        one.close()
+    big.close(); model.close()

@@ -419,7 +419,7 @@ extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross
 }
 static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
-    if (max_batch < 1 || max_batch > 128) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, 128]", max_batch);
+    if (max_batch < 1 || max_batch > kMaxSessionSlots) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, %d]", max_batch, kMaxSessionSlots);
     WH_HIP(hipSetDevice(m->device));
     wh_session* s = new wh_session();
     s->B = max_batch;

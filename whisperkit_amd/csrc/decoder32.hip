@@ -125,94 +125,74 @@ __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, flo
 // __launch_bounds__(256, 2): capping the wave at 256 unified registers keeps the accumulators in arch VGPRs (with 512 allowed the
 // compiler parked them in AccVGPRs and copied all 32 of them out and back in every loop iteration: 160 v_accvgpr moves per launch);
 // every instantiation fits (88 - 204 VGPRs, no scratch), two workgroups can share a CU.
-// NB (round 5): batch tiles per workgroup.  With NB = 2 a workgroup multiplies ITS weight slab with two batch tiles (two accumulator sets,
-// the planes of both tiles; chunks of <= 2 k-tiles keep it under the register cap): the slab crosses L2 -> CU once instead of twice,
-// half as many workgroups are in flight, and the fixed part of a workgroup's life (entry, first data, reduction, epilogue operands: ~5 of
-// its ~7 us) is paid once per two tiles - beside other sessions the launches are priced in CU-time, not in latency.  Per slot nothing
-// changes: the same MFMA sequence into the same accumulator, the same reduction order, the same epilogue - results are bit-identical
-// to NB = 1 and batch-invariant.
-// NTW: non-temporal weight loads.  A slab is read by the workgroups of ONE XCD (ids x + 8 g): with a single reader it is streamed
+// (Round 5, measured and rejected, profiles/r05c_projection_two_batch_tiles_per_workgroup_ab_rejected.jsonl: ONE workgroup per weight slab for TWO
+// batch tiles - two accumulator sets, the planes of both tiles in every chunk, chunks of 2 k-tiles to stay under the register cap; built,
+// bit-identical (tests/test_gpu_round5.py at 70 slots), and slower: every N = d launch 10.5 -> 13.9 us alone (the wave's MFMA chain doubles
+// and ten chunk round trips replace four), 5.44 -> 5.98 ms per 64-slot step, 2314 -> 2150 audio-s/s at 64 slots x 3 in flight, 2602 -> 2579 at
+// 128 x 3: beside other sessions the launches are not priced in workgroups-in-flight either.  Code in git history, commit "decoder
+// projections: two batch tiles per workgroup".)
+// NTW: non-temporal weight loads.  A slab is read by n_bt workgroups of ONE XCD (ids x + 8 t): with a single batch tile it is streamed
 // once (nt keeps it from displacing the activations in L2); with two or more, the later readers are meant to hit the first one's lines.
-template <int MODE, bool HILO, int TC, bool NTW, int NB>
+template <int MODE, bool HILO, int TC, bool NTW>
 __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
-    __shared__ float red[NB][4][16][64];             // the four waves' partial tiles (per batch tile)
-    __shared__ float st_l[NB][8][32][3];             // LayerNorm statistics: 8 partial (n, mean, M2) per slot
-    __shared__ float xs_raw[NB][MODE == P32_LOGITS ? 256 * 6 : 32 * 33];   // RESID: the tile's new residual values; LOGITS: sampler records
+    __shared__ float red[4][16][64];                 // the four waves' partial tiles
+    __shared__ float st_l[8][32][3];                 // LayerNorm statistics: 8 partial (n, mean, M2) per slot
+    __shared__ float xs_raw[MODE == P32_LOGITS ? 256 * 6 : 32 * 33];   // RESID: the tile's new residual values; LOGITS: sampler records
+    float (*xs)[33] = reinterpret_cast<float (*)[33]>(xs_raw);
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_rt = (a.N + 31) >> 5;
-    // Workgroup id -> (row tile, K slice, batch-tile group): ids x + 8 g of one group of 8 share the weight slab x and differ in the batch
-    // tiles g NB .. g NB + NB - 1, so the readers of a slab are dispatched back to back onto the SAME XCD (id % 8) and the slab crosses HBM
-    // once, whatever the parity of the tile count (PMC at 64 slots before this: the 1621 logits tiles fetched 273 MB for 133 MB of weights).
-    const int n_btg = (a.n_bt + NB - 1) / NB;
-    const int grp8 = blockIdx.x / (8 * n_btg), in8 = blockIdx.x % (8 * n_btg);
-    const int xw = grp8 * 8 + (in8 & 7), btg = in8 >> 3;
+    // Workgroup id -> (row tile, K slice, batch tile): ids x + 8 t of one group of 8 share the weight slab x and differ in the batch
+    // tile t, so the readers of a slab are dispatched back to back onto the SAME XCD (id % 8) and the slab crosses HBM once, whatever
+    // the parity of the tile count (PMC at 64 slots before this: the 1621 logits tiles fetched 273 MB for 133 MB of weights).
+    const int grp8 = blockIdx.x / (8 * a.n_bt), in8 = blockIdx.x % (8 * a.n_bt);
+    const int xw = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
     if (xw >= n_rt * a.ks) return;          // padding of the last group (workgroup-uniform)
     const int rt = xw % n_rt, ksi = xw / n_rt;
     const int KT = a.K >> 4;
     const int kt0 = (ksi * 4 + wave) * a.tw;
     const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)rt * KT + kt0) * 64 + lane;
-    // epilogue coordinates of this thread: slot j of every batch tile, channels n .. n + 3 (the accumulator rows 4 wave + i of half-wave h)
+    const size_t zoff = ((size_t)bt * KT + kt0) * 64 + lane;
+    const u32x4* hp = reinterpret_cast<const u32x4*>(a.zhi) + zoff;
+    const u32x4* lp = HILO ? reinterpret_cast<const u32x4*>(a.zlo) + zoff : nullptr;
+    // epilogue coordinates of this thread: slot j, channels n .. n + 3 (the accumulator rows 4 wave + i of half-wave h)
     const int j = tid & 31, sub = tid >> 5;
     const int n = rt * 32 + 4 * sub;
-    // the group's batch tiles; the last group of an odd tile count has a tile that does not exist: it streams the planes of the last real
-    // tile again (uniform control flow through the MFMA loop) and its epilogue is skipped as a whole (workgroup-uniform)
-    int bt[NB], gb[NB];
-    bool has[NB], valid[NB];
-    const u32x4* hp[NB];
-    const u32x4* lp[NB];
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        has[t] = btg * NB + t < a.n_bt;
-        bt[t] = min(btg * NB + t, a.n_bt - 1);
-        gb[t] = bt[t] * 32 + j;
-        valid[t] = has[t] && gb[t] < a.batch;
-        const size_t zoff = ((size_t)bt[t] * KT + kt0) * 64 + lane;
-        hp[t] = reinterpret_cast<const u32x4*>(a.zhi) + zoff;
-        lp[t] = HILO ? reinterpret_cast<const u32x4*>(a.zlo) + zoff : nullptr;
-    }
+    const int gb = bt * 32 + j;
+    const bool valid = gb < a.batch;
 
-#define D32_STAMP(i) do { if (a.dbg && tid == 0 && btg == 0) a.dbg[(size_t)(xw & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(xw & 4095) * 8 + (i)] = wall_clock64(); } while (0)
     D32_STAMP(0);
     // ---- small epilogue operands, requested first (memory returns are in order per wave: they arrive under the weight stream)
-    float2 sp[NB][5] = {};
+    float2 sp[5] = {};
     if constexpr (kLN) {
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int idx = min(sub + 8 * i, a.n_stat - 1);
-                sp[t][i] = a.stat_in[((size_t)bt[t] * a.n_stat + idx) * 32 + j];
-            }
+        for (int i = 0; i < 5; ++i) {
+            const int idx = min(sub + 8 * i, a.n_stat - 1);
+            sp[i] = a.stat_in[((size_t)bt * a.n_stat + idx) * 32 + j];
+        }
     }
-    float4 e0 = {0, 0, 0, 0}, e1[NB];       // LN modes: g, c (per channel);  RESID: bias (per channel), old x (per slot)
-    int pos_l[NB], live_l[NB];
-    if constexpr (kLN) e0 = *reinterpret_cast<const float4*>(a.fold_g + n);
-    else e0 = *reinterpret_cast<const float4*>(a.bias + n);
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        if constexpr (kLN) e1[t] = *reinterpret_cast<const float4*>(a.fold_c + n);
-        else e1[t] = *reinterpret_cast<const float4*>(a.x + (size_t)gb[t] * a.d + n);
-        pos_l[t] = 0; live_l[t] = 0;
-        if (valid[t]) { live_l[t] = slot_live(a.seq + gb[t]); if constexpr (MODE == P32_QKV) pos_l[t] = a.seq[gb[t]].token_index; }
+    float4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};    // LN modes: g, c;  RESID: bias, old x
+    int pos_l = 0, live_l = 0;
+    if constexpr (kLN) {
+        e0 = *reinterpret_cast<const float4*>(a.fold_g + n);
+        e1 = *reinterpret_cast<const float4*>(a.fold_c + n);
+    } else {
+        e0 = *reinterpret_cast<const float4*>(a.bias + n);
+        e1 = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
     }
-    int rules[NB][6];
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rules[t][i] = 0;
+    if (valid) { live_l = slot_live(a.seq + gb); if constexpr (MODE == P32_QKV) pos_l = a.seq[gb].token_index; }
+    int rules[6] = {0, 0, 0, 0, 0, 0};
     unsigned masked4 = 0xffffffffu;
     int tb = 0, ws_tok = 0, eot_tok = 0, nots_tok = 0, r16 = 0;
     if constexpr (MODE == P32_LOGITS) {
         if (a.cfg) r16 = a.cfg->f16_logits;
         if (a.stats) {
+            if (valid) {
 #pragma unroll
-            for (int t = 0; t < NB; ++t)
-                if (valid[t]) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) rules[t][i] = a.seq[gb[t]].f_rules[i];
-                }
+                for (int i = 0; i < 6; ++i) rules[i] = a.seq[gb].f_rules[i];
+            }
             if (n + 3 < a.N) masked4 = *reinterpret_cast<const unsigned*>(a.sup_mask + n);
             else {
                 masked4 = 0;
@@ -224,51 +204,37 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     }
 
     // ---- weight stream x activation planes on the matrix cores
-    f32x16 acc_h[NB], acc_l[NB];
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_h[t][r] = 0.0f; acc_l[t][r] = 0.0f; }
+    f32x16 acc_h = {0}, acc_l = {0};
     auto stats_to_lds = [&]() {
         // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
         if constexpr (kLN) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                float cm = sp[t][0].x, cM2 = sp[t][0].y;           // n_stat >= 8 is not required: a thread without partials writes count 0
-                const int mine = sub < a.n_stat ? (a.n_stat - sub + 7) >> 3 : 0;
-                if (mine > 1) chan32_k<1>(cm, cM2, sp[t][1].x, sp[t][1].y);
-                if (mine > 2) chan32_k<2>(cm, cM2, sp[t][2].x, sp[t][2].y);
-                if (mine > 3) chan32_k<3>(cm, cM2, sp[t][3].x, sp[t][3].y);
-                if (mine > 4) chan32_k<4>(cm, cM2, sp[t][4].x, sp[t][4].y);
-                st_l[t][sub][j][0] = 32.0f * (float)mine; st_l[t][sub][j][1] = cm; st_l[t][sub][j][2] = cM2;
-            }
+            float cm = sp[0].x, cM2 = sp[0].y;                     // n_stat >= 8 is not required: a thread without partials writes count 0
+            const int mine = sub < a.n_stat ? (a.n_stat - sub + 7) >> 3 : 0;
+            if (mine > 1) chan32_k<1>(cm, cM2, sp[1].x, sp[1].y);
+            if (mine > 2) chan32_k<2>(cm, cM2, sp[2].x, sp[2].y);
+            if (mine > 3) chan32_k<3>(cm, cM2, sp[3].x, sp[3].y);
+            if (mine > 4) chan32_k<4>(cm, cM2, sp[4].x, sp[4].y);
+            st_l[sub][j][0] = 32.0f * (float)mine; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
         }
     };
     {
-        constexpr int LC = HILO ? TC : 1;
-        u32x4 wa[TC], wb[TC], ha[NB][TC], hb[NB][TC], la[NB][LC], lb[NB][LC];
-        auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[NB][TC], u32x4 (&l)[NB][LC], int c) {
+        u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
+        auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
             for (int i = 0; i < TC; ++i) w[i] = NTW ? __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64) : wp[(size_t)(c * TC + i) * 64];
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
+            for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
+            if constexpr (HILO) {
 #pragma unroll
-                for (int i = 0; i < TC; ++i) h[t][i] = hp[t][(size_t)(c * TC + i) * 64];
-                if constexpr (HILO) {
-#pragma unroll
-                    for (int i = 0; i < TC; ++i) l[t][i] = lp[t][(size_t)(c * TC + i) * 64];
-                }
+                for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
             }
         };
-        auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[NB][TC], const u32x4 (&l)[NB][LC]) {
+        auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
                 const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[t][i]), acc_h[t], 0, 0, 0);
-                    if constexpr (HILO) acc_l[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[t][i]), acc_l[t], 0, 0, 0);
-                }
+                acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h, 0, 0, 0);
+                if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l, 0, 0, 0);
             }
         };
         const int nch = a.tw / TC;
@@ -288,39 +254,29 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     stats_to_lds();       // after the stream: the statistics are epilogue operands (timeline probe: waiting for them up front cost 1 us per launch)
     D32_STAMP(3);
 #pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[t][wave][r][lane] = HILO ? fmaf(acc_l[t][r], 1.0f / 2048.0f, acc_h[t][r]) : acc_h[t][r];
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = HILO ? fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]) : acc_h[r];
     __syncthreads();
     D32_STAMP(4);
-    float v[NB][4];
+    float v[4];
 #pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v[t][i] = ((red[t][0][4 * wave + i][lane] + red[t][1][4 * wave + i][lane]) + red[t][2][4 * wave + i][lane]) + red[t][3][4 * wave + i][lane];
+    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
 
     // ---- K split across workgroups: publish, ticket, the last arriver sums the slices in index order.  Write-through (sc1)
     // 16-byte stores, a drained vmcnt in every storing wave, one relaxed ticket; the finisher reads the slabs with sc1 loads, which
     // bypass its L1 and are served by L2 - no agent-scope fence on either side (MI355X_MICROARCH.md "handoff-flag", R1).
-    // (NB > 1: one ticket per workgroup = per (row tile, batch-tile group), kept in the first tile's counter.)
     if (a.ks > 1) {
-        float* base[NB];
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            base[t] = a.part + (((size_t)bt[t] * n_rt + rt) * a.ks) * 1024 + tid * 4;
-            if (has[t]) {
-                const f32x4 pv4 = {v[t][0], v[t][1], v[t][2], v[t][3]};
-                float* mine = base[t] + (size_t)ksi * 1024;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
-            }
+        float* base = a.part + (((size_t)bt * n_rt + rt) * a.ks) * 1024 + tid * 4;
+        {
+            const f32x4 pv4 = {v[0], v[1], v[2], v[3]};
+            float* mine = base + (size_t)ksi * 1024;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            int* cnt = a.ticket + bt[0] * n_rt + rt;
-            const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (tk == a.ks - 1);
+            int* cnt = a.ticket + bt * n_rt + rt;
+            const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == a.ks - 1);
             if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
             last_flag = last;
         }
@@ -329,114 +285,106 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }
             return;
         }
+        float pv[8][4];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            float pv[8][4];
+        for (int s = 0; s < 8; ++s) {       // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
+            const float* p = base + (size_t)(s < a.ks ? s : 0) * 1024;
 #pragma unroll
-            for (int s_ = 0; s_ < 8; ++s_) {    // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
-                const float* p = base[t] + (size_t)(s_ < a.ks ? s_ : 0) * 1024;
+            for (int i = 0; i < 4; ++i) pv[s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pv[s_][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        for (int i = 0; i < 4; ++i) {
+            float t = pv[0][i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x_ = pv[0][i];
-#pragma unroll
-                for (int s_ = 1; s_ < 8; ++s_) x_ += (s_ < a.ks) ? pv[s_][i] : 0.0f;
-                v[t][i] = x_;
-            }
+            for (int s = 1; s < 8; ++s) t += (s < a.ks) ? pv[s][i] : 0.0f;
+            v[i] = t;
         }
     }
 
     D32_STAMP(5);
-    // ---- epilogues, one batch tile after the other (a tile that does not exist is skipped as a whole: `has` is workgroup-uniform)
+    // ---- epilogues
+    float y[4];
+    if constexpr (kLN) {
+        float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        if (!has[t]) continue;
-        float (*xs)[33] = reinterpret_cast<float (*)[33]>(xs_raw[t]);
-        float y[4];
-        if constexpr (kLN) {
-            float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
+        for (int s = 0; s < 8; ++s) chan_merge(cn, cm, cM2, st_l[s][j][0], st_l[s][j][1], st_l[s][j][2]);
+        const float mu = cm, rstd = rsqrtf(cM2 / (float)a.d + 1e-5f);
+        const float g4[4] = {e0.x, e0.y, e0.z, e0.w}, c4[4] = {e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-            for (int s_ = 0; s_ < 8; ++s_) chan_merge(cn, cm, cM2, st_l[t][s_][j][0], st_l[t][s_][j][1], st_l[t][s_][j][2]);
-            const float mu = cm, rstd = rsqrtf(cM2 / (float)a.d + 1e-5f);
-            const float g4[4] = {e0.x, e0.y, e0.z, e0.w}, c4[4] = {e1[t].x, e1[t].y, e1[t].z, e1[t].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = fmaf(rstd, v[t][i] - mu * g4[i], c4[i]);
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(rstd, v[i] - mu * g4[i], c4[i]);
+    }
+    if constexpr (MODE == P32_QKV) {
+        if (valid && live_l) {
+            const int d = a.d;
+            if (n < d) *reinterpret_cast<float4*>(a.q + (size_t)gb * d + n) = float4{y[0], y[1], y[2], y[3]};
+            else {
+                int c = n - d;
+                f16* dst = a.self_k;
+                if (c >= d) { c -= d; dst = a.self_v; }
+                const int pos = min(max(pos_l, 0), kMaxTok - 1);
+                *reinterpret_cast<f16x4*>(dst + (((size_t)gb * a.n_head + (c >> 6)) * kMaxTok + pos) * kHeadDim + (c & 63)) =
+                    f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+            }
         }
-        if constexpr (MODE == P32_QKV) {
-            if (valid[t] && live_l[t]) {
-                const int d = a.d;
-                if (n < d) *reinterpret_cast<float4*>(a.q + (size_t)gb[t] * d + n) = float4{y[0], y[1], y[2], y[3]};
-                else {
-                    int c = n - d;
-                    f16* dst = a.self_k;
-                    if (c >= d) { c -= d; dst = a.self_v; }
-                    const int pos = min(max(pos_l[t], 0), kMaxTok - 1);
-                    *reinterpret_cast<f16x4*>(dst + (((size_t)gb[t] * a.n_head + (c >> 6)) * kMaxTok + pos) * kHeadDim + (c & 63)) =
-                        f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-                }
+    } else if constexpr (MODE == P32_Q) {
+        if (valid && live_l) *reinterpret_cast<float4*>(a.q + (size_t)gb * a.d + n) = float4{y[0], y[1], y[2], y[3]};
+    } else if constexpr (MODE == P32_FC1) {
+        if (valid) {      // hidden activations as an f16 hi | lo pair: rounding them to ONE f16 plane (round 2) was the largest single term
+            f16x4 hi, lo;  // of the decoder's logits error at 32 layers (1e-3 of the fp32 oracle; tests/test_gpu_fulldepth.py)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(gelu_erf(y[i]), h_, l_); hi[i] = h_; lo[i] = l_; }
+            const size_t o = plane_index(gb, n, a.N);
+            *reinterpret_cast<f16x4*>(a.h_out + o) = hi;
+            *reinterpret_cast<f16x4*>(a.h_out_lo + o) = lo;
+        }
+    } else if constexpr (MODE == P32_RESID) {
+        const float b4[4] = {e0.x, e0.y, e0.z, e0.w}, x4[4] = {e1.x, e1.y, e1.z, e1.w};
+        float xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[i] + b4[i]);
+        d32_resid_tail(xn, valid && live_l, bt, rt, n_rt, n, j, gb, tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out, xs);
+    } else {    // P32_LOGITS
+        if (r16) {      // reference-numerics switch: the TextDecoder output is a Float16 array (Core/Models.swift:1041)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (float)(f16)y[i];
+        }
+        if (a.logits && valid && live_l) {
+            float* lo = a.logits + (size_t)gb * a.N + n;
+            if (n + 3 < a.N) {
+                *reinterpret_cast<float2*>(lo) = float2{y[0], y[1]};
+                *reinterpret_cast<float2*>(lo + 2) = float2{y[2], y[3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n + i < a.N) lo[i] = y[i];
             }
-        } else if constexpr (MODE == P32_Q) {
-            if (valid[t] && live_l[t]) *reinterpret_cast<float4*>(a.q + (size_t)gb[t] * a.d + n) = float4{y[0], y[1], y[2], y[3]};
-        } else if constexpr (MODE == P32_FC1) {
-            if (valid[t]) {   // hidden activations as an f16 hi | lo pair: rounding them to ONE f16 plane (round 2) was the largest single term
-                f16x4 hi, lo; // of the decoder's logits error at 32 layers (1e-3 of the fp32 oracle; tests/test_gpu_fulldepth.py)
+        }
+        if (a.stats) {
+            // fused greedy sampler, part 1 (decoder.hip logits_block_stats): the index-predicate filters of LogitsFilter.swift on this
+            // thread's 4 ids, then (max, sum exp, argmax) separately for text and timestamp ids; the 8 threads of a slot meet in LDS
+            SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
+            const int blank = rules[0], ts_active = rules[1];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { f16 h_, l_; split_hilo(gelu_erf(y[i]), h_, l_); hi[i] = h_; lo[i] = l_; }
-                const size_t o = plane_index(gb[t], n, a.N);
-                *reinterpret_cast<f16x4*>(a.h_out + o) = hi;
-                *reinterpret_cast<f16x4*>(a.h_out_lo + o) = lo;
+            for (int i = 0; i < 4; ++i) {
+                const int id = n + i;
+                bool masked = ((masked4 >> (8 * i)) & 0xff) != 0 || id >= a.N;                                   // SuppressTokensFilter
+                masked |= blank && (id == ws_tok || id == eot_tok);                                               // SuppressBlankFilter
+                masked |= ts_active && (id == nots_tok || (id >= rules[2] && id < rules[3]) || (id >= rules[4] && id < rules[5]));   // TimestampRulesFilter
+                if (!masked) { if (id < tb) stat_merge(t, y[i], 1.0f, id); else stat_merge(u, y[i], 1.0f, id); }
             }
-        } else if constexpr (MODE == P32_RESID) {
-            const float b4[4] = {e0.x, e0.y, e0.z, e0.w}, x4[4] = {e1[t].x, e1[t].y, e1[t].z, e1[t].w};
-            float xn[4];
+            float* rec = xs_raw + (size_t)(sub * 32 + j) * 6;
+            rec[0] = t.m; rec[1] = t.s; rec[2] = __int_as_float(t.i); rec[3] = u.m; rec[4] = u.s; rec[5] = __int_as_float(u.i);
+            __syncthreads();
+            if (tid < 32 && valid && live_l) {
+                SoftStat T{-INFINITY, 0.0f, 0x7fffffff}, U{-INFINITY, 0.0f, 0x7fffffff};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[t][i] + b4[i]);
-            d32_resid_tail(xn, valid[t] && live_l[t], bt[t], rt, n_rt, n, j, gb[t], tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out, xs);
-        } else {    // P32_LOGITS
-            if (r16) {      // reference-numerics switch: the TextDecoder output is a Float16 array (Core/Models.swift:1041)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (float)(f16)y[i];
-            }
-            if (a.logits && valid[t] && live_l[t]) {
-                float* lo = a.logits + (size_t)gb[t] * a.N + n;
-                if (n + 3 < a.N) {
-                    *reinterpret_cast<float2*>(lo) = float2{y[0], y[1]};
-                    *reinterpret_cast<float2*>(lo + 2) = float2{y[2], y[3]};
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (n + i < a.N) lo[i] = y[i];
+                for (int s = 0; s < 8; ++s) {
+                    const float* r_ = xs_raw + (size_t)(s * 32 + tid) * 6;
+                    stat_merge(T, r_[0], r_[1], __float_as_int(r_[2]));
+                    stat_merge(U, r_[3], r_[4], __float_as_int(r_[5]));
                 }
-            }
-            if (a.stats) {
-                // fused greedy sampler, part 1 (decoder.hip logits_block_stats): the index-predicate filters of LogitsFilter.swift on this
-                // thread's 4 ids, then (max, sum exp, argmax) separately for text and timestamp ids; the 8 threads of a slot meet in LDS
-                SoftStat T_{-INFINITY, 0.0f, 0x7fffffff}, U_{-INFINITY, 0.0f, 0x7fffffff};
-                const int blank = rules[t][0], ts_active = rules[t][1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int id = n + i;
-                    bool masked = ((masked4 >> (8 * i)) & 0xff) != 0 || id >= a.N;                                   // SuppressTokensFilter
-                    masked |= blank && (id == ws_tok || id == eot_tok);                                               // SuppressBlankFilter
-                    masked |= ts_active && (id == nots_tok || (id >= rules[t][2] && id < rules[t][3]) || (id >= rules[t][4] && id < rules[t][5]));   // TimestampRulesFilter
-                    if (!masked) { if (id < tb) stat_merge(T_, y[i], 1.0f, id); else stat_merge(U_, y[i], 1.0f, id); }
-                }
-                float* rec = xs_raw[t] + (size_t)(sub * 32 + j) * 6;
-                rec[0] = T_.m; rec[1] = T_.s; rec[2] = __int_as_float(T_.i); rec[3] = U_.m; rec[4] = U_.s; rec[5] = __int_as_float(U_.i);
-                __syncthreads();
-                if (tid < 32 && valid[t] && live_l[t]) {
-                    SoftStat T{-INFINITY, 0.0f, 0x7fffffff}, U{-INFINITY, 0.0f, 0x7fffffff};
-#pragma unroll
-                    for (int s_ = 0; s_ < 8; ++s_) {
-                        const float* r_ = xs_raw[t] + (size_t)(s_ * 32 + tid) * 6;
-                        stat_merge(T, r_[0], r_[1], __float_as_int(r_[2]));
-                        stat_merge(U, r_[3], r_[4], __float_as_int(r_[5]));
-                    }
-                    float* o = a.stats + ((size_t)gb[t] * kStatBlocks + rt) * 8;
-                    *reinterpret_cast<float4*>(o) = float4{T.m, T.s, __int_as_float(T.i), U.m};
-                    *reinterpret_cast<float2*>(o + 4) = float2{U.s, __int_as_float(U.i)};
-                }
+                float* o = a.stats + ((size_t)gb * kStatBlocks + rt) * 8;
+                *reinterpret_cast<float4*>(o) = float4{T.m, T.s, __int_as_float(T.i), U.m};
+                *reinterpret_cast<float2*>(o + 4) = float2{U.s, __int_as_float(U.i)};
             }
         }
     }
@@ -492,35 +440,22 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
     return want;
 }
 
-template <int MODE, bool HILO, bool NTW, int NB>
+template <int MODE, bool HILO, bool NTW>
 static void launch_tc_w(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
     static const int tc_cap = env_int32("WH_D32_TC", 5);     // A/B knob: smaller chunks = fewer registers (TC 2: ~100) = room beside a cross-attention wave
-    if constexpr (NB == 1) {
-        // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
-        if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW, 1><<<grid, 256, 0, st>>>(a);
-        else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW, 1><<<grid, 256, 0, st>>>(a);
-        else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3, NTW, 1><<<grid, 256, 0, st>>>(a);
-        else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW, 1><<<grid, 256, 0, st>>>(a);
-        else dec32_proj_kernel<MODE, HILO, 1, NTW, 1><<<grid, 256, 0, st>>>(a);
-    } else {
-        // two batch tiles per workgroup: the planes of both tiles ride in every chunk, so chunks of <= 2 k-tiles (20 16-byte loads per lane in flight, double-buffered)
-        if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW, NB><<<grid, 256, 0, st>>>(a);
-        else dec32_proj_kernel<MODE, HILO, 1, NTW, NB><<<grid, 256, 0, st>>>(a);
-    }
-}
-// batch tiles per workgroup (kernel header, NB): 2 from two batch tiles on (33+ slots); WH_D32_NB=1 is the A/B side (one tile per workgroup, rounds 2 - 4)
-static int d32_nb(int n_bt) {
-    static const int nb = env_int32("WH_D32_NB", 2);
-    return (nb >= 2 && n_bt >= 2) ? 2 : 1;
+    // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
+    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3, NTW><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1, NTW><<<grid, 256, 0, st>>>(a);
 }
 template <int MODE, bool HILO>
-static void launch_tc(const P32Args& a, dim3 grid, int nb, hipStream_t st) {
-    static const int ntw = env_int32("WH_D32_NTW", -1);      // -1: nt when ONE workgroup reads a slab; 0 never; 1 always (the behaviour before round 4's last change)
-    const int readers = (a.n_bt + nb - 1) / nb;
-    const bool nt = ntw < 0 ? readers == 1 : ntw != 0;
-    if (nb == 2) { if (nt) launch_tc_w<MODE, HILO, true, 2>(a, grid, st); else launch_tc_w<MODE, HILO, false, 2>(a, grid, st); }
-    else { if (nt) launch_tc_w<MODE, HILO, true, 1>(a, grid, st); else launch_tc_w<MODE, HILO, false, 1>(a, grid, st); }
+static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
+    static const int ntw = env_int32("WH_D32_NTW", -1);      // -1: nt for a single batch tile only; 0 never; 1 always (the behaviour before round 4's last change)
+    const bool nt = ntw < 0 ? a.n_bt == 1 : ntw != 0;
+    if (nt) launch_tc_w<MODE, HILO, true>(a, grid, st); else launch_tc_w<MODE, HILO, false>(a, grid, st);
 }
 
 unsigned long long* debug_buffer();
@@ -532,17 +467,16 @@ void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) 
     a.tw = a.K / (64 * a.ks);
     a.n_bt = n_bt;
     const int nx = ((a.N + 31) / 32) * a.ks;
-    const int nb = d32_nb(n_bt), n_btg = (n_bt + nb - 1) / nb;
-    const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * n_btg));
+    const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * n_bt));
     ProfScope ps_(a.prof_kind, st);
     switch (mode) {
-        case P32_QKV: launch_tc<P32_QKV, true>(a, grid, nb, st); break;
-        case P32_Q: launch_tc<P32_Q, true>(a, grid, nb, st); break;
-        case P32_FC1: launch_tc<P32_FC1, true>(a, grid, nb, st); break;
-        case P32_LOGITS: launch_tc<P32_LOGITS, true>(a, grid, nb, st); break;
+        case P32_QKV: launch_tc<P32_QKV, true>(a, grid, st); break;
+        case P32_Q: launch_tc<P32_Q, true>(a, grid, st); break;
+        case P32_FC1: launch_tc<P32_FC1, true>(a, grid, st); break;
+        case P32_LOGITS: launch_tc<P32_LOGITS, true>(a, grid, st); break;
         default:
-            if (hilo) launch_tc<P32_RESID, true>(a, grid, nb, st);
-            else launch_tc<P32_RESID, false>(a, grid, nb, st);
+            if (hilo) launch_tc<P32_RESID, true>(a, grid, st);
+            else launch_tc<P32_RESID, false>(a, grid, st);
     }
 }
 

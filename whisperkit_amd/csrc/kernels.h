@@ -248,6 +248,7 @@ void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const fl
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
+constexpr int kMaxSessionSlots = 256;    // windows one session decodes in lock-step (eight 32-slot batch tiles of the decoder projections)
 constexpr int kXabsAutoMinSlots = 24;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides): measured large-v3,
                                         // one stream, ms per decoder step with fp32 K / V rows vs absorbed: 16 slots 3.60 / 3.91, 24 slots 4.31 / 4.00 (profiles/r05a_*)
 constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); a session uses Xabs::n_split of them, fixed at creation
