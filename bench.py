@@ -113,8 +113,9 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
     raise KeyError(kind)
 
 
-def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
-    """HIP-event timing of every kernel launch of one eager pass (mel, encoder, cross-K/V, n_meas decoder steps)."""
+def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name, steps_per_batch=1):
+    """HIP-event timing of every kernel launch of one eager pass (mel, encoder, cross-K/V, n_meas decoder steps) over one device batch of B
+    slots.  A device batch carries `steps_per_batch` bench steps: `launches_per_step` and everything derived from it is per bench step."""
     from whisperkit_amd import api
     lib = sess.lib
     nk = lib.wh_kernel_kind_count()
@@ -131,7 +132,7 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
             continue
         bound, amount = algorithmic_work(name, dims, B, avg_len, absorbed=absorbed, splits=splits)
         is_dec = name.startswith("dec_") or name == "sampler"
-        per_step = cnt[k] / n_meas * decode_steps if is_dec else cnt[k]      # launches in one full hot-path step
+        per_step = (cnt[k] / n_meas * decode_steps if is_dec else cnt[k]) / steps_per_batch      # launches per bench step (a launch over a device batch serves steps_per_batch steps)
         step_us[name] = avg[k] * per_step
         rate = amount / (avg[k] * 1e-6)
         if bound == "hbm":
@@ -160,7 +161,8 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name):
             "peak": HBM_PEAK_GBS if t["bound"] == "hbm" else MFMA_F16_PEAK_TF, "unit": t["unit"], "frac": t["frac"], "traffic": t["traffic"],
             "avg_us": t["avg_us"], "alg_per_launch": t["alg_per_launch"], "share_of_step_time": t["share_of_step"],
             "sum_kernel_ms_per_step": round(tot / 1e3, 3), "kernels": table,
-            "note": "eager launches, one HIP event pair per launch on the session stream (the pair itself adds ~2 us to short kernels: "
+            "note": f"one device batch = {B} slots = {steps_per_batch} bench step(s): launches_per_step, sum_kernel_ms_per_step and share_of_step are per bench step; "
+                    "eager launches, one HIP event pair per launch on the session stream (the pair itself adds ~2 us to short kernels: "
                     "fractions of the projection kernels are lower bounds); decoder kernels averaged over "
                     f"{n_meas} steps (positions 0..{n_meas - 1}) and weighted to {decode_steps} steps; traffic = HBM bytes per launch "
                     f"from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/{PMC_TRAFFIC_FILE}; FETCH_SIZE x2 "
@@ -183,13 +185,13 @@ def get_model(name, local_rank, keep_sd=False):
 
 def plan_batches(n_steps, F, G):
     """n_steps steps over F workers (sessions in flight) as device batches of at most G steps: every worker gets an equal share of the
-    steps (the first n_steps % F one more), cut into batches of G and one shorter remainder.  Returns [[steps per batch, ...] per worker]."""
+    steps (the first n_steps % F one more), cut into one shorter remainder batch (run first) and batches of G.  Returns [[steps per batch, ...] per worker]."""
     F = max(1, min(F, n_steps))
     plan = []
     for w in range(F):
         mine = n_steps // F + (1 if w < n_steps % F else 0)
-        plan.append([G] * (mine // G) + ([mine % G] if mine % G else []))
-    return plan
+        plan.append(([mine % G] if mine % G else []) + [G] * (mine // G))      # the short batch FIRST: the run ends on full batches (a 20-step run
+    return plan                                                                 # that ended on two single-step batches was 5 % slower over all, profiles/r05f_*)
 
 
 def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False,
@@ -351,7 +353,8 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                          "us_per_decoder_step": med[4] * 1e6 / max(r2[0].steps, 1)}
         log(f"{model_name}: stages {json.dumps({k: round(v, 3) for k, v in out['stages'].items()})}")
     if rank == 0 and want_roofline:
-        rf = out["roofline"] = measure_kernels(sess, dims, slots, 16, dec_steps[0], model_name)
+        rf = out["roofline"] = measure_kernels(sess, dims, slots, 16, dec_steps[0], model_name, steps_per_batch=G)
+        rf["steps_per_device_batch"] = G
         ns = sess.crossAttentionSplits
         if ns:
             # the cross-attention takes slots x splits workgroups, one per CU: with several sessions in flight it is configured to leave CUs to
@@ -365,7 +368,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                         s4.padOrTrim(x, k * n_local + b)
                 s4.logMelSpectrogram(slots); s4.encodeFeatures(slots); s4.prepareDecoderInputs(slots)
                 s4.decodeText(prompt, opts, batch=slots)          # (wh_measure_kernels re-arms the slot state the last decodeText left)
-                r4 = measure_kernels(s4, dims, slots, 16, dec_steps[0], model_name)
+                r4 = measure_kernels(s4, dims, slots, 16, dec_steps[0], model_name, steps_per_batch=G)
                 s4.close()
                 k4 = r4["kernels"]["dec_cross_attn"]
                 rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "workgroups": slots * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],

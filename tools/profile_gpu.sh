@@ -12,7 +12,7 @@ export WH_PMC_STEPS=16
 export WH_XABS_SPLITS=$XS
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $R
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --cross-attention-splits $XS > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --cross-attention-splits $XS > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?
 DB=$(ls /tmp/${TAG}_prof/*.db /tmp/${TAG}_prof/*/*.db 2>/dev/null | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats.csv 2> $R/${TAG}_summary.err; head -12 $R/${TAG}_kernel_stats.csv
 # the same command with ONE step in flight: the kernel's own duration (what bench.py's roofline leg times with HIP events on an otherwise

@@ -1,0 +1,6 @@
+#!/bin/bash
+# Round 5, final call A: the whole GPU suite, smoke(), the bench under the driver's command line
+cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp; R=gpurun_out; mkdir -p $R; T=r05f
+( timeout 1300 python -m pytest tests -m gpu -q 2>&1 | tail -40 ) > $R/${T}_pytest_gpu.log 2>&1; tail -n 3 $R/${T}_pytest_gpu.log
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > $R/${T}_smoke.log 2>&1; tail -n 2 $R/${T}_smoke.log
+( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/${T}_bench_steps20_warmup5.json ) 2> $R/${T}_bench.err; tail -n 3 $R/${T}_bench.err; cut -c1-700 $R/${T}_bench_steps20_warmup5.json
