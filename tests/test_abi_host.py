@@ -330,3 +330,25 @@ def test_swift_shim_source_names_the_session_entry_points_of_the_header():
     for fn in ("wh_session_create_tuned", "wh_session_set_window_hooks", "wh_xabs_auto_min_slots", "wh_session_cross_attention_mode",
                "wh_session_cross_attention_splits", "wh_session_step_graph_count"):
         assert fn in called, fn
+
+
+def test_round5_bench_line_bookkeeping_is_per_bench_step():
+    """The committed round-5 bench line (profiles/r05g_*): a 128-slot device batch carries two 64-chunk bench steps, so the decoder kernels' launches_per_step is
+    32 layers x 223 decoder steps / 2 = 3568 (the event pool used to overflow and report 6467 of 7136), launches x average duration of the dominant kernel
+    fits inside ms_per_step, the algorithmic bytes are the formula's, and the PMC pass of the same binary (profiles/r05_pmc_traffic.json) is not below them."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r05g_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    r, cfg = line["roofline"], line["config"]
+    assert cfg["device_batch_slots"] == 128 and cfg["steps_per_device_batch"] == 2 and r["steps_per_device_batch"] == 2
+    k = r["kernels"]["dec_cross_attn"]
+    assert k["launches_per_step"] == 32 * 223 / 2 and k["launches_measured"] == 32 * 16
+    dims = weights.MODEL_DIMS["large-v3"]
+    d, H, B = dims.n_text_state, dims.n_text_head, 128
+    assert r["alg_per_launch"] == B * 1500 * d * 2 + B * H * d * 4 + 1 * B * H * (d * 4 + 8) == 517_754_880
+    assert r["frac"] == pytest.approx(r["alg_per_launch"] / (r["avg_us"] * 1e-6) / 8e12, rel=1e-3)
+    assert k["launches_per_step"] * k["avg_us"] * 1e-3 <= line["ms_per_step"]                       # the dominant kernel fits inside the step it is a share of
+    assert r["whole_step"]["hbm_bound_algorithmic_bytes"] / (line["ms_per_step"] * 1e-3) <= 8e12 and r["whole_step_frac"] == r["whole_step"]["frac"]
+    assert r["whole_chip_frac"] == r["same_kernel_alone_on_the_whole_chip"]["frac"] and r["whole_chip_frac"] > r["frac"]
+    tj = json.load(open(os.path.join(root, "profiles", "r05_pmc_traffic.json")))
+    assert tj["chunks_per_step"] == 128 and tj["cross_attention_splits"] == 1
+    assert 1.0 <= tj["bytes_per_launch"]["dec_cross_attn"] / r["alg_per_launch"] <= 1.05
