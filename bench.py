@@ -96,8 +96,8 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
         # weight-absorbed form (csrc/xabs.hip): the slot's encoder output [1500][d] f16 ONCE, absorbed queries (f16 hi | lo) in,
         # every key split's unnormalised O' [H][d] f32 + (m, l) out
         return "hbm", B * T * d * 2 + B * H * d * 4 + splits * B * H * (d * 4 + 8)
-    if kind == "dec_cross_attn":  # 1500 K and V rows per slot (fp32 since round 5), q in, att planes out
-        return "hbm", B * 2 * T * d * 4 + 2 * act
+    if kind == "dec_cross_attn":  # 1500 K and V rows per slot (24-bit rows since round 5: Float16 + 8-bit residual), q in, att planes out
+        return "hbm", B * 2 * T * d * 3 + 2 * act
     if kind == "dec_xabs_qk":    # W_k^T tiles + q in, absorbed queries [H][d] per slot (f16 hi | lo) out
         return "hbm", d * d * 2 + act + B * H * d * 4
     if kind == "dec_xabs_vup":   # W_v tiles + the split partials in, att planes out
@@ -467,7 +467,7 @@ def long_audio_config(args, local_rank):
     out["note"] = ("10 min synthetic audio -> VADAudioChunker (30 s chunks, one device batch) -> decodeWithFallback with the ladder "
                    "forced once per window (T = 0 greedy, then 0.2 with the seeded top-5 sampler) -> segments")
     # (the library's choice at 100 slots: the absorbed cross-attention, which reads the audio's one encoder output with cacheable loads when
-    # slots share it - round 5, profiles/r05b_beam5_cross_attention_mode_ab.jsonl: 241 audio-s/s against 233 with fp32 K / V rows)
+    # slots share it - round 5, profiles/r05b_beam5_cross_attention_mode_ab.jsonl: 241 audio-s/s against 233 with fp32 K / V rows, the first round-5 form of the rows)
     beam = run(100, beamSize=5)
     beam["note"] = ("NO REFERENCE BEHAVIOUR: the same workload with beam = 5 for the T = 0 pass (20 windows x 5 beams = 100 decoder slots, "
                     "openai/whisper BeamSearchDecoder semantics, host-ranked candidates per step), then the same sampled fallback; the "

@@ -202,10 +202,10 @@ int wh_session_create(wh_model* m, int max_batch, wh_session** out);
 void wh_session_destroy(wh_session* s);
 int wh_session_max_batch(const wh_session* s);
 /* 1: the session's decoder attends over the encoder output directly (weight-absorbed cross-attention: encoder_output_embeds is the
-   decoder input in the reference too, Core/Models.swift:986-987), 0: per-layer cross K / V rows (fp32) are materialised by
+   decoder input in the reference too, Core/Models.swift:986-987), 0: per-layer cross K / V rows (24 bits per element: Float16 + an 8-bit residual) are materialised by
    wh_prepare_decoder_inputs.  Fixed at creation: automatic = absorbed when the width supports it (512 / 768 / 1024 / 1280) and
-   max_batch >= wh_xabs_auto_min_slots() (24; WH_XABS_MIN_SLOTS), or WH_XABS=0 / 1.  The choice is made from max_batch alone, so
-   Session(m, 23) and Session(m, 24) run different kernels: both modes meet the 1e-3 relative logits contract against the fp32
+   max_batch >= wh_xabs_auto_min_slots() (28; WH_XABS_MIN_SLOTS), or WH_XABS=0 / 1.  The choice is made from max_batch alone, so
+   Session(m, 27) and Session(m, 28) run different kernels: both modes meet the 1e-3 relative logits contract against the fp32
    model, bit-identity across batch sizes holds within a mode.  Mode 1 streams the encoder output once per SLOT: callers whose slots
    share encoder outputs (beam search: beam_size slots per audio) should ask for mode 0 (wh_session_create_with_mode), whose rows
    are shared through the L2.  Mode 1 reads the session's encoder output LIVE at every decoder step (mode 0 snapshots it into the K / V

@@ -271,9 +271,9 @@ def test_bench_work_formulas_reproduce_the_survey_figures():
         assert w("gemm_cross_kv", dims) == pytest.approx(ckv_flop, rel=0.02), model
     dims = weights.MODEL_DIMS["large-v3"]
     d, L_, V = dims.n_text_state, dims.n_text_layer, dims.n_vocab
-    # K and V of 1500 positions: SURVEY's 245.8 MB per token and sequence is the Float16 figure; the K / V-row mode keeps fp32 rows since round 5
-    # (twice the bytes: Float16 rows cost 7e-3 sigma of the logits, tests/test_gpu_realistic.py), the absorbed mode reads HALF of SURVEY's figure
-    assert L_ * (w("dec_cross_attn", dims) - 2 * d * 4) == pytest.approx(2 * 245.8e6, rel=0.001)
+    # K and V of 1500 positions: SURVEY's 245.8 MB per token and sequence is the Float16 figure; the K / V-row mode keeps 24-bit rows since round 5
+    # (1.5 x the bytes: Float16 rows cost 7e-3 sigma of the logits, tests/test_gpu_realistic.py), the absorbed mode reads HALF of SURVEY's figure
+    assert L_ * (w("dec_cross_attn", dims) - 2 * d * 4) == pytest.approx(1.5 * 245.8e6, rel=0.001)
     # decoder weights read per step, shared by the batch (MFMA path: every matrix exactly once, no folded product matrices)
     per_layer_w = (3 * d * d + d * d + d * d + d * d + 4 * d * d + 4 * d * d) * 2
     got = L_ * sum(w(k, dims, 1, 0.0) for k in ("dec_proj_qkv", "dec_proj_oproj", "dec_proj_cq", "dec_proj_coproj", "dec_proj_fc1", "dec_proj_fc2")) + \
@@ -333,11 +333,11 @@ def test_swift_shim_source_names_the_session_entry_points_of_the_header():
 
 
 def test_round5_bench_line_bookkeeping_is_per_bench_step():
-    """The committed round-5 bench line (profiles/r05g_*): a 128-slot device batch carries two 64-chunk bench steps, so the decoder kernels' launches_per_step is
+    """The committed round-5 bench line (profiles/r05i_*: the final binary): a 128-slot device batch carries two 64-chunk bench steps, so the decoder kernels' launches_per_step is
     32 layers x 223 decoder steps / 2 = 3568 (the event pool used to overflow and report 6467 of 7136), launches x average duration of the dominant kernel
     fits inside ms_per_step, the algorithmic bytes are the formula's, and the PMC pass of the same binary (profiles/r05_pmc_traffic.json) is not below them."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r05g_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(root, "profiles", "r05i_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
     r, cfg = line["roofline"], line["config"]
     assert cfg["device_batch_slots"] == 128 and cfg["steps_per_device_batch"] == 2 and r["steps_per_device_batch"] == 2
     k = r["kernels"]["dec_cross_attn"]
@@ -352,3 +352,4 @@ def test_round5_bench_line_bookkeeping_is_per_bench_step():
     tj = json.load(open(os.path.join(root, "profiles", "r05_pmc_traffic.json")))
     assert tj["chunks_per_step"] == 128 and tj["cross_attention_splits"] == 1
     assert 1.0 <= tj["bytes_per_launch"]["dec_cross_attn"] / r["alg_per_launch"] <= 1.05
+    assert r["traffic"] == tj["bytes_per_launch"]["dec_cross_attn"]                                   # the line carries the PMC figure of its own workload

@@ -1,7 +1,7 @@
 """Full-depth GPU parity on weights with the activation statistics of a trained model, in the cross-attention mode the LIBRARY picks for
 every BASELINE configuration (VERDICT r04 "next round" 1a / 1b / 1d):
 
-  * large-v3, 32 + 32 layers, 64 slots (configs[3]: the absorbed cross-attention, the library's choice from 24 slots)
+  * large-v3, 32 + 32 layers, 64 slots (configs[3]: the absorbed cross-attention, the library's choice from 28 slots)
   * small, 12 + 12, 8 slots, word-timestamp alignment rows (configs[2]: the library's choice, per-layer K / V rows) - and the same
     fixture with the absorbed path forced
   * tiny.en, 4 + 4, 1 slot (configs[1]: the library's choice; d = 384 has no absorbed kernel)
@@ -17,7 +17,8 @@ deviation, and writes everything to gpurun_out/r05_realistic_errors.json (commit
   * STAGE-ISOLATED (oracle decoder on the GPU's encoder output): <= 1e-3 sigma against the fp32 oracle (openai/whisper in fp32: keys
     and values never rounded) in EVERY shipped mode.  Round 4 met this on the absorbed path only: the K / V-row path stored the cross
     keys / values as Float16 and sat at 7.1e-3 sigma (the keys' rounding under a sharp softmax; the values' alone is 1.9e-3 sigma,
-    measured with the oracle on the CPU).  Since round 5 the rows are fp32 (csrc/gemm.hip EPI_CROSS_KV, csrc/decoder.hip).
+    measured with the oracle on the CPU).  Since round 5 the rows carry 19 mantissa bits in 3 bytes (a Float16 + an 8-bit residual,
+    csrc/kernels.h hr24; csrc/gemm.hip EPI_CROSS_KV writes them, csrc/decoder.hip reads them).
   * END TO END from PCM (the oracle's own fp64 mel + fp32 encoder): the encoder output is a Float16 tensor (the reference's
     AudioEncoderOutput type, Core/Models.swift:938) and a sharp cross-attention amplifies key errors by the score magnitude, so no
     Float16 encoder output can meet 1e-3 sigma here, the reference's included.  The floor is measured IN THIS TEST with the oracle alone:

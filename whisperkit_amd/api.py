@@ -447,9 +447,9 @@ class Session:
     """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
 
     def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None, crossAttentionSplits: Optional[int] = None):
-        """crossAttentionMode: None = the library's choice (absorbed from `xabsAutoMinSlots()` = 24 slots at the widths that support it: the
-        choice looks at maxBatch only, so Session(m, 23) and Session(m, 24) run different kernels; both meet the 1e-3 relative logits
-        contract), 0 = per-layer cross K / V rows (fp32), 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
+        """crossAttentionMode: None = the library's choice (absorbed from `xabsAutoMinSlots()` = 28 slots at the widths that support it: the
+        choice looks at maxBatch only, so Session(m, 27) and Session(m, 28) run different kernels; both meet the 1e-3 relative logits
+        contract), 0 = per-layer cross K / V rows (24-bit: Float16 + 8-bit residual), 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
         Beam search (decodeTextBeam, DecodingOptions.beamSize): ask for 0 - the absorbed kernel streams the encoder output once per slot,
         i.e. beamSize times per audio, while the K / V rows of an audio are shared by its beams.  Mode 1 reads the encoder output live
         at every decoder step: do not call encodeFeatures / setEncoderOutput between prepareDecoderInputs and the end of the decode.

@@ -436,7 +436,7 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
     DALLOC(s->hmlp, B * kCtx * 4 * d); DALLOC(s->enc16, B * kCtx * d); DALLOC(s->enc32, B * kCtx * d);
     // Cross-attention path, fixed per session: the absorbed form (xabs.hip) streams the encoder output instead of per-layer K / V rows;
     // it pays from about kXabsAutoMinSlots slots (three launches per layer instead of one, one workgroup per (slot, key split) and CU;
-    // profiles/r04*, r05*).  Both modes meet the 1e-3 relative logits contract against fp32 (the K / V rows are fp32 since round 5).
+    // profiles/r04*, r05*).  Both modes meet the 1e-3 relative logits contract against fp32 (the K / V rows carry 19 mantissa bits since round 5: kernels.h hr24).
     // WH_XABS=0 / 1 forces the choice (A/B, tests), WH_XABS_MIN_SLOTS moves the automatic threshold.
     {
         const char* e_ = getenv("WH_XABS");       // read per session: a process can hold sessions of both modes (tests, A/B)
@@ -458,7 +458,8 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
         s->xabs.part = c.take<float>(S * H * (d / 8) * B * 8);
         s->xabs.ml = c.take<float2>(S * H * B);
     } else {
-        DALLOC(s->cross_k, L * B * kCtx * d); DALLOC(s->cross_v, L * B * kCtx * d);
+        DALLOC(s->cross_k_hi, L * B * kCtx * d); DALLOC(s->cross_v_hi, L * B * kCtx * d);
+        DALLOC(s->cross_k_lo, L * B * kCtx * d); DALLOC(s->cross_v_lo, L * B * kCtx * d);
     }
     DALLOC(s->self_k, L * B * kMaxTok * d); DALLOC(s->self_v, L * B * kMaxTok * d);
     DALLOC(s->part, B * H * kMaxSplit * kPartStride); DALLOC(s->ticket, B * H);
@@ -502,7 +503,7 @@ extern "C" void wh_session_destroy(wh_session* s) {
     if (s->xabs_blob) hipFree(s->xabs_blob);
     if (s->align_tmp) hipFree(s->align_tmp);
     void* ptrs[] = {s->pcm, s->n_valid, s->logspec, s->maxkey, s->mel_t, s->mel_f32, s->h1, s->x, s->xn, s->q16, s->k16, s->vt16, s->att16,
-                    s->hmlp, s->enc16, s->enc32, s->cross_k, s->cross_v, s->self_k, s->self_v, s->part, s->ticket, s->logits,
+                    s->hmlp, s->enc16, s->enc32, s->cross_k_hi, s->cross_v_hi, s->cross_k_lo, s->cross_v_lo, s->self_k, s->self_v, s->part, s->ticket, s->logits,
                     s->align, s->align_mean, s->seq, s->cfg_dev, s->suppress_dev, s->sup_mask_dev, s->stats, s->tok_out_dev, s->lp_out_dev, s->scratch_logits,
                     s->beam_owner, s->beam_tok, s->beam_lp};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -670,7 +671,7 @@ DecodeBuffers decode_buffers(wh_session* s, int batch, int max_position) {
     db.self_owner = nullptr;
     db.batch = batch; db.max_batch = s->B; db.d = m->dims.n_text_state; db.n_head = m->dims.n_text_head; db.n_layer = m->dims.n_text_layer; db.n_vocab = m->dims.n_vocab;
     db.emb = m->emb; db.pos = m->dec_pos; db.layers_host = m->dec.data(); db.lnf_g = m->lnf_g; db.lnf_b = m->lnf_b;
-    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k = s->cross_k; db.cross_v = s->cross_v;
+    db.self_k = s->self_k; db.self_v = s->self_v; db.cross_k_hi = s->cross_k_hi; db.cross_v_hi = s->cross_v_hi; db.cross_k_lo = s->cross_k_lo; db.cross_v_lo = s->cross_v_lo;
     db.part = s->part; db.ticket = s->ticket; db.logits = s->logits; db.seq = s->seq;
     db.stats = s->stats; db.sup_mask = s->sup_mask_dev; db.fused_greedy = s->fused_greedy ? 1 : 0;
     db.align = s->align_enabled ? s->align : nullptr; db.align_slot = m->align_slot_dev; db.n_align = s->n_align_alloc;
@@ -729,7 +730,7 @@ extern "C" int wh_prepare_decoder_inputs(wh_session* s, int batch) {
     if (!s->use_xabs) {     // (the absorbed cross-attention reads the encoder output itself: no per-layer K / V projection)
         GemmArgs g{};
         g.A = s->enc16; g.W = m->ckv_w; g.bias = m->ckv_b; g.M = batch * kCtx; g.N = L * 2 * d; g.K = d; g.lda = d; g.a_rows_per_batch = g.M;
-        g.ldc = L * 2 * d; g.k32 = s->cross_k; g.v32 = s->cross_v; g.d_model = d; g.max_batch = s->B;
+        g.ldc = L * 2 * d; g.kv_k_hi = s->cross_k_hi; g.kv_v_hi = s->cross_v_hi; g.kv_k_lo = s->cross_k_lo; g.kv_v_lo = s->cross_v_lo; g.d_model = d; g.max_batch = s->B;
         g.prof_kind = KK_CROSS_KV;
         launch_gemm(EPI_CROSS_KV, g, s->st);
         WH_CHECK_LAUNCH();

@@ -76,7 +76,8 @@ struct AttnArgs {
     int cross_div;           // > 1: slot b attends over the cross K / V of slot b / cross_div (beams of one audio share one copy)
     const float* q;          // [B][d]
     const f16* self_k; const f16* self_v;     // layer base [Bmax][H][224][64]
-    const float* cross_k; const float* cross_v;   // layer base [Bmax][H][1500][64], fp32 (round 5: Float16 rows cost 7e-3 sigma under a sharp softmax)
+    const f16 *cross_k_hi, *cross_v_hi;       // layer base [Bmax][H][1500][64]: 24-bit rows (round 5: Float16 rows cost 7e-3 sigma under a sharp softmax) =
+    const signed char *cross_k_lo, *cross_v_lo;   //   a Float16 and a signed 8-bit residual in units of ulp(hi) / 256 per element (kernels.h, hr24)
     f16 *att_hi, *att_lo;    // attention output (before the out projection) as an f16 hi | lo pair in B-fragment plane order (decoder32.hip)
     float* part;             // [B][H][n_split][kPartStride]: (m, l, o[64]) of every key split, one 128-byte-aligned slot each
     int* ticket;             // [B][H] arrival counters (zero between launches)
@@ -101,13 +102,19 @@ __device__ __forceinline__ void store_att(const AttnArgs& a, int b, int n, float
     a.att_lo[o] = lo;
 }
 
-// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 channels, T = f16: the self-attention cache, T = float:
-// the cross-attention rows).  Thread layout: 8 lanes per key (8 channels each: 16 bytes of f16, 32 bytes of fp32), 32 keys per pass,
-// PASSES passes; all K and V rows of the block are in flight before the first use.  Returns this block's softmax statistics (m, l)
-// and leaves the unnormalised output o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional,
-// global) gets s_t.
+// One query against keys [t0, t0 + n) of a head-major K/V block (rows of 64 channels; T = f16: the self-attention cache, T = hr24: the
+// cross-attention rows, a Float16 plus an 8-bit residual per element = 19 mantissa bits in 3 bytes).  Thread layout: 8 lanes per key (8
+// channels each: 16 bytes of f16, + 8 bytes of residuals), 32 keys per pass, PASSES passes; all K and V rows of the block are in flight
+// before the first use.  Returns this block's softmax statistics (m, l) and leaves the unnormalised output
+// o[64] = sum_t exp(s_t - m) V[t] in o_out (LDS, valid for tid < 64).  raw_scores (optional, global) gets s_t.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <typename T> struct KvPiece { static constexpr int W = (int)sizeof(T) / 2; uint4 r[W]; };     // 8 channels of one row
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct KvSrc;
+template <> struct KvSrc<f16> { const f16* p; };
+template <> struct KvSrc<hr24> { const f16* hi; const signed char* lo; };
+template <typename T> struct KvPiece;                    // 8 channels of one row
+template <> struct KvPiece<f16> { uint4 h; };
+template <> struct KvPiece<hr24> { uint4 h; uint2 l; };
 template <bool NT>
 __device__ __forceinline__ uint4 load16(const void* p) {      // NT: non-temporal (streamed once per step)
     if constexpr (NT) {
@@ -115,37 +122,47 @@ __device__ __forceinline__ uint4 load16(const void* p) {      // NT: non-tempora
         return uint4{v[0], v[1], v[2], v[3]};
     } else return *reinterpret_cast<const uint4*>(p);
 }
-template <bool NT, typename T>
-__device__ __forceinline__ void load_kv8(const T* p, KvPiece<T>& o) {
-#pragma unroll
-    for (int w = 0; w < KvPiece<T>::W; ++w) o.r[w] = load16<NT>(reinterpret_cast<const unsigned char*>(p) + 16 * w);
+template <bool NT>
+__device__ __forceinline__ uint2 load8(const void* p) {
+    if constexpr (NT) {
+        const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+        return uint2{v[0], v[1]};
+    } else return *reinterpret_cast<const uint2*>(p);
 }
-template <typename T>
-__device__ __forceinline__ void kv8_to_float(const KvPiece<T>& k, float (&f)[8]) {
-    if constexpr (sizeof(T) == 2) {
-        const f16x8 h = *reinterpret_cast<const f16x8*>(&k.r[0]);
+template <bool NT>
+__device__ __forceinline__ void load_kv8(const KvSrc<f16>& s, size_t o, KvPiece<f16>& r) { r.h = load16<NT>(s.p + o); }
+template <bool NT>
+__device__ __forceinline__ void load_kv8(const KvSrc<hr24>& s, size_t o, KvPiece<hr24>& r) { r.h = load16<NT>(s.hi + o); r.l = load8<NT>(s.lo + o); }
+__device__ __forceinline__ void kv8_to_float(const KvPiece<f16>& k, float (&f)[8]) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(&k.h);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
-    } else {
-        f[0] = __uint_as_float(k.r[0].x); f[1] = __uint_as_float(k.r[0].y); f[2] = __uint_as_float(k.r[0].z); f[3] = __uint_as_float(k.r[0].w);
-        f[4] = __uint_as_float(k.r[1].x); f[5] = __uint_as_float(k.r[1].y); f[6] = __uint_as_float(k.r[1].z); f[7] = __uint_as_float(k.r[1].w);
+    for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+}
+__device__ __forceinline__ void kv8_to_float(const KvPiece<hr24>& k, float (&f)[8]) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(&k.h);
+    const unsigned hw[4] = {k.h.x, k.h.y, k.h.z, k.h.w}, lw[2] = {k.l.x, k.l.y};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned hb = (hw[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        const int lo = (int)(lw[j >> 2] << (24 - 8 * (j & 3))) >> 24;              // sign-extended byte j
+        f[j] = fmaf((float)lo, hr24_unit(hb), (float)h[j]);
     }
 }
 
 // attend_fetch: every K and V row of the block is requested before anything is used.  Rows past n_load are not skipped but
 // re-read row n_load - 1 (clamped address): straight-line loads, no exec-mask branches; attend_compute ignores them (key >= n).
 template <int PASSES, bool NT, typename T>
-__device__ __forceinline__ void attend_fetch(const T* __restrict__ kb, const T* __restrict__ vb, int n_load, KvPiece<T> (&kreg)[PASSES], KvPiece<T> (&vreg)[PASSES]) {
+__device__ __forceinline__ void attend_fetch(const KvSrc<T>& kb, const KvSrc<T>& vb, int n_load, KvPiece<T> (&kreg)[PASSES], KvPiece<T> (&vreg)[PASSES]) {
     const int part = threadIdx.x & 7, kg = threadIdx.x >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = min(kg + 32 * i, n_load - 1);
-        load_kv8<NT>(kb + (size_t)key * kHeadDim + part * 8, kreg[i]);
+        load_kv8<NT>(kb, (size_t)key * kHeadDim + part * 8, kreg[i]);
     }
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
         const int key = min(kg + 32 * i, n_load - 1);
-        load_kv8<NT>(vb + (size_t)key * kHeadDim + part * 8, vreg[i]);
+        load_kv8<NT>(vb, (size_t)key * kHeadDim + part * 8, vreg[i]);
     }
 }
 __device__ __forceinline__ void attend_load_q(const float* __restrict__ qg, float (&qv)[8]) {
@@ -214,19 +231,19 @@ __device__ __forceinline__ void attend_compute(const float (&qv)[8], KvPiece<T> 
 }
 
 template <int PASSES, bool NT, typename T, typename GetN, typename QFix>
-__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const T* __restrict__ kb, const T* __restrict__ vb, int n_load,
+__device__ __forceinline__ bool attend_block(const float* __restrict__ qg, const KvSrc<T>& kb, const KvSrc<T>& vb, int n_load,
                                              GetN get_n, QFix qfix, float* const* raw_pp, float* red /* [16] */, float* osum /* [4][64] */,
                                              float* o_out /* [64] */, float* m_out, float* l_out, unsigned long long* stamp = nullptr) {
     // n_load rows are FETCHED right away; how many of them count (n = get_n(), < 0: slot not live) is only looked at
     // afterwards, so the slot-state loads and the K/V stream share one memory round trip instead of two.
     KvPiece<T> kreg[PASSES], vreg[PASSES];
-    attend_fetch<PASSES, NT>(kb, vb, n_load, kreg, vreg);
+    attend_fetch<PASSES, NT, T>(kb, vb, n_load, kreg, vreg);
     float qv[8];
     attend_load_q(qg, qv);
     const int n = get_n();
     if (n < 0) return false;            // workgroup-uniform
     qfix(qv, threadIdx.x & 7);          // hook for a query fix-up (identity today)
-    attend_compute<PASSES>(qv, kreg, vreg, n, *raw_pp, red, osum, o_out, m_out, l_out, stamp);
+    attend_compute<PASSES, T>(qv, kreg, vreg, n, *raw_pp, red, osum, o_out, m_out, l_out, stamp);
     return true;
 }
 
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const AttnArgs a) {
     float* raw = nullptr;
     auto get_n = [&]() { return (s_act && !s_done) ? min(min(max(s_ti, 0), kMaxTok - 1) + 1, n_load) : -1; };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<PASSES, false>(a.q + (size_t)b * d + h * kHeadDim, a.self_k + base, a.self_v + base, n_load, get_n, qfix, &raw, red, osum, o_l, &m, &l))
+    if (!attend_block<PASSES, false, f16>(a.q + (size_t)b * d + h * kHeadDim, KvSrc<f16>{a.self_k + base}, KvSrc<f16>{a.self_v + base}, n_load, get_n, qfix, &raw, red, osum, o_l, &m, &l))
         return;
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
@@ -274,15 +291,15 @@ __global__ __launch_bounds__(256) void dec_self_attn_owner_kernel(const AttnArgs
     }
     KvPiece<f16> kreg[PASSES], vreg[PASSES];
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i) load_kv8<false>(a.self_k + off[i], kreg[i]);
+    for (int i = 0; i < PASSES; ++i) load_kv8<false>(KvSrc<f16>{a.self_k}, off[i], kreg[i]);
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i) load_kv8<false>(a.self_v + off[i], vreg[i]);
+    for (int i = 0; i < PASSES; ++i) load_kv8<false>(KvSrc<f16>{a.self_v}, off[i], vreg[i]);
     float qv[8];
     attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
     if (!(s_act && !s_done)) return;            // workgroup-uniform
     const int n = min(min(max(s_ti, 0), kMaxTok - 1) + 1, n_load);
     float m, l;
-    attend_compute<PASSES>(qv, kreg, vreg, n, nullptr, red, osum, o_l, &m, &l, nullptr);
+    attend_compute<PASSES, f16>(qv, kreg, vreg, n, nullptr, red, osum, o_l, &m, &l, nullptr);
     if (threadIdx.x < 64) store_att(a, b, h * kHeadDim + threadIdx.x, o_l[threadIdx.x] / l);
 }
 
@@ -346,7 +363,8 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         return n;
     };
     auto qfix = [](float (&)[8], int) {};
-    if (!attend_block<PASSES, NT>(a.q + (size_t)b * d + h * kHeadDim, a.cross_k + base, a.cross_v + base, n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
+    if (!attend_block<PASSES, NT, hr24>(a.q + (size_t)b * d + h * kHeadDim, KvSrc<hr24>{a.cross_k_hi + base, a.cross_k_lo + base}, KvSrc<hr24>{a.cross_v_hi + base, a.cross_v_lo + base},
+                                        n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
         return;
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
@@ -759,8 +777,8 @@ int cross_attn_splits(int batch, int n_head) {
     static const int forced = env_int("WH_XATT_PASSES", 0);     // tuning knob: 8 / 6 / 4 / 2
     // measured large-v3, 64 slots (profiles/r03a_*): 6 passes (8 splits, 70 registers, 7 waves per SIMD) 5.20 ms per decoder step against
     // 5.38 with 8 passes (6 splits, 87 registers); 1754 vs 1715 audio-s/s with three sessions in flight
-    // round 5: the rows are fp32 (32 bytes per lane and key), so a pass carries the bytes two Float16 passes carried: 4 passes at >= 12 heads
-    // hold what the round-3 choice of 8 did (64 KB in flight per workgroup), 2 passes below
+    // round 5: the rows are 24-bit (24 bytes per lane and key: a pass carries 1.5 x the bytes of a Float16 pass): 4 passes at >= 12 heads
+    // (48 KB in flight per workgroup; the round-3 choice of 6 Float16 passes held the same), 2 passes below
     int passes = forced ? forced : (n_head >= 12 ? 4 : 2);
     passes = passes > 6 ? 8 : passes > 4 ? 6 : passes > 2 ? 4 : 2;            // instantiated: 2 / 4 / 6 / 8 passes = 24 / 12 / 8 / 6 splits
     return (kCtx + passes * 32 - 1) / (passes * 32);
@@ -839,7 +857,8 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         AttnArgs at{};
         at.batch = B; at.d = d; at.n_head = H; at.layer = l; at.n_layer = L; at.n_split = S; at.q = D.q; at.cross_div = db.cross_div;
         at.self_k = a.self_k; at.self_v = a.self_v;
-        at.cross_k = db.cross_k + (size_t)l * cross_stride; at.cross_v = db.cross_v + (size_t)l * cross_stride;
+        at.cross_k_hi = db.cross_k_hi + (size_t)l * cross_stride; at.cross_k_lo = db.cross_k_lo + (size_t)l * cross_stride;
+        at.cross_v_hi = db.cross_v_hi + (size_t)l * cross_stride; at.cross_v_lo = db.cross_v_lo + (size_t)l * cross_stride;
         at.att_hi = D.zb_hi; at.att_lo = D.zb_lo; at.part = db.part; at.ticket = db.ticket; at.seq = db.seq;
         at.align = db.align; at.align_slot = db.align_slot; at.n_align = db.n_align; at.gate = db.xattn_gate;
         at.self_rows = db.self_rows; at.self_owner = db.self_owner;

@@ -76,8 +76,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
                         const int d = a.d_model, H = d >> 6;
                         const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
                         const int bb = m / kCtx, t = m - bb * kCtx;
-                        float* dst = kv ? a.v32 : a.k32;         // fp32 rows (round 5): Float16 keys under a sharp softmax cost 7e-3 sigma of the logits
-                        dst[((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63)] = x;
+                        const size_t o = ((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63);
+                        f16 hi_; signed char lo_;                // 24-bit rows (round 5, kernels.h hr24): Float16 keys under a sharp softmax cost 7e-3 sigma of the logits
+                        hr24_encode(x, hi_, lo_);
+                        (kv ? a.kv_v_hi : a.kv_k_hi)[o] = hi_;
+                        (kv ? a.kv_v_lo : a.kv_k_lo)[o] = lo_;
                     } else if constexpr (EPI == EPI_CONV1) {
                         int bb = m / a.rows_per_batch_out, t = m - bb * a.rows_per_batch_out;
                         a.out16[((size_t)bb * kFramesPad + t + 1) * a.ldc + n] = (f16)gelu_erf_fast(x);
@@ -132,8 +135,12 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
                 } else if constexpr (EPI == EPI_CROSS_KV) {
                     const int d = a.d_model, H = d >> 6;
                     const int l = n / (2 * d), rem = n - l * 2 * d, kv = rem >= d, hc = rem - kv * d;
-                    float* dst = (kv ? a.v32 : a.k32) + ((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63);
-                    *reinterpret_cast<float4*>(dst) = float4{v0, v1, v2, v3};
+                    const size_t o = ((((size_t)l * a.max_batch + bb) * H + (hc >> 6)) * kCtx + t) * kHeadDim + (hc & 63);
+                    f16x4 hi4; char4 lo4;
+                    { f16 h_; signed char l_; hr24_encode(v0, h_, l_); hi4[0] = h_; lo4.x = l_; hr24_encode(v1, h_, l_); hi4[1] = h_; lo4.y = l_;
+                      hr24_encode(v2, h_, l_); hi4[2] = h_; lo4.z = l_; hr24_encode(v3, h_, l_); hi4[3] = h_; lo4.w = l_; }
+                    *reinterpret_cast<f16x4*>((kv ? a.kv_v_hi : a.kv_k_hi) + o) = hi4;
+                    *reinterpret_cast<char4*>((kv ? a.kv_v_lo : a.kv_k_lo) + o) = lo4;
                 } else if constexpr (EPI == EPI_CONV1) {
                     *reinterpret_cast<f16x4*>(a.out16 + ((size_t)bb * kFramesPad + t + 1) * a.ldc + n) =
                         f16x4{(f16)gelu_erf_fast(v0), (f16)gelu_erf_fast(v1), (f16)gelu_erf_fast(v2), (f16)gelu_erf_fast(v3)};

@@ -72,7 +72,8 @@ struct wh_session {
     f16* h1 = nullptr; float* x = nullptr; f16* xn = nullptr; f16 *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *att16 = nullptr;
     f16* hmlp = nullptr; f16* enc16 = nullptr; float* enc32 = nullptr;
     // decoder
-    float *cross_k = nullptr, *cross_v = nullptr;   // K / V-row mode: fp32 rows
+    f16 *cross_k_hi = nullptr, *cross_v_hi = nullptr;               // K / V-row mode: 24-bit rows (kernels.h hr24), Float16 part ...
+    signed char *cross_k_lo = nullptr, *cross_v_lo = nullptr;       // ... and 8-bit residuals
     f16 *self_k = nullptr, *self_v = nullptr;
     float *part = nullptr, *logits = nullptr;
     int* ticket = nullptr;

@@ -25,6 +25,32 @@ struct PerDeviceOnce {
     }
 };
 
+// ---------------------------------------------------------------------------------------------- 24-bit rows (hr24)
+// The cross-attention key / value rows of the K / V-row mode: x ~ hi + lo * ulp(hi) / 256 with hi = Float16(x) and lo a signed byte - 19 mantissa
+// bits in 3 bytes.  Float16 rows cost 7.1e-3 sigma of the logits under a sharp softmax (keys) and 1.9e-3 sigma (values); fp32 rows (the first
+// round-5 form) cost twice the stream; this keeps the error below 1e-5 sigma at 1.5 x the Float16 bytes.
+struct hr24 {};
+__host__ __device__ __forceinline__ float hr24_unit(unsigned hi_bits) {      // ulp(hi) / 256 = 2^(e - 33), e = the biased exponent (subnormals: e = 1)
+    unsigned e = (hi_bits >> 10) & 31u;
+    e = e < 1u ? 1u : e;
+    const unsigned bits = (e + 94u) << 23;
+    float f;
+    __builtin_memcpy(&f, &bits, 4);
+    return f;
+}
+__device__ __forceinline__ void hr24_encode(float x, f16& hi, signed char& lo) {
+    hi = (f16)x;
+    unsigned short hb;
+    __builtin_memcpy(&hb, &hi, 2);
+    unsigned e = ((unsigned)hb >> 10) & 31u;
+    e = e < 1u ? 1u : e;
+    const unsigned ibits = (160u - e) << 23;          // 2^(33 - e) = 1 / hr24_unit
+    float inv;
+    __builtin_memcpy(&inv, &ibits, 4);
+    const float r = rintf((x - (float)hi) * inv);     // |x - hi| <= ulp / 2  ->  |r| <= 128
+    lo = (signed char)(int)fminf(fmaxf(r, -128.0f), 127.0f);
+}
+
 // ---------------------------------------------------------------------------------------------- measurement
 // Every kernel launch of the hot path is tagged with a kind; when a KernelProfiler is armed on the calling thread
 // (wh_measure_kernels) each launch is bracketed by a HIP event pair on the launch stream.
@@ -75,7 +101,7 @@ enum GemmEpi {
     EPI_CONV1 = 4,      // out16[(b*3002 + t + 1)*ldc + n] = gelu(v)  (padded time-major input of conv2)
     EPI_CONV2 = 5,      // x32[m*ldc + n] = gelu(v) + pos[t*ldc + n]
     EPI_F32 = 6,        // out32[m*ldc + n] = v
-    EPI_CROSS_KV = 7,   // n = l*2d + kv*d + h*64 + c, m = b*1500 + t -> (kv ? v32 : k32)[(((l*Bmax + b)*H + h)*1500 + t)*64 + c]  (fp32 rows)
+    EPI_CROSS_KV = 7,   // n = l*2d + kv*d + h*64 + c, m = b*1500 + t -> (kv ? V : K) hi / lo [(((l*Bmax + b)*H + h)*1500 + t)*64 + c]  (24-bit rows, hr24)
 };
 
 struct GemmArgs {
@@ -97,8 +123,8 @@ struct GemmArgs {
     const float* pos;
     int rows_per_batch_out;    // 3000 (conv1) / 1500 (conv2, qkv)
     int max_batch = 0;         // EPI_CROSS_KV: slot stride of the head-major cross K/V layout
-    float* k32 = nullptr;      // EPI_CROSS_KV: the fp32 cross-attention key / value rows
-    float* v32 = nullptr;
+    f16 *kv_k_hi = nullptr, *kv_v_hi = nullptr;              // EPI_CROSS_KV: the cross-attention key / value rows as hr24 (below): Float16 part ...
+    signed char *kv_k_lo = nullptr, *kv_v_lo = nullptr;      // ... and the 8-bit residuals
     int prof_kind = -1;        // KernelKind of this launch (measurement only)
 };
 
@@ -165,8 +191,8 @@ struct DecodeBuffers {
     const float *lnf_g, *lnf_b;
     f16* self_k;             // [L][Bmax][H][224][64]  head-major self-attention cache
     f16* self_v;
-    const float* cross_k;    // [L][Bmax][H][1500][64] head-major cross-attention K / V rows, fp32 (written by the cross-K/V GEMM epilogue;
-    const float* cross_v;    //  K / V-row mode only)
+    const f16 *cross_k_hi, *cross_v_hi;           // [L][Bmax][H][1500][64] head-major cross-attention K / V rows in 24 bits per element (hr24: Float16 +
+    const signed char *cross_k_lo, *cross_v_lo;   //  8-bit residual), written by the cross-K/V GEMM epilogue; K / V-row mode only
     float* x;                // [n_bt*32][d] residual stream (= d32->x)
     float* q;                // [n_bt*32][d] f32 query (= d32->q)
     float* part;             // [B][H][kMaxSplit][kPartStride] cross-attention split partials
@@ -249,8 +275,9 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
 constexpr int kMaxSessionSlots = 256;    // windows one session decodes in lock-step (eight 32-slot batch tiles of the decoder projections)
-constexpr int kXabsAutoMinSlots = 24;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides): measured large-v3,
-                                        // one stream, ms per decoder step with fp32 K / V rows vs absorbed: 16 slots 3.60 / 3.91, 24 slots 4.31 / 4.00 (profiles/r05a_*)
+constexpr int kXabsAutoMinSlots = 28;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides): measured large-v3,
+                                        // one stream, ms per decoder step with 24-bit K / V rows vs absorbed (4 splits): 16 slots 3.27 / 3.91, 24 slots 3.88 / 4.00, 28 slots
+                                        // 4.17 / 4.05, 32 slots 4.40 / 4.09 (profiles/r05h_*, r05a_*)
 constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); a session uses Xabs::n_split of them, fixed at creation
 // key splits of a session: one workgroup per (slot, split) owns a whole CU (LDS, registers), so slots x splits is the number of CUs the
 // kernel takes.  WH_XABS_SPLITS overrides (A/B).
