@@ -492,7 +492,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="30 s chunks per step (one decode batch = batch / 32 MFMA batch tiles): in total over the GPUs "
                     "with --scaling strong (BASELINE configs[3]: 64 chunks sharded across the GPUs), per GPU with --scaling weak")
     ap.add_argument("--device-batch", type=int, default=-1, help="slots of one device batch: the rank's shares of consecutive steps are packed into batches of "
-                    "at most this many chunks (continuous batching; one session holds at most 128).  -1 = automatic: 128 when a step has >= 64 chunks (two "
+                    "at most this many chunks (continuous batching; one session holds at most 256 windows, no gain was measured beyond 128).  -1 = automatic: 128 when a step has >= 64 chunks (two "
                     "64-chunk steps per batch at one GPU: the decoder's weight stream is shared by four batch tiles), else --batch (one step per batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: strong = --batch chunks per step in total, block-partitioned "
                     "over the ranks (SURVEY 8d c4; the default); weak = --batch chunks per step and GPU")

@@ -198,7 +198,7 @@ int wh_special_tokens_default(const wh_model* m, wh_special_tokens* out); /* ids
 void wh_decoding_options_default(wh_decoding_options* out);  /* DecodingOptions() defaults */
 
 /* ---- session: prepareDecoderInputs (Core/TextDecoder.swift:109-161) ------------------------------ */
-int wh_session_create(wh_model* m, int max_batch, wh_session** out);
+int wh_session_create(wh_model* m, int max_batch /* 1 .. 256 windows decoded in lock-step */, wh_session** out);
 void wh_session_destroy(wh_session* s);
 int wh_session_max_batch(const wh_session* s);
 /* 1: the session's decoder attends over the encoder output directly (weight-absorbed cross-attention: encoder_output_embeds is the
