@@ -221,8 +221,13 @@ static int build_xabs(wh_model* m) {
         p = c.take<f16>(d * d); dec32_tile_weights(wv, (int)d, (int)d, p, st); tiles[l].wv_t = p;
         tiles[l].bv = m->ckv_b + l * 2 * d + d;
     }
-    WH_CHECK_LAUNCH();
-    WH_HIP(hipDeviceSynchronize());
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipDeviceSynchronize();
+    if (le != hipSuccess) {         // nothing half-built stays behind: the next absorbed session tries again
+        hipFree(m->xabs_blob);
+        m->xabs_blob = nullptr;
+        return set_error(WH_ERR_HIP, "building the absorbed cross-attention weights failed: %s", hipGetErrorString(le));
+    }
     m->xabs.swap(tiles);          // published complete: sessions only read it after their own build_xabs call returned
     return WH_OK;
 }
