@@ -100,8 +100,6 @@ def algorithmic_work(kind: str, dims, B: int, avg_len: float, fused_sampler: boo
         return "hbm", B * 2 * T * d * 3 + 2 * act
     if kind == "dec_xabs_qk":    # W_k^T tiles + q in, absorbed queries [H][d] per slot (f16 hi | lo) out
         return "hbm", d * d * 2 + act + B * H * d * 4
-    if kind == "dec_cq_xqk":     # cross query + absorbed queries in one launch (WH_XABS_FUSE_QK): W_cq + planes in, W_k^T tiles in, Q' (f16 hi | lo) out
-        return "hbm", 2 * d * d * 2 + act + B * H * d * 4
     if kind == "dec_xabs_vup":   # W_v tiles + the split partials in, att planes out
         return "hbm", d * d * 2 + splits * B * H * (d * 4 + 8) + act
     if kind == "dec_proj_fc1":   # W[4d][d] + planes in, hidden hi|lo plane pair out

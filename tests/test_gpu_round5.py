@@ -192,46 +192,3 @@ def test_a_session_of_200_slots_decodes_every_slot_like_a_lone_session():
         one.close()
     big.close(); model.close()
 
-
-_FUSE = r"""
-import hashlib, sys
-sys.path.insert(0, %r)
-import numpy as np
-from whisperkit_amd import api, weights
-from whisperkit_amd.synth import synthetic_chunk
-out = []
-for name, B in (("test-large-v3-l2", 70), ("test-small-l2", 33)):
-    dims = weights.MODEL_DIMS[name]
-    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=11))
-    sess = api.Session(model, B, crossAttentionMode=1)
-    for b in range(B):
-        sess.padOrTrim(synthetic_chunk(4000 + 17 * b), b)
-    sess.logMelSpectrogram(B); sess.encodeFeatures(B); sess.prepareDecoderInputs(B)
-    h = hashlib.md5()
-    for t, p in ((50258, 0), (50259, 1), (50359, 2), (1029, 3), (400, 150), (77, 222)):
-        h.update(np.ascontiguousarray(sess.predictLogits([t] * B, [p] * B)).tobytes())
-    opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
-                               temperatureFallbackCount=0, sampleLength=20)
-    sess.prepareDecoderInputs(B)
-    res = sess.decodeText(sess.prefillPrompt(opts), opts, batch=B)
-    for r in res:
-        h.update(np.asarray(r.tokens, np.int32).tobytes()); h.update(np.asarray(r.tokenLogProbs, np.float32).tobytes())
-    out.append(h.hexdigest())
-    sess.close(); model.close()
-print("MD5", " ".join(out), flush=True)
-"""
-
-
-def test_fused_cross_query_and_absorbed_query_launch_is_bit_identical(tmp_path):
-    """WH_XABS_FUSE_QK=1 (csrc/decoder32.hip dec32_cq_xqk_kernel): the cross-query projection and xabs_qk as one launch must give the SAME BITS as
-    the two launches - teacher-forced logits of every slot over six positions and the greedy tokens / log-probs, at 20 heads (two head
-    tiles, 70 slots = three batch tiles) and at 12 heads (one head tile, 33 slots)."""
-    script = tmp_path / "fuse.py"
-    script.write_text(_FUSE % ROOT)
-    got = {}
-    for flag in ("0", "1"):
-        env = dict(os.environ, PYTHONPATH=ROOT, WH_XABS_FUSE_QK=flag)
-        p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-        got[flag] = [l for l in p.stdout.splitlines() if l.startswith("MD5")][-1]
-    assert got["0"] == got["1"], got

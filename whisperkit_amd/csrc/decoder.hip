@@ -870,8 +870,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a = base;               // LN2 (folded) + cross-attention query
         a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
         a.gate = db.xabs ? nullptr : db.xattn_gate;
-        const bool fuse_qk = db.xabs && dec32_fuse_qk();
-        if (!fuse_qk) launch_dec32_proj(P32_Q, a, n_bt, st);
+        launch_dec32_proj(P32_Q, a, n_bt, st);
         if (db.xabs) {          // weight-absorbed cross-attention over the encoder output (xabs.hip): no per-layer K / V rows
             const Xabs& X = *db.xabs;
             XabsArgs xa{};
@@ -881,8 +880,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             xa.align = db.align; xa.align_slot = db.align_slot; xa.n_align = db.n_align; xa.seq = db.seq; xa.kpart = D.part; xa.ticket = D.ticket;
             xa.gate = db.xattn_gate;
             xa.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
-            if (fuse_qk) launch_dec32_cq_xqk(a, xa, n_bt, st);      // cross query + absorbed queries in one launch (decoder32.hip)
-            else launch_xabs_qk(xa, n_bt, st);
+            launch_xabs_qk(xa, n_bt, st);
             launch_xabs_attn(xa, st);
             launch_xabs_vup(xa, n_bt, st);
         } else {

@@ -28,10 +28,7 @@
 
 namespace wh {
 
-static int env_int32(const char* name, int dflt);
-
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef f16 f16x2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------- model-load helpers
 __global__ void d32_tile_weights_kernel(const f16* __restrict__ W, int N, int K, u32x4* __restrict__ out, size_t n_out) {
@@ -395,207 +392,11 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }    // dec_shared.h
 }
 
-// ---------------------------------------------------------------------------------------------- cross query + absorbed query, one launch
-// Round 5 (WH_XABS_FUSE_QK): the cross-query projection (dec32_proj<P32_Q>) and xabs_qk (xabs.hip) as ONE kernel - a workgroup owns a whole
-// HEAD of a batch tile: phase 1 is dec32_proj's arithmetic for the head's two 32-row tiles of W_cq (the same k-tile split over the four
-// waves, the same reduction order, the same LayerNorm fold), q_h stays in LDS; phase 2 is xabs_qk's arithmetic (Q'_h = W_k,h^T q_h, the same
-// MFMA sequence per 32-channel tile, the same hi | lo packing and stores) with the d / 32 channel tiles of the head dealt to the four waves.
-// Per slot both phases compute exactly what the two launches computed: Q' is bit-identical, one kernel boundary, one entry latency and the
-// global round trip of q are gone.  grid = heads x batch tiles (ids x + 8 t: the batch tiles of a head on one XCD).
-template <int NHT, int TC, bool NTW>
-__global__ __launch_bounds__(256, 2) void dec32_cq_xqk_kernel(const P32Args a, const XabsArgs xa) {
-    __shared__ float red[2][4][16][64];
-    __shared__ float st_l[8][32][3];
-    __shared__ float qs[32][68];                      // q_h of the tile's 32 slots (64 channels + pad)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = a.n_head, d = a.d;
-    const int grp8 = blockIdx.x / (8 * a.n_bt), in8 = blockIdx.x % (8 * a.n_bt);
-    const int h = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
-    if (h >= H) return;
-    const int KT = a.K >> 4;
-    const int kt0 = wave * a.tw;
-    const u32x4* wp0 = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)(2 * h) * KT + kt0) * 64 + lane;
-    const u32x4* wp1 = wp0 + (size_t)KT * 64;
-    const size_t zoff = ((size_t)bt * KT + kt0) * 64 + lane;
-    const u32x4* hp = reinterpret_cast<const u32x4*>(a.zhi) + zoff;
-    const u32x4* lp = reinterpret_cast<const u32x4*>(a.zlo) + zoff;
-    const int j = tid & 31, sub = tid >> 5;
-    const int gb = bt * 32 + j;
-    // ---- epilogue operands of phase 1 first (they arrive under the weight stream)
-    float2 sp[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int idx = min(sub + 8 * i, a.n_stat - 1);
-        sp[i] = a.stat_in[((size_t)bt * a.n_stat + idx) * 32 + j];
-    }
-    float4 fg[2], fc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = (2 * h + t) * 32 + 4 * sub;
-        fg[t] = *reinterpret_cast<const float4*>(a.fold_g + n);
-        fc[t] = *reinterpret_cast<const float4*>(a.fold_c + n);
-    }
-    // ---- phase 1: the head's two row tiles of W_cq x the batch tile's planes
-    f32x16 acc_h[2], acc_l[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_h[t][r] = 0.0f; acc_l[t][r] = 0.0f; }
-    {
-        u32x4 w0a[TC], w1a[TC], ha[TC], la[TC], w0b[TC], w1b[TC], hb[TC], lb[TC];
-        auto ld = [&](u32x4 (&w0)[TC], u32x4 (&w1)[TC], u32x4 (&hh)[TC], u32x4 (&ll)[TC], int c) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-                w0[i] = NTW ? __builtin_nontemporal_load(wp0 + (size_t)(c * TC + i) * 64) : wp0[(size_t)(c * TC + i) * 64];
-                w1[i] = NTW ? __builtin_nontemporal_load(wp1 + (size_t)(c * TC + i) * 64) : wp1[(size_t)(c * TC + i) * 64];
-            }
-#pragma unroll
-            for (int i = 0; i < TC; ++i) { hh[i] = hp[(size_t)(c * TC + i) * 64]; ll[i] = lp[(size_t)(c * TC + i) * 64]; }
-        };
-        auto mm = [&](const u32x4 (&w0)[TC], const u32x4 (&w1)[TC], const u32x4 (&hh)[TC], const u32x4 (&ll)[TC]) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-                const f16x8 zh = __builtin_bit_cast(f16x8, hh[i]), zl = __builtin_bit_cast(f16x8, ll[i]);
-                const f16x8 f0 = __builtin_bit_cast(f16x8, w0[i]), f1 = __builtin_bit_cast(f16x8, w1[i]);
-                acc_h[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, zh, acc_h[0], 0, 0, 0);
-                acc_l[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, zl, acc_l[0], 0, 0, 0);
-                acc_h[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, zh, acc_h[1], 0, 0, 0);
-                acc_l[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, zl, acc_l[1], 0, 0, 0);
-            }
-        };
-        const int nch = a.tw / TC;
-        ld(w0a, w1a, ha, la, 0);
-#pragma unroll 1
-        for (int c = 0; c < nch; c += 2) {
-            if (c + 1 < nch) ld(w0b, w1b, hb, lb, c + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(w0a, w1a, ha, la);
-            if (c + 2 < nch) ld(w0a, w1a, ha, la, c + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < nch) mm(w0b, w1b, hb, lb);
-        }
-    }
-    // phase 2's first weight tiles are requested now: they arrive under phase 1's reduction and epilogue
-    const int RT = d >> 5, RTW = RT >> 2;              // 32-channel tiles of Q'_h; per wave
-    const u32x4* kp = reinterpret_cast<const u32x4*>(xa.wkT) + ((size_t)(h * RT + wave * RTW) * 4) * 64 + lane;
-    u32x4 wka[4], wkb[4];      // ping-pong tile sets of phase 2 (static names: a runtime-indexed register array would go to scratch)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) wka[kt] = kp[kt * 64];
-    {   // LayerNorm statistics of the slot (dec32_proj_kernel: stats_to_lds)
-        float cm = sp[0].x, cM2 = sp[0].y;
-        const int mine = sub < a.n_stat ? (a.n_stat - sub + 7) >> 3 : 0;
-        if (mine > 1) chan32_k<1>(cm, cM2, sp[1].x, sp[1].y);
-        if (mine > 2) chan32_k<2>(cm, cM2, sp[2].x, sp[2].y);
-        if (mine > 3) chan32_k<3>(cm, cM2, sp[3].x, sp[3].y);
-        if (mine > 4) chan32_k<4>(cm, cM2, sp[4].x, sp[4].y);
-        st_l[sub][j][0] = 32.0f * (float)mine; st_l[sub][j][1] = cm; st_l[sub][j][2] = cM2;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[t][wave][r][lane] = fmaf(acc_l[t][r], 1.0f / 2048.0f, acc_h[t][r]);
-    __syncthreads();
-    {
-        float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
-#pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) chan_merge(cn, cm, cM2, st_l[s_][j][0], st_l[s_][j][1], st_l[s_][j][2]);
-        const float mu = cm, rstd = rsqrtf(cM2 / (float)d + 1e-5f);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float g4[4] = {fg[t].x, fg[t].y, fg[t].z, fg[t].w}, c4[4] = {fc[t].x, fc[t].y, fc[t].z, fc[t].w};
-            float y[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = ((red[t][0][4 * wave + i][lane] + red[t][1][4 * wave + i][lane]) + red[t][2][4 * wave + i][lane]) + red[t][3][4 * wave + i][lane];
-                y[i] = fmaf(rstd, v - mu * g4[i], c4[i]);
-            }
-            *reinterpret_cast<float4*>(&qs[j][t * 32 + 4 * sub]) = float4{y[0], y[1], y[2], y[3]};
-        }
-    }
-    __syncthreads();
-    // ---- phase 2 (xabs_qk_kernel): q_h as B fragments (K = 16 channels x N = 32 slots), hi | lo
-    const int hl = lane >> 5;
-    f16x8 qh[4], ql[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const float4 v0 = *reinterpret_cast<const float4*>(&qs[j][kt * 16 + hl * 8]);
-        const float4 v1 = *reinterpret_cast<const float4*>(&qs[j][kt * 16 + hl * 8 + 4]);
-        const float z[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { f16 h_, l_; split_hilo(z[i], h_, l_); qh[kt][i] = h_; ql[kt][i] = l_; }
-    }
-    auto tile = [&](const u32x4 (&w)[4], int rt) {
-        f32x16 ah = {0}, al = {0};
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const f16x8 wf = __builtin_bit_cast(f16x8, w[kt]);
-            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, qh[kt], ah, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, ql[kt], al, 0, 0, 0);
-        }
-        unsigned ph[4][2], pl[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16 zh[4], zl[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) split_hilo(fmaf(al[4 * g + i], 1.0f / 2048.0f, ah[4 * g + i]), zh[i], zl[i]);
-            ph[g][0] = __builtin_bit_cast(unsigned, f16x2_t{zh[0], zh[1]});
-            ph[g][1] = __builtin_bit_cast(unsigned, f16x2_t{zh[2], zh[3]});
-            pl[g][0] = __builtin_bit_cast(unsigned, f16x2_t{zl[0], zl[1]});
-            pl[g][1] = __builtin_bit_cast(unsigned, f16x2_t{zl[2], zl[3]});
-        }
-        u32x4 oh[2], ol[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                auto sh = __builtin_amdgcn_permlane32_swap(ph[u][i], ph[u + 2][i], false, false);
-                auto sl = __builtin_amdgcn_permlane32_swap(pl[u][i], pl[u + 2][i], false, false);
-                oh[u][i] = sh[0]; oh[u][2 + i] = sh[1];
-                ol[u][i] = sl[0]; ol[u][2 + i] = sl[1];
-            }
-        }
-        if (gb < a.batch) {
-            const size_t o = ((size_t)gb * (NHT * 16) + h) * d + rt * 32 + 16 * hl;
-            f16* lo_dst = h < 16 ? xa.qf_lo + o : xa.qf_hi + o + (size_t)8 * d;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                *reinterpret_cast<u32x4*>(xa.qf_hi + o + 8 * u) = oh[u];
-                *reinterpret_cast<u32x4*>(lo_dst + 8 * u) = ol[u];
-            }
-        }
-    };
-#pragma unroll 1
-    for (int s_ = 0; s_ < RTW; s_ += 2) {          // (RTW = d / 128 is even at every supported width)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) wkb[kt] = kp[((size_t)(s_ + 1) * 4 + kt) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        tile(wka, wave * RTW + s_);
-        if (s_ + 2 < RTW) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) wka[kt] = kp[((size_t)(s_ + 2) * 4 + kt) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tile(wkb, wave * RTW + s_ + 1);
-    }
-    if (xa.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(xa.gate);
-}
-
-void launch_dec32_cq_xqk(const P32Args& a_in, const XabsArgs& xa, int n_bt, hipStream_t st) {
-    P32Args a = a_in;
-    a.ks = 1; a.tw = a.K / 64; a.n_bt = n_bt;
-    const int H = a.n_head;
-    const dim3 grid((unsigned)(((H + 7) / 8) * 8 * n_bt));
-    ProfScope ps_(KK_DEC_CQ_XQK, st);
-    const bool nt = n_bt == 1;
-#define CQX(NHT_, TC_) do { if (nt) dec32_cq_xqk_kernel<NHT_, TC_, true><<<grid, 256, 0, st>>>(a, xa); else dec32_cq_xqk_kernel<NHT_, TC_, false><<<grid, 256, 0, st>>>(a, xa); } while (0)
-    if (H > 16) { if (a.tw % 2 == 0) CQX(2, 2); else CQX(2, 1); }
-    else { if (a.tw % 2 == 0) CQX(1, 2); else CQX(1, 1); }
-#undef CQX
-}
-bool dec32_fuse_qk() {
-    static const int v = env_int32("WH_XABS_FUSE_QK", 0);
-    return v != 0;
-}
+// (Round 5, measured and rejected, profiles/r05l_*: the cross-query projection and xabs_qk as ONE launch - a workgroup per (head, batch tile): phase 1
+// = this kernel's arithmetic for the head's two row tiles of W_cq with q_h kept in LDS, phase 2 = xabs_qk's arithmetic over the head's d / 32
+// channel tiles.  Bit-identical (tests at 70 / 33 slots), and no faster: 23.3 us against 10.4 + 10.3 us - 80 workgroups that each stream 328 KB in two
+// dependent phases instead of 160 + 400 short ones - 8.23 -> 8.40 ms per 128-slot step alone, 2610 -> 2615 audio-s/s in flight.  Code in git
+// history, commit "cross query + absorbed query as one launch".)
 
 // ---------------------------------------------------------------------------------------------- embedding
 // x = token_embedding[next_token] + positional_embedding[token_index] (openai/whisper TextDecoder.forward), the head of the

@@ -914,7 +914,7 @@ extern "C" int wh_transcription_window_seeks(const wh_transcription* t, const in
 static const char* kKindNames[KK_COUNT] = {
     "mel_power", "mel_finalize", "gemm_conv1", "gemm_conv2", "layernorm", "gemm_enc_qkv", "enc_attention", "gemm_enc_o", "gemm_enc_fc1",
     "gemm_enc_fc2", "gemm_cross_kv", "dec_proj_qkv", "dec_self_attn", "dec_proj_oproj", "dec_proj_cq", "dec_cross_attn", "dec_proj_coproj",
-    "dec_proj_fc1", "dec_proj_fc2", "dec_proj_logits", "sampler", "dec_embed", "dec_xabs_qk", "dec_xabs_vup", "dec_cq_xqk"};
+    "dec_proj_fc1", "dec_proj_fc2", "dec_proj_logits", "sampler", "dec_embed", "dec_xabs_qk", "dec_xabs_vup"};
 namespace wh { unsigned long long* debug_buffer(); }
 extern "C" int wh_debug_dump(const char* path) {
     unsigned long long* b = wh::debug_buffer();

@@ -57,7 +57,7 @@ __device__ __forceinline__ void hr24_encode(float x, f16& hi, signed char& lo) {
 enum KernelKind {
     KK_MEL_POWER = 0, KK_MEL_FINALIZE, KK_CONV1, KK_CONV2, KK_LAYERNORM, KK_ENC_QKV, KK_ENC_ATTN, KK_ENC_O, KK_ENC_FC1, KK_ENC_FC2,
     KK_CROSS_KV, KK_DEC_QKV, KK_DEC_SELF_ATTN, KK_DEC_OPROJ, KK_DEC_CQ, KK_DEC_CROSS_ATTN, KK_DEC_COPROJ, KK_DEC_FC1, KK_DEC_FC2, KK_DEC_LOGITS,
-    KK_SAMPLER, KK_DEC_EMBED, KK_DEC_XQK, KK_DEC_XVUP, KK_DEC_CQ_XQK,
+    KK_SAMPLER, KK_DEC_EMBED, KK_DEC_XQK, KK_DEC_XVUP,
     KK_COUNT
 };
 struct KernelProfiler {
@@ -311,9 +311,6 @@ struct XabsArgs {
 bool xabs_supported(int d, int n_head);
 void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);
 void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st);
-// cross-query projection + absorbed queries in one launch (decoder32.hip; WH_XABS_FUSE_QK=1), bit-identical to dec32_proj<P32_Q> followed by xabs_qk
-void launch_dec32_cq_xqk(const struct P32Args& a, const XabsArgs& xa, int n_bt, hipStream_t st);
-bool dec32_fuse_qk();
 void launch_xabs_attn(const XabsArgs& a, hipStream_t st);
 void launch_xabs_vup(const XabsArgs& a, int n_bt, hipStream_t st);
 
