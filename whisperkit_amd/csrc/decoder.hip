@@ -88,11 +88,6 @@ struct AttnArgs {
     const int* self_owner;     // self-attention: row -> owning slot table of beam search, or null
     int* gate; int gate_wg;    // cross-attention gate (dec_shared.h): the workgroup with linear id gate_wg gives it back at entry
     unsigned long long* dbg;   // optional timeline probe (WH_DBG=1)
-    // fused cross query (dec_cross_attn_kernel<.., QF = true>, d <= 384): the workgroup computes its head's query itself from the LayerNorm-2 planes
-    const f16 *qf_zhi, *qf_zlo;          // gamma_2 x planes (hi | lo) of the residual stream
-    const float2* qf_stat; int qf_n_stat; // per-row-tile (mean, M2) partials of the residual stream
-    const float *qf_g, *qf_c;            // LayerNorm folds of the cross-query projection: g = W gamma, c = W beta + b
-    const f16* qf_w;                     // W_cq [d][d] as in the blob (null: the query comes from a.q)
 };
 __device__ __forceinline__ void gate_release_if_mine(const AttnArgs& a) {
     if (a.gate && threadIdx.x == 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) == a.gate_wg) xattn_gate_release(a.gate);
@@ -340,17 +335,15 @@ __device__ __forceinline__ void combine_splits(const AttnArgs& a, int b, int h, 
     }
 }
 
-// QF (round 5, models of width <= 384: tiny.en, the micro fixtures): the cross-QUERY projection is folded into this kernel.  A (split, head,
-// slot) workgroup computes its head's 64 query channels itself - q_h = rstd (W_cq,h (gamma x) - mu (W gamma)_h) + (W beta + b)_h from the
-// LayerNorm-2 planes, 49 KB of weights at d = 384, four threads per channel - while its K / V rows are already on their way, so the
-// per-layer launch of dec32_proj<P32_Q> (with its boundary, entry and first-data latency: ~5.5 us of a 56 us layer at tiny.en / 1 slot)
-// disappears.  Redundant across the key splits and slots of a head (144 x 49 KB = 7 MB of L2 reads per layer at tiny.en): affordable only at
-// small widths.  Per slot the arithmetic does not depend on the batch: batched == lone slot bit for bit, as before.
-template <int PASSES, bool NT, bool QF>
+// (Round 5, measured and rejected, profiles/r05o_*: at width <= 384 the cross-QUERY projection folded into this kernel - a (split, head, slot)
+// workgroup computing its head's 64 query channels itself from the LayerNorm-2 planes (49 KB of W_cq at d = 384, four threads per channel) while its
+// K / V rows are in flight, so that dec32_proj<P32_Q>'s launch disappears.  Parity-green (the whole GPU suite), and slower: the query phase is twelve
+// dependent L2 round trips that the row stream does not hide, and it is redundant across key splits and slots - tiny.en at 1 slot 10.8 -> 17.7 us
+// per launch (0.2266 -> 0.2365 ms per decoder step with the cross-query launch gone), at 8 slots 18.3 -> 42.4 us.  Code in git history.)
+template <int PASSES, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
     constexpr int KPB = PASSES * 32;
     __shared__ float red[16], osum[256], o_l[64];
-    __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ int last_flag;
     const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     gate_release_if_mine(a);
@@ -374,44 +367,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const AttnArgs a) {
         if (slot >= 0 && pos + 1 < kMaxTok) raw = a.align + (((size_t)b * kMaxTok + pos + 1) * a.n_align + slot) * kCtx + t0;
         return n;
     };
-    // every K and V row of the block is requested first; the query (from a.q, or computed here: QF) is looked at while they are in flight
-    KvPiece<hr24> kreg[PASSES], vreg[PASSES];
-    attend_fetch<PASSES, NT, hr24>(KvSrc<hr24>{a.cross_k_hi + base, a.cross_k_lo + base}, KvSrc<hr24>{a.cross_v_hi + base, a.cross_v_lo + base}, n, kreg, vreg);
-    float qv[8];
-    if constexpr (QF) {
-        const int tid_ = threadIdx.x, c = tid_ >> 2, kq = tid_ & 3, K = d, KQ = K >> 2;
-        const int row = h * kHeadDim + c;
-        const f16* wrow = a.qf_w + (size_t)row * K + kq * KQ;
-        float t = 0.0f;
-        for (int k0 = 0; k0 < KQ; k0 += 8) {
-            const f16x8 w8 = *reinterpret_cast<const f16x8*>(wrow + k0);
-            const size_t zo = plane_index(b, kq * KQ + k0, K);
-            const f16x8 h8 = *reinterpret_cast<const f16x8*>(a.qf_zhi + zo), l8 = *reinterpret_cast<const f16x8*>(a.qf_zlo + zo);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t = fmaf((float)w8[i], fmaf((float)l8[i], 1.0f / 2048.0f, (float)h8[i]), t);
-        }
-        t += dpp_mov<kDppXor1>(t);            // the four K quarters of a channel sit in one quad
-        t += dpp_mov<kDppXor2>(t);
-        // LayerNorm statistics of the slot: Chan-combine of the row-tile partials in index order
-        const float2* sp = a.qf_stat + ((size_t)(b >> 5) * a.qf_n_stat) * 32 + (b & 31);
-        float cn = 32.0f, cm = sp[0].x, cM2 = sp[0].y;
-        for (int i = 1; i < a.qf_n_stat; ++i) {
-            const float2 p = sp[(size_t)i * 32];
-            const float nn = cn + 32.0f, delta = p.x - cm;
-            cm = fmaf(delta, 32.0f / nn, cm);
-            cM2 += fmaf(delta * delta, cn * 32.0f / nn, p.y);
-            cn = nn;
-        }
-        const float rstd = rsqrtf(cM2 / (float)K + 1e-5f);
-        if (kq == 0) qs[c] = fmaf(rstd, t - cm * a.qf_g[row], a.qf_c[row]);
-        __syncthreads();
-        attend_load_q(qs, qv);
-    } else {
-        attend_load_q(a.q + (size_t)b * d + h * kHeadDim, qv);
-    }
-    const int n_live = get_n();
-    if (n_live < 0) return;             // workgroup-uniform
-    attend_compute<PASSES, hr24>(qv, kreg, vreg, n_live, raw, red, osum, o_l, &m, &l, stamp);
+    auto qfix = [](float (&)[8], int) {};
+    if (!attend_block<PASSES, NT, hr24>(a.q + (size_t)b * d + h * kHeadDim, KvSrc<hr24>{a.cross_k_hi + base, a.cross_k_lo + base}, KvSrc<hr24>{a.cross_v_hi + base, a.cross_v_lo + base},
+                                        n, get_n, qfix, &raw, red, osum, o_l, &m, &l, stamp))
+        return;
     // ---- publish this split's partial, take a ticket; the last arriver combines all splits in index order
     const int tid = threadIdx.x;
     float* mine = a.part + (((size_t)b * a.n_head + h) * S + sp) * kPartStride;
@@ -871,8 +830,7 @@ static void launch_cross_attn(const AttnArgs& at_in, int S, int H, int B, hipStr
     // flight 13.4 k -> 14.2 k sequence-steps/s, profiles/r02i_*); WH_XATT_NT=0 is the A/B side
     static const int nt = env_int("WH_XATT_NT", 1);
     const bool ntl = nt && at.cross_div <= 1;      // (cross_div > 1, beam search: cacheable loads - the L2 of the XCD serves the other beams of the audio)
-#define XATT(P_) do { if (at.qf_w) { if (ntl) dec_cross_attn_kernel<P_, true, true><<<grid, 256, xlds, st>>>(at); else dec_cross_attn_kernel<P_, false, true><<<grid, 256, xlds, st>>>(at); } \
-                      else if (ntl) dec_cross_attn_kernel<P_, true, false><<<grid, 256, xlds, st>>>(at); else dec_cross_attn_kernel<P_, false, false><<<grid, 256, xlds, st>>>(at); } while (0)
+#define XATT(P_) do { if (ntl) dec_cross_attn_kernel<P_, true><<<grid, 256, xlds, st>>>(at); else dec_cross_attn_kernel<P_, false><<<grid, 256, xlds, st>>>(at); } while (0)
     if (S == 6) XATT(8);
     else if (S == 8) XATT(6);
     else if (S == 12) XATT(4);
@@ -917,10 +875,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
         a = base;               // LN2 (folded) + cross-attention query
         a.N = d; a.K = d; a.Wt = t.cq_t; a.zhi = D.za_hi; a.zlo = D.za_lo; a.fold_g = t.cq_g; a.fold_c = t.cq_c; a.q = D.q; a.prof_kind = KK_DEC_CQ;
         a.gate = db.xabs ? nullptr : db.xattn_gate;
-        // width <= 384 in K / V-row mode: the cross query is computed inside the cross-attention workgroups (dec_cross_attn_kernel QF); WH_FUSE_CQ=0 = A/B side
-        static const int fuse_cq_knob = env_int("WH_FUSE_CQ", 1);
-        const bool fuse_cq = !db.xabs && d <= 384 && fuse_cq_knob != 0;
-        if (!fuse_cq) launch_dec32_proj(P32_Q, a, n_bt, st);
+        launch_dec32_proj(P32_Q, a, n_bt, st);
         if (db.xabs) {          // weight-absorbed cross-attention over the encoder output (xabs.hip): no per-layer K / V rows
             const Xabs& X = *db.xabs;
             XabsArgs xa{};
@@ -935,9 +890,6 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             launch_xabs_vup(xa, n_bt, st);
         } else {
             at.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
-            if (fuse_cq) {
-                at.qf_zhi = D.za_hi; at.qf_zlo = D.za_lo; at.qf_stat = D.stat; at.qf_n_stat = d / 32; at.qf_g = t.cq_g; at.qf_c = t.cq_c; at.qf_w = w.cq_w;
-            }
             launch_cross_attn(at, S, H, B, st);
         }
         a = base;               // x += W_co att + b_co; planes gamma_3 x, statistics for LN3
