@@ -184,3 +184,17 @@ def test_xabs_ring_of_seven_half_tiles_never_overwrites_a_resident_tile():
                 assert victim is None or victim not in needed, (n, i, h, victim)
                 assert victim is None or victim // 2 <= i, (n, i, h, victim)     # only tile i (or older) is overwritten
                 put(h)
+
+
+def test_gemm256_staged_epilogue_maps_cover_the_wave_tile_exactly_once(tmp_path):
+    """csrc/epi_stage.h (round 5): the write / read maps that turn a wave's 128 x 64 accumulator tile through 16 KB of LDS, replayed for all
+    64 lanes by tests/native/epi_stage_check.cpp (the SAME header the kernel includes): every element reaches its row-major place exactly
+    once, every access stays inside the wave's slice and is aligned, every store instruction covers whole 128-byte lines."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "epi_stage_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "whisperkit_amd", "csrc"),
+                    os.path.join(root, "tests", "native", "epi_stage_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "EPI_STAGE_OK" in out.stdout, out.stdout[-2000:]

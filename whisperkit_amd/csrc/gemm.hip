@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "epi_stage.h"
 #include "kernels.h"
 
 namespace wh {
@@ -94,11 +95,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
     }
 }
 
+// The bias of a wave's 64 columns in the swapped accumulator layout (columns j * 32 + 8 g + 4 (lane >> 5) .. + 3), fetched in ONE batch.
+// The direct epilogues fetch each float4 where it is used, behind a branch on a.bias: every fetch is followed by s_waitcnt vmcnt(0),
+// which on this ISA also waits for every store issued before it - 32 serial round trips per wave.
+__device__ __forceinline__ void load_tile_bias(const GemmArgs& a, float4 (&bias)[2][4], int nw, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[j][g] = float4{0, 0, 0, 0};
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[j][g] = *reinterpret_cast<const float4*>(a.bias + nw + j * 32 + 8 * g + 4 * (lane >> 5));
+    }
+}
+
 // Epilogue for accumulators produced with the operands swapped (mfma(W fragment, A fragment)): the 32 x 32 tile is C^T,
 // so a lane owns ONE output row m = lane & 31 and, per register group, 4 CONSECUTIVE columns n - row-major outputs go
 // out as 8-byte (f16x4) / 16-byte (float4) accesses instead of 2- and 4-byte ones.
-template <int EPI, int TM, int TN>
+template <int EPI, int TM, int TN, bool BATCH_BIAS = false>
 __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m_wave, int n_wave, int lane) {
+    float4 tile_bias[2][4];
+    if constexpr (BATCH_BIAS) {       // gemm256_kernel, N % 64 == 0: the wave's 64 columns are inside or outside as a whole
+        static_assert(TM == 4 && TN == 2, "wave tile of gemm256_kernel");
+        if (n_wave >= a.N) return;
+        load_tile_bias(a, tile_bias, n_wave, lane);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_wave + i * 32 + (lane & 31);
@@ -113,7 +136,8 @@ __device__ __forceinline__ void gemm_epilogue_swapped(const GemmArgs& a, f32x16 
                 const int n = n_wave + j * 32 + 8 * g + 4 * (lane >> 5);
                 if (n >= a.N) continue;
                 float4 bias = float4{0, 0, 0, 0};
-                if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + n);
+                if constexpr (BATCH_BIAS) bias = tile_bias[j][g];
+                else if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + n);
                 float v0 = acc[i][j][4 * g] + bias.x, v1 = acc[i][j][4 * g + 1] + bias.y;
                 float v2 = acc[i][j][4 * g + 2] + bias.z, v3 = acc[i][j][4 * g + 3] + bias.w;
                 if constexpr (EPI == EPI_F16) {
@@ -256,6 +280,126 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {     //
     }
 }
 
+// ---------------------------------------------------------------------------------------------- LDS-staged epilogues of gemm256_kernel
+// (round 5; index maps and the reason in epi_stage.h, replayed on the CPU by tests/native/epi_stage_check.cpp).  A wave's 128 x 64 tile
+// goes through its private 16 KB slice `wl` of the dead operand stages in passes; the arithmetic (bias add, GELU, conversion, the
+// residual's x + v) is that of the direct epilogues above, term for term: the outputs are the same bits, only the store instructions
+// differ - 16 bytes per lane with 8 (f16) / 16 (fp32) neighbouring lanes on one row instead of 8 bytes per lane on 32 different rows.
+// Requires N % 64 == 0 (a wave's 64 columns are inside or outside as a whole), M % 4 == 0, 16-byte aligned rows (launch_epi checks).
+__device__ __forceinline__ void wave_lds_turn() {      // LDS operations of ONE wave execute in order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_staged_f16(const GemmArgs& a, f32x16 (&acc)[4][2], unsigned char* wl, int mw, int nw, int lane) {
+    if (nw >= a.N) return;
+    f16* base = a.out16;
+    int ld = a.ldc, nc = nw;
+    if constexpr (EPI == EPI_QKV_ENC) {      // q / k columns (the V^T tiles take epi_staged_vt)
+        ld = a.d_model;
+        if (nw >= ld) { base = a.k16; nc = nw - ld; }
+    }
+    float4 bias[2][4];
+    load_tile_bias(a, bias, nw, lane);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& c = acc[2 * hh + i2][j];
+                    const float v0 = c[4 * g] + bias[j][g].x, v1 = c[4 * g + 1] + bias[j][g].y, v2 = c[4 * g + 2] + bias[j][g].z, v3 = c[4 * g + 3] + bias[j][g].w;
+                    f16x4 pk;
+                    if constexpr (EPI == EPI_GELU_F16) pk = f16x4{(f16)gelu_erf_fast(v0), (f16)gelu_erf_fast(v1), (f16)gelu_erf_fast(v2), (f16)gelu_erf_fast(v3)};
+                    else pk = f16x4{(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+                    *reinterpret_cast<f16x4*>(wl + epi::f16_write_off(lane, i2, j, g)) = pk;
+                }
+        wave_lds_turn();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = mw + hh * 64 + epi::f16_read_row(lane, it);
+            const uint4 v = *reinterpret_cast<const uint4*>(wl + epi::f16_read_off(lane, it));
+            if (m < a.M) *reinterpret_cast<uint4*>(base + (size_t)m * ld + nc + epi::f16_read_col(lane)) = v;
+        }
+        wave_lds_turn();
+    }
+}
+
+__device__ __forceinline__ void epi_staged_resid(const GemmArgs& a, f32x16 (&acc)[4][2], unsigned char* wl, int mw, int nw, int lane) {
+    if (nw >= a.N) return;
+    float4 bias[2][4];
+    load_tile_bias(a, bias, nw, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m_first = mw + i * 32 + epi::f32_read_row(lane, 0);
+        float* const col0 = a.out32 + nw + epi::f32_read_col(lane);
+        float4 old[8];      // the residual rows of this pass, in flight under the LDS turn (rows past M: clamped loads, no store)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) old[it] = *reinterpret_cast<const float4*>(col0 + (size_t)min(m_first + it * 4, a.M - 1) * a.ldc);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& c = acc[i][j];
+                *reinterpret_cast<float4*>(wl + epi::f32_write_off(lane, j, g)) =
+                    float4{c[4 * g] + bias[j][g].x, c[4 * g + 1] + bias[j][g].y, c[4 * g + 2] + bias[j][g].z, c[4 * g + 3] + bias[j][g].w};
+            }
+        wave_lds_turn();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const float4 v = *reinterpret_cast<const float4*>(wl + epi::f32_read_off(lane, it));
+            float4 o = old[it];
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            if (m_first + it * 4 < a.M) *reinterpret_cast<float4*>(col0 + (size_t)(m_first + it * 4) * a.ldc) = o;
+        }
+        wave_lds_turn();
+    }
+}
+
+// V^T columns of the encoder QKV projection (unswapped accumulators): V^T[(b * d + c) * kCtxPad + t] is contiguous along the product's rows.
+__device__ __forceinline__ void epi_staged_vt(const GemmArgs& a, f32x16 (&acc)[4][2], unsigned char* wl, int mw, int nw, int lane) {
+    if (nw >= a.N) return;
+    const int d = a.d_model;
+    float bias2[2] = {0.0f, 0.0f};
+    if (a.bias) { bias2[0] = a.bias[nw + (lane & 31)]; bias2[1] = a.bias[nw + 32 + (lane & 31)]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float bias = bias2[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& c = acc[i][j];
+                *reinterpret_cast<f16x4*>(wl + epi::vt_write_off(lane, i, g)) =
+                    f16x4{(f16)(c[4 * g] + bias), (f16)(c[4 * g + 1] + bias), (f16)(c[4 * g + 2] + bias), (f16)(c[4 * g + 3] + bias)};
+            }
+        wave_lds_turn();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint4 v = *reinterpret_cast<const uint4*>(wl + epi::vt_read_off(lane, it));
+            const int call = nw - 2 * d + j * 32 + epi::vt_read_col(lane, it);
+            const int m = mw + epi::vt_read_row(lane);
+            // two groups of 4 rows: 1500 is a multiple of 4, so a group never straddles two windows; 8 rows may (1500 % 8 == 4)
+            if (m < a.M) {
+                const int bb = m / kCtx, t = m - bb * kCtx;
+                *reinterpret_cast<uint2*>(a.vt16 + ((size_t)bb * d + call) * kCtxPad + t) = uint2{v.x, v.y};
+            }
+            if (m + 4 < a.M) {
+                const int bb = (m + 4) / kCtx, t = m + 4 - bb * kCtx;
+                *reinterpret_cast<uint2*>(a.vt16 + ((size_t)bb * d + call) * kCtxPad + t) = uint2{v.z, v.w};
+            }
+        }
+        wave_lds_turn();
+    }
+}
+
+template <int EPI>
+constexpr bool kHasStagedEpilogue = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ENC;
+
 // ---------------------------------------------------------------------------------------------- 256 x 256 x 64 tile, ping-pong
 // Large-problem path (encoder GEMMs at batch >= 2, cross-K/V projection): 8 waves (2 along M x 4 along N, wave tile 128 x 64 =
 // 4 x 2 MFMA tiles), operands staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two 64 KB
@@ -275,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {     //
 // Hazards: tile t is read in slots 4t .. 4t+3 (every X ends with lgkmcnt(0) before its barrier); DMA(t+1) overwrites the stage of
 // tile t-1 from slot 4t on (its last read was slot 4t-1) and every wave has waited for its pieces before b_{4t+3}; the first read
 // of tile t+1 is slot 4t+4.  Both groups execute 4 nk + 1 barriers.
-template <int EPI>
+template <int EPI, int MODE>      // MODE 0: direct epilogues; 1: LDS-staged (kHasStagedEpilogue); 2: direct with the bias fetched in one batch
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     constexpr int TM = 4, TN = 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [2 stages][A 32 KB | B 32 KB]
@@ -388,7 +532,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
                 Y(kNoDma, 0); PP_BAR();
             }
         }
-        if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        // every wave is past its last fragment read and its last LDS-DMA wait here (both precede the final barrier): the stages are dead
+        if constexpr (MODE == 1 && kHasStagedEpilogue<EPI>) {
+            unsigned char* wl = smem + wave * epi::kWaveRegion;
+            if constexpr (!SWAP) epi_staged_vt(a, acc, wl, m0 + wm * 128, n0 + wn * 64, lane);
+            else if constexpr (EPI == EPI_RESID_F32) epi_staged_resid(a, acc, wl, m0 + wm * 128, n0 + wn * 64, lane);
+            else epi_staged_f16<EPI>(a, acc, wl, m0 + wm * 128, n0 + wn * 64, lane);
+        } else if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN, MODE == 2>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
         else gemm_epilogue<EPI, TM, TN>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
     };
 #undef PP_BAR
@@ -408,11 +558,21 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
     const long long tiles256 = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     static const bool no256 = [] { const char* e = getenv("WH_NO_GEMM256"); return e && e[0] == '1'; }();
     if (!no256 && tiles256 >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.a_batch_stride % 8 == 0 && a.N % 4 == 0) {
-        static PerDeviceOnce raised;
-        raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
         // measured and rejected (profiles/r02s_*): staggering the first-round workgroups by up to a tile time to spread the store
         // epilogues of the 256 CUs over each other's K loops - no change (1476 vs 1475 us, large-v3 fc1 at 64 chunks)
-        gemm256_kernel<EPI><<<(unsigned)tiles256, 512, 131072, st>>>(a);
+        static const int epi_mode = [] { const char* e = getenv("WH_GEMM_EPI_MODE"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+        auto go = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            static PerDeviceOnce raised;
+            raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
+            gemm256_kernel<EPI, MODE><<<(unsigned)tiles256, 512, 131072, st>>>(a);
+        };
+        if constexpr (kHasStagedEpilogue<EPI>) {
+            const bool shape_ok = a.N % 64 == 0 && a.M % 4 == 0 && a.ldc % 8 == 0 && a.d_model % 64 == 0;
+            if (shape_ok && epi_mode == 1) { go(std::integral_constant<int, 1>{}); return; }
+            if (shape_ok && epi_mode == 2) { go(std::integral_constant<int, 2>{}); return; }
+        }
+        go(std::integral_constant<int, 0>{});
         return;
     }
     // small problems get 64x64 tiles so that more than a handful of CUs are busy
