@@ -1,5 +1,5 @@
 #!/bin/bash
-# one GPU call: the three epilogue modes of gemm256_kernel - identical encoder outputs, then the encoder's time per chunk and per kernel
+# gpurun -- "bash tools/epi_modes_ab.sh": the three epilogue modes of gemm256_kernel - identical encoder outputs, then the encoder's time per chunk and per kernel
 mkdir -p gpurun_out
 for m in 0 1 2; do
   WH_GEMM_EPI_MODE=$m timeout 300 python tools/enc_epi_ab.py > gpurun_out/r05r_epi_md5_mode$m.json 2> gpurun_out/r05r_epi_md5_mode$m.err || echo "md5 mode $m FAILED rc=$?"
