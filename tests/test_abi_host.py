@@ -353,3 +353,18 @@ def test_round5_bench_line_bookkeeping_is_per_bench_step():
     assert tj["chunks_per_step"] == 128 and tj["cross_attention_splits"] == 1
     assert 1.0 <= tj["bytes_per_launch"]["dec_cross_attn"] / r["alg_per_launch"] <= 1.05
     assert r["traffic"] == tj["bytes_per_launch"]["dec_cross_attn"]                                   # the line carries the PMC figure of its own workload
+
+
+def test_library_carries_the_staged_epilogue_kernels():
+    """csrc/gemm.hip (round 5): the four layer GEMMs of the encoder run gemm256_kernel<EPI, 1> (LDS-staged epilogues) by default; the
+    direct variants <EPI, 0> stay for WH_GEMM_EPI_MODE=0 and for shapes the staged form does not take.  A build that lost either set
+    would silently change what the encoder runs: the mangled names must be in the library's code object."""
+    import os
+    from whisperkit_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.__file__), "libwhisperhip.so")
+    blob = open(path, "rb").read()
+    for epi in (0, 1, 2, 3):                                     # F16, GELU_F16, RESID_F32, QKV_ENC (kernels.h GemmEpi)
+        for mode in (0, 1, 2):
+            assert f"gemm256_kernelILi{epi}ELi{mode}EEE".encode() in blob, (epi, mode)
+    for epi in (4, 5, 6, 7):                                     # conv1, conv2, plain fp32, cross K / V rows: direct only
+        assert f"gemm256_kernelILi{epi}ELi0EEE".encode() in blob and f"gemm256_kernelILi{epi}ELi1EEE".encode() not in blob, epi

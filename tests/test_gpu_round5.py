@@ -192,3 +192,20 @@ def test_a_session_of_200_slots_decodes_every_slot_like_a_lone_session():
         one.close()
     big.close(); model.close()
 
+
+
+def test_encoder_output_is_bit_identical_in_every_gemm_epilogue_mode():
+    """csrc/gemm.hip, round 5: gemm256_kernel's LDS-staged epilogues (WH_GEMM_EPI_MODE=1, the default) change which store instruction
+    carries a value, not the value: MD5 of the encoder output at four widths / slot counts (ragged M, a partial 256-column tile, the q / k,
+    V^T, GELU and residual epilogues) in the staged mode, the direct mode of rounds 2 - 4 (0) and the direct mode with the batched bias (2).
+    One process per mode: the library reads the knob once."""
+    import json
+    got = {}
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, PYTHONPATH=ROOT, WH_GEMM_EPI_MODE=mode, WH_EPI_AB_QUICK="1")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "enc_epi_ab.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert rec.pop("mode") == mode
+        got[mode] = rec
+    assert len(got["1"]) == 4 and got["0"] == got["1"] == got["2"], got

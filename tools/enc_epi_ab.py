@@ -19,6 +19,8 @@ from whisperkit_amd import api, weights  # noqa: E402
 from whisperkit_amd.synth import synthetic_chunk  # noqa: E402
 
 CASES = [("test-large-v3-l2", 64), ("test-large-v3-l2", 3), ("test-small-l2", 8), ("tiny.en", 8), ("base", 9), ("test-micro", 8), ("tiny.en", 1)]
+if os.environ.get("WH_EPI_AB_QUICK"):        # tests/test_gpu_round5.py: seconds per mode (ragged M, a partial 256-column tile at width 384, every staged epilogue)
+    CASES = [("test-large-v3-l2", 3), ("test-small-l2", 8), ("tiny.en", 8), ("test-micro", 8)]
 out = {"mode": os.environ.get("WH_GEMM_EPI_MODE", "default")}
 for name, slots in CASES:
     dims = weights.MODEL_DIMS[name]
