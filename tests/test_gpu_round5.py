@@ -5,7 +5,9 @@
     with a single rank); the first box with more GPUs runs the real multi-rank collective without a code change;
   * both cross-attention modes against the fp32 oracle on the realistic-statistics recipe at two layers (the quick form of
     tests/test_gpu_realistic.py: the K / V rows carry 19 mantissa bits since round 5);
-  * wh_debug_peek refuses a request beyond the named buffer; the automatic mode threshold is what the header documents.
+  * wh_debug_peek refuses a request beyond the named buffer; the automatic mode threshold is what the header documents;
+  * 70- and 200-slot sessions against one-slot sessions, bit for bit; the encoder output's MD5 in the three epilogue modes of the large GEMM
+    kernel (LDS-staged = the default, direct, direct with the batched bias).
 """
 import os
 import subprocess
