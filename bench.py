@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
 PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
+AUDIO_SETS = 6             # distinct chunk sets a run cycles through (3 device batches in flight x 2 packed steps)
 T_START = time.perf_counter()
 
 
@@ -195,7 +196,7 @@ def plan_batches(n_steps, F, G):
 
 
 def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, dev, want_roofline, want_cpu, word_timestamps=False,
-               comm=None, scaling="strong", device_batch=None):
+               comm=None, scaling="strong", device_batch=None, whole_chip_leg=True):
     """B = chunks per step: in total over the ranks (strong scaling, the default) or per rank (weak).  A rank's share of a step is the
     contiguous block partition_chunks gives it; the shares of up to G consecutive steps are packed into one device batch of at most
     `device_batch` slots (continuous batching: default = B, i.e. G = 1 at one GPU; the headline packs two 64-chunk steps into one 128-slot
@@ -203,7 +204,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     import torch
     import torch.distributed as dist
     from whisperkit_amd import api, parallel
-    from whisperkit_amd.synth import synthetic_chunk
+    from whisperkit_amd.synth import bench_chunk_seed, synthetic_chunk
 
     model, dims, sd = get_model(model_name, local_rank, keep_sd=want_cpu)
     F = max(1, F)
@@ -220,20 +221,26 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     xsplits = args.cross_attention_splits if args.cross_attention_splits >= 0 else (max(1, min(4, 128 // max(slots, 1))) if F > 1 else 0)
     sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None) for _ in range(F)]
     sess = sessions[0]
-    chunks = [np.ascontiguousarray(synthetic_chunk(1234 + first + b), dtype=np.float32) for b in range(n_local)]   # host float32 PCM
+    # host float32 PCM: a pool of AUDIO_SETS chunk sets; step n of a run (steps numbered worker by worker, batch by batch: the order the records are
+    # gathered in) carries set n % AUDIO_SETS, so the packed steps of a device batch and the sessions in flight carry DIFFERENT audio (VERDICT r05
+    # weak 9: identical halves let the embedding kernel read one row for two slots) and an N-rank run sees the audio of the 1-rank run step by step.
+    # Set 0 is the chunk set of rounds 1 - 5 (seeds 1234 + chunk index): the CPU baseline and tests/test_gpu_fulldepth.py check against it.
+    n_sets = max(1, min(AUDIO_SETS, max(steps, warmup, F * G)))
+    audio = [[np.ascontiguousarray(synthetic_chunk(bench_chunk_seed(first + b, k)), dtype=np.float32) for b in range(n_local)] for k in range(n_sets)]
+    chunks = audio[0]
     opts = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None,
                                noSpeechThreshold=None, temperatureFallbackCount=0, sampleLength=args.sample_length,
                                wordTimestamps=word_timestamps)
     prompt = sess.prefillPrompt(opts)
     st = model.specialTokens
 
-    def hot_path(ss, g=1):
-        """the rank's chunks of g consecutive steps as ONE device batch; returns (results, [records of step 0, step 1, ...], segments)"""
+    def hot_path(ss, g=1, n0=0):
+        """the rank's chunks of g consecutive steps (run steps n0 .. n0 + g - 1) as ONE device batch; returns (results, [records of step 0, step 1, ...], segments)"""
         nb = g * n_local
         if nb == 0:
             return [], [np.zeros((0, parallel.RECORD_INTS), np.int32) for _ in range(g)], 0
         for k in range(g):
-            for b, x in enumerate(chunks):
+            for b, x in enumerate(audio[(n0 + k) % n_sets]):
                 ss.padOrTrim(x, k * n_local + b)       # PCM in host memory -> HBM, inside the timed region (SURVEY 8d)
         ss.logMelSpectrogram(nb)
         ss.encodeFeatures(nb)
@@ -258,11 +265,16 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         out = [[None] * len(p) for p in plan]
         dur = [[0.0] * len(p) for p in plan]
         errs = []
+        starts, acc = [], 0                       # run-step number of every batch's first step (gather order: worker by worker, batch by batch)
+        for p_ in plan:
+            starts.append([])
+            for g in p_:
+                starts[-1].append(acc); acc += g
 
         def work(f):
             try:
                 for i, g in enumerate(plan[f]):
-                    a = time.perf_counter(); out[f][i] = hot_path(sessions[f], g); dur[f][i] = time.perf_counter() - a
+                    a = time.perf_counter(); out[f][i] = hot_path(sessions[f], g, starts[f][i]); dur[f][i] = time.perf_counter() - a
             except BaseException as e:   # noqa: BLE001
                 errs.append(e)
         if len(plan) == 1:
@@ -318,7 +330,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     out = {"value": audio_s / elapsed, "elapsed": elapsed, "audio_s": audio_s, "dec_steps": dec_steps[0], "B": B, "inflight": F,
            "cross_attention": (f"absorbed, {sess.crossAttentionSplits} key splits per slot ({slots * sess.crossAttentionSplits} workgroups = CUs per launch)"
                                if sess.crossAttentionMode == 1 else "per-layer K / V rows"),
-           "total": total, "n_local": n_local, "steps_per_batch": G, "slots": slots,
+           "total": total, "n_local": n_local, "steps_per_batch": G, "slots": slots, "audio_sets": n_sets,
            "median_step_latency_ms": float(np.median(lat)) * 1e3, "median_ms_per_step": float(np.median(durs)) * 1e3 / Fe, "n_median": int(len(durs))}
     if rank == 0 and F > 1 and args.serial_reference:
         # single-stream reference on rank 0 only: local synchronisation, no collective (the other ranks are not here)
@@ -337,7 +349,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         for _ in range(3):
             sess.synchronize(); a0 = time.perf_counter()
             for k in range(G):
-                for b, x in enumerate(chunks):
+                for b, x in enumerate(audio[k % n_sets]):
                     sess.padOrTrim(x, k * n_local + b)
             sess.synchronize(); a = time.perf_counter()
             sess.logMelSpectrogram(nb); sess.synchronize(); b_ = time.perf_counter()
@@ -361,10 +373,10 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
             # the other sessions' kernels.  The same kernel with 4 splits (the whole chip at 64 slots) is timed beside it, alone on the GPU.
             rf["workgroups"] = slots * ns
             rf["cu_share"] = round(min(1.0, slots * ns / 256.0), 3)
-            if ns != 4:
+            if ns != 4 and whole_chip_leg:
                 s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=4)
                 for k in range(G):
-                    for b, x in enumerate(chunks):
+                    for b, x in enumerate(audio[k % n_sets]):
                         s4.padOrTrim(x, k * n_local + b)
                 s4.logMelSpectrogram(slots); s4.encodeFeatures(slots); s4.prepareDecoderInputs(slots)
                 s4.decodeText(prompt, opts, batch=slots)          # (wh_measure_kernels re-arms the slot state the last decodeText left)
@@ -412,7 +424,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         k = len(ores.tokens) - 1    # the oracle's result ends with the appended EOT
         same = (ores.tokens[:k] == res[0].tokens[:k]) if first == 0 else None
         out["cpu_baseline"] = {
-            "value": round(30.0 / total, 4), "unit": "audio-sec/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "value": round(30.0 / total, 4), "unit": "audio-sec/sec", "cores": torch.get_num_threads(), "cores_of": f"{torch.get_num_threads()} of {os.cpu_count()} logical CPUs", "kind": "port",
             "sample": f"one 30 s {model_name} chunk: mel {c1 - c0:.2f} s + encoder {c2 - c1:.2f} s + cross-K/V {c3 - c2:.2f} s measured "
                       f"in full, {ores.steps} decoder steps measured ({per_step * 1e3:.1f} ms/step) and extrapolated to {dec_steps[0]} steps "
                       f"(torch fp32, {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs)",
@@ -464,6 +476,27 @@ def long_audio_config(args, local_rank):
                 "temperature_fallbacks": sum(int(r.timings["total_decoding_fallbacks"]) for _, r in got),
                 "decoder_forward_passes": sum(int(r.timings["total_decoding_loops"]) for _, r in got)}
     out = run(20)
+    # roofline of the greedy line: the kernels of one 20-slot decoder step, HIP-event timed; whole run = the algorithmic HBM bytes of
+    # every decoder forward pass the transcription made / its wall time (encoder, host windowing and the fallback's second pass inside the same time)
+    try:
+        s20 = api.Session(model, 20)
+        for b in range(20):
+            s20.padOrTrim(audio[b * 480000:(b + 1) * 480000], b)
+        s20.logMelSpectrogram(20); s20.encodeFeatures(20); s20.prepareDecoderInputs(20)
+        o20 = api.DecodingOptions(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None,
+                                  temperatureFallbackCount=0, sampleLength=args.sample_length)
+        s20.decodeText(s20.prefillPrompt(o20), o20, batch=20)
+        passes_per_slot = out["decoder_forward_passes"] / max(out["chunks"], 1)
+        rf = measure_kernels(s20, dims, 20, 16, passes_per_slot, "large-v3")
+        hbm = sum(k["alg_per_launch"] * k["launches_per_step"] for n_, k in rf["kernels"].items() if k["bound"] == "hbm" and (n_.startswith("dec_") or n_ == "sampler"))
+        rf["whole_step"] = {"hbm_bound_algorithmic_bytes": int(hbm), "ms_per_step": round(out["seconds"] * 1e3, 3),
+                            "achieved": round(hbm / out["seconds"] / 1e9, 1), "unit": "GB/s", "frac": round(hbm / out["seconds"] / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "decoder launches of every forward pass of the 10 min transcription (20 slots, ladder forced once) / its wall time"}
+        rf["whole_step_achieved"], rf["whole_step_frac"] = rf["whole_step"]["achieved"], rf["whole_step"]["frac"]
+        out["roofline_full"] = rf
+        s20.close()
+    except Exception as e:   # noqa: BLE001 - a secondary figure must not take the headline down
+        out["roofline_error"] = repr(e)
     out["note"] = ("10 min synthetic audio -> VADAudioChunker (30 s chunks, one device batch) -> decodeWithFallback with the ladder "
                    "forced once per window (T = 0 greedy, then 0.2 with the seeded top-5 sampler) -> segments")
     # (the library's choice at 100 slots: the absorbed cross-attention, which reads the audio's one encoder output with cacheable loads when
@@ -562,6 +595,13 @@ def main():
                 comm = None
                 gather_kind = f"torch.distributed all_gather_into_tensor ({args.dist_backend}); wh_comm failed on another rank"
 
+    from whisperkit_amd import parallel as parallel_mod
+    # what the result gather actually runs on: the world size and transport of the communicator wh_comm_create formed
+    comm_world = int(comm.lib.wh_comm_world_size(comm.handle)) if comm is not None else (world if world > 1 else 1)
+    if comm is not None:
+        comm_transport = "rccl" if comm.lib.wh_comm_transport(comm.handle) == comm._L.COMM_RCCL else "tcp"
+    else:
+        comm_transport = "torch.distributed" if world > 1 else "none"
     dev_batch = args.device_batch if args.device_batch > 0 else (128 if args.batch >= 64 else args.batch)
     main_cfg = run_config(args, args.model, args.batch, args.inflight, args.steps, args.warmup, world, rank, local_rank, dev,
                           want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline), comm=comm, scaling=args.scaling,
@@ -570,27 +610,43 @@ def main():
     headline = (args.model, args.batch) == ("large-v3", 64)
     extra = rank == 0 and world == 1 and not args.no_other_configs
 
+    def brief_roofline(rf):
+        """the dominant kernel's line + the whole-step HBM figure of a secondary configuration (every BASELINE config carries one)"""
+        if not rf:
+            return None
+        keep = ("kernel", "cross_attention", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us", "alg_per_launch", "share_of_step_time",
+                "sum_kernel_ms_per_step", "workgroups", "cu_share", "whole_step_achieved", "whole_step_frac")
+        r = {k: rf[k] for k in keep if k in rf}
+        r["whole_step"] = rf.get("whole_step")
+        # the three largest kernels of the step beside the dominant one
+        top = sorted(rf["kernels"].items(), key=lambda kv: -(kv[1]["share_of_step"] or 0))[:4]
+        r["top_kernels"] = {k: {"avg_us": v["avg_us"], "frac": v["frac"], "bound": v["bound"], "share_of_step": v["share_of_step"]} for k, v in top}
+        return r
+
     def brief(o, n):
-        return {"value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / n * 1e3, 3),
+        return {"roofline": brief_roofline(o.get("roofline")),
+                "value": round(o["value"], 2), "unit": "audio-sec/sec", "ms_per_step": round(o["elapsed"] / n * 1e3, 3),
                 "median_ms_per_step": round(o["median_ms_per_step"], 3), "chunks_per_step": o["B"], "steps_in_flight": o["inflight"],
                 "decoder_steps": o["dec_steps"], "cross_attention": o["cross_attention"], "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in o["stages"].items()}}
     if extra and headline:
-        o = run_config(args, "large-v3", 8, 3, 9, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        o = run_config(args, "large-v3", 8, 3, 9, 3, 1, 0, local_rank, dev, want_roofline=True, want_cpu=False, whole_chip_leg=False)
         other["round-1 headline configuration: whisper-large-v3, 8 x 30 s chunks per step, 3 steps in flight, greedy, 1 GPU"] = brief(o, 9)
         saved = args.sample_length
         args.sample_length = 64
-        o = run_config(args, "large-v3", 64, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        o = run_config(args, "large-v3", 64, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=True, want_cpu=False, whole_chip_leg=False)
         args.sample_length = saved
         other["whisper-large-v3, 64 chunks per step, 3 in flight, 64-token run (sampleLength 64, SURVEY 8d)"] = brief(o, 6)
-        o = run_config(args, "large-v3", 128, 3, 3, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        o = run_config(args, "large-v3", 128, 3, 3, 3, 1, 0, local_rank, dev, want_roofline=True, want_cpu=False, whole_chip_leg=False)
         other["whisper-large-v3, 128 chunks per step (four decoder batch tiles per session), 3 in flight = 384 chunks resident, greedy, 1 GPU"] = brief(o, 3)
-        other["configs[4] whisper-large-v3, 10 min audio in 30 s VAD chunks, temperature ladder forced once, 1 GPU"] = long_audio_config(args, local_rank)
+        la = long_audio_config(args, local_rank)
+        la["roofline"] = brief_roofline(la.pop("roofline_full", None))
+        other["configs[4] whisper-large-v3, 10 min audio in 30 s VAD chunks, temperature ladder forced once, 1 GPU"] = la
         _MODELS.pop("large-v3")[0].close()
     if extra and (args.model, args.batch) != ("tiny.en", 1):
-        o = run_config(args, "tiny.en", 1, 3, 9, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False)
+        o = run_config(args, "tiny.en", 1, 3, 9, 3, 1, 0, local_rank, dev, want_roofline=True, want_cpu=False, whole_chip_leg=False)
         other["configs[1] whisper-tiny.en, 1 x 30 s chunk per step, 3 in flight, greedy, 1 GPU"] = brief(o, 9)
     if extra and headline:
-        o = run_config(args, "small", 8, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=False, want_cpu=False, word_timestamps=True)
+        o = run_config(args, "small", 8, 3, 6, 3, 1, 0, local_rank, dev, want_roofline=True, want_cpu=False, word_timestamps=True, whole_chip_leg=False)
         other["configs[2] whisper-small, 8 x 30 s chunks, greedy + word-timestamp alignment (DTW), 3 in flight, 1 GPU"] = brief(o, 6)
     if rank == 0:
         B = args.batch
@@ -609,6 +665,9 @@ def main():
                        "chunks_per_step": total, "chunks_per_gpu": nl, "steps_per_device_batch": G, "device_batch_slots": main_cfg["slots"],
                        "parallelism": f"chunk-dp{world}", "decoder_steps": main_cfg["dec_steps"], "cross_attention": main_cfg["cross_attention"],
                        "steps_in_flight": main_cfg["inflight"] * G, "device_batches_in_flight": main_cfg["inflight"], "result_gather": gather_kind,
+                       "comm_world_size": comm_world, "comm_transport": comm_transport,
+                       "chunk_ranges_per_rank": [list(parallel_mod.partition_chunks(total, world, r)) for r in range(world)],
+                       "audio_sets": main_cfg["audio_sets"],
                        "serial_ms_per_step": round(main_cfg.get("serial_ms_per_step", 0.0), 3) or None,
                        "arith": "fp16 operands (decoder activations as f16 hi|lo pairs), fp32 accumulate/residual/softmax; mel fp32"},
             "rtf": round(main_cfg["elapsed"] / main_cfg["audio_s"], 6),

@@ -29,8 +29,9 @@ public final class HIPModel {
 }
 
 /// One decode session (= the reference's per-task `DecodingInputs`, Core/Models.swift:291-323) with the creation knobs of the C ABI:
-/// `wh_session_create_tuned` (cross-attention mode -1 automatic / 0 fp32 K / V rows / 1 weight-absorbed; key splits per slot of the
-/// absorbed form = the share of the CUs one session's cross-attention takes: 4 alone, 2 with several sessions in flight) and the window
+/// `wh_session_create_tuned` (cross-attention mode -1 automatic / 0 per-layer K / V rows, stored as 24-bit rows = Float16 + an 8-bit residual /
+/// 1 weight-absorbed over the encoder output; key splits per slot of the absorbed form = the share of the CUs one session's cross-attention
+/// takes: 4 for a lone session, 128 / slots with several sessions in flight - 1 at a 128-slot device batch, 2 at 64 slots) and the window
 /// hooks of TranscribeTask for the library's own orchestrator (`wh_session_set_window_hooks`: windowPreprocess / windowPostProcess /
 /// segmentDiscoveryCallback, Core/TranscribeTask.swift:42-55,130,246,260).
 public final class HIPSession {
@@ -39,7 +40,7 @@ public final class HIPSession {
     private var hookBox: Unmanaged<HookBox>?
 
     public enum CrossAttentionMode: Int32 { case automatic = -1, keyValueRows = 0, absorbed = 1 }
-    /// slots from which `.automatic` picks the absorbed path (wh_xabs_auto_min_slots: 48)
+    /// slots from which `.automatic` picks the absorbed path (wh_xabs_auto_min_slots: 28 since the K / V rows carry 24 bits; WH_XABS_MIN_SLOTS overrides)
     public static var absorbedFromSlots: Int { Int(wh_xabs_auto_min_slots()) }
 
     public init(model: HIPModel, maxBatch: Int = 1, crossAttention: CrossAttentionMode = .automatic, keySplits: Int = 0) throws {
@@ -52,6 +53,32 @@ public final class HIPSession {
     public var crossAttentionMode: CrossAttentionMode { CrossAttentionMode(rawValue: wh_session_cross_attention_mode(handle)) ?? .automatic }
     public var crossAttentionKeySplits: Int { Int(wh_session_cross_attention_splits(handle)) }
     public var capturedStepGraphs: Int { Int(wh_session_step_graph_count(handle)) }
+
+    /// WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) (Core/WhisperKit.swift:716-812) on the library's own orchestrator:
+    /// one `wh_decoding_options` per audio (nil = DecodingOptions()) and one Result per audio - a failing audio is `.failure` and does not
+    /// fail its neighbours (:786-790).  The transcription handles are owned by the caller (wh_transcription_free).
+    public func transcribeWithOptions(audioArrays: [[Float]], options: [wh_decoding_options?], specialTokens: wh_special_tokens) throws -> [Result<OpaquePointer, WhisperError>] {
+        guard audioArrays.count == options.count else { throw WhisperError.transcriptionFailed("The number of audio arrays and decoding options must be balanced.") }
+        let n = audioArrays.count
+        var st = specialTokens
+        var outs = [OpaquePointer?](repeating: nil, count: n)
+        var statuses = [Int32](repeating: 0, count: n)
+        var lens = audioArrays.map { Int32($0.count) }
+        let pcm = audioArrays.map { a -> UnsafeMutablePointer<Float> in
+            let p = UnsafeMutablePointer<Float>.allocate(capacity: max(a.count, 1)); p.initialize(from: a, count: a.count); return p
+        }
+        let optStore = UnsafeMutablePointer<wh_decoding_options>.allocate(capacity: max(n, 1))
+        defer { pcm.forEach { $0.deallocate() }; optStore.deallocate() }
+        var optPtrs = [UnsafePointer<wh_decoding_options>?](repeating: nil, count: n)
+        for i in 0..<n { if let o = options[i] { optStore[i] = o; optPtrs[i] = UnsafePointer(optStore + i) } }
+        var pcmPtrs = pcm.map { UnsafePointer<Float>?($0) }
+        try check(wh_transcribe_batch_with_options(handle, &pcmPtrs, &lens, Int32(n), &optPtrs, &st, &outs, &statuses))
+        return (0..<n).map { i in
+            if statuses[i] == WH_OK.rawValue, let t = outs[i] { return .success(t) }
+            let why = String(cString: wh_session_item_error(handle, Int32(i)))
+            return .failure(wh_session_item_status(handle, Int32(i)) == WH_ERR_AUDIO_PROCESSING_FAILED.rawValue ? .audioProcessingFailed(why) : .transcriptionFailed(why))
+        }
+    }
 
     final class HookBox {
         var pre: ((Int, UnsafeBufferPointer<Float>, Int, Int) -> Void)?

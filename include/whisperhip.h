@@ -440,15 +440,33 @@ int wh_session_set_tokenizer(wh_session* s, const wh_tokenizer* t);
 /* ---- TranscribeTask.run (Core/TranscribeTask.swift:57-296) --------------------------------------- */
 int wh_transcribe(wh_session* s, const float* pcm_host, int n_samples, const wh_decoding_options* opt,
                   const wh_special_tokens* st, wh_transcription** out);
-/* WhisperKit.transcribe(audioArrays:) (Core/WhisperKit.swift:716-812): independent audios/chunks, batched on device */
+/* WhisperKit.transcribe(audioArrays:) -> [[TranscriptionResult]?] (Core/WhisperKit.swift:660-688 over :716-812): independent audios /
+ * chunks with ONE options value, batched on the device.  Every audio carries its own Result as in the reference (`.failure(error)`,
+ * :786-790): an audio that fails leaves out[i] == NULL (the reference's nil) and does not fail its neighbours; its status and message stay
+ * readable through wh_session_item_status / wh_session_item_error until the session's next batch call.  The call itself returns non-zero
+ * only when nothing could run: a null argument, every audio failed (the first failing audio's status), a device error, cancellation. */
 int wh_transcribe_batch(wh_session* s, const float* const* pcm_host, const int32_t* n_samples, int n_audio,
                         const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out /* [n_audio] */);
+/* WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) -> [Result<[TranscriptionResult], Error>] (Core/WhisperKit.swift:716-812):
+ * opts[i] are the options of audio i (a NULL entry, or opts == NULL, = DecodingOptions()); statuses[i] (may be NULL) receives audio i's
+ * wh_status, out[i] its transcription or NULL.  Audios whose options differ only in their clip timestamps share lock-stepped device
+ * batches; audios with different decoding options run in groups, one group after the other (the reference runs one TranscribeTask per
+ * audio: grouping changes the batching, never a result).  Returns WH_OK whenever the per-audio results are valid - also when every audio
+ * failed - and non-zero for a null argument, a device error or cancellation. */
+int wh_transcribe_batch_with_options(wh_session* s, const float* const* pcm_host, const int32_t* n_samples, int n_audio,
+                                     const wh_decoding_options* const* opts /* [n_audio] or NULL */, const wh_special_tokens* st,
+                                     wh_transcription** out /* [n_audio] */, int32_t* statuses /* [n_audio] or NULL */);
+/* The Result of audio `audio_index` of the session's last wh_transcribe_batch / _with_options / wh_transcribe / wh_transcribe_chunked call:
+ * its wh_status, and the message of its error ("" when it succeeded; valid until the next such call on the session). */
+int wh_session_item_status(const wh_session* s, int audio_index);
+const char* wh_session_item_error(const wh_session* s, int audio_index);
 /* WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): audio longer than one window is
  * split by VADAudioChunker.chunkAll, the chunks are transcribed as independent audios (batched on the device, clipTimestamps
  * reset) and every segment / word is shifted by its chunk's seek offset (AudioChunking.updateSeekOffsetsForResults,
  * Core/Audio/AudioChunker.swift:14-39; TranscriptionUtilities.updateSegmentTimings, Utilities/TranscriptionUtilities.swift:55-69).
  * Writes one transcription per chunk into out[0..*n_out) (chunk order) and the chunks' seek offsets (samples) into
- * seek_offsets_out (may be NULL); returns WH_ERR_INVALID_ARGUMENT when more than `capacity` chunks are needed. */
+ * seek_offsets_out (may be NULL); returns WH_ERR_INVALID_ARGUMENT when more than `capacity` chunks are needed.  A chunk that fails is
+ * skipped as in updateSeekOffsetsForResults (`case .failure`: logged, not returned): *n_out counts the chunks that succeeded. */
 int wh_transcribe_chunked(wh_session* s, const float* pcm_host, int n_samples, const wh_decoding_options* opt,
                           const wh_special_tokens* st, wh_transcription** out, int capacity, int32_t* seek_offsets_out, int* n_out);
 void wh_transcription_free(wh_transcription* t);

@@ -1,6 +1,9 @@
-"""GPU parity at the configurations the benchmark TIMES, at full depth (VERDICT r02 "next round" item 1):
+"""GPU parity at the configurations the benchmark TIMES, at full depth (VERDICT r02 "next round" item 1; VERDICT r05 item 1):
 
-  * whisper-large-v3, 32 + 32 layers, 64 slots (two batch tiles of the decoder kernels) - BASELINE configs[3], the headline
+  * whisper-large-v3, 32 + 32 layers, 128 slots x 1 key split, filled as TWO packed 64-chunk steps - the device batch bench.py's headline
+    TIMES since round 5 (continuous batching: slots 0..63 = step k, 64..127 = step k + 1, each with its own audio, synth.bench_chunk_seed)
+  * whisper-large-v3, 56 slots x 2 key splits - the device batch of one GPU of the 8-GPU shape (7 packed steps of 8 chunks)
+  * whisper-large-v3, 32 + 32 layers, 64 slots x 2 key splits (two batch tiles of the decoder kernels) - BASELINE configs[3], the round-4 headline batch
   * whisper-small, 12 + 12 layers, 8 slots, word-timestamp alignment rows                - BASELINE configs[2]
   * whisper-tiny.en, 4 + 4 layers, 1 slot                                                - BASELINE configs[1]
 
@@ -44,7 +47,7 @@ from oracle import decode as OD
 from oracle import mel as omel
 from oracle.model import OracleWhisper
 from whisperkit_amd import api, weights
-from whisperkit_amd.synth import synthetic_chunk
+from whisperkit_amd.synth import bench_chunk_seed, synthetic_chunk
 
 pytestmark = pytest.mark.gpu
 
@@ -54,10 +57,14 @@ POSITIONS = [0, 1, 2, 3, 129, 222]
 
 # name -> (slots in the session, slots checked against the oracle, word timestamps)
 CONFIGS = {
+    "large-v3@128x1": (128, [0, 63, 64, 127], False),       # what bench.py TIMES: two packed 64-chunk steps, 1 key split per slot
+    "large-v3@56x2": (56, [0, 55], False),                  # one GPU's device batch of the 8-GPU shape: 7 packed steps of 8 chunks, 2 key splits
     "large-v3": (64, [0, 31, 32, 63], False),
     "small": (8, [0, 7], True),
     "tiny.en": (1, [0], False),
 }
+# configuration -> (architecture, chunks per packed step): slot k * chunks + b carries the chunk bench.py puts there (synth.bench_chunk_seed)
+PACKED = {"large-v3@128x1": ("large-v3", 64), "large-v3@56x2": ("large-v3", 8)}
 # word-timestamp heads: the (layer, head) sets published with the checkpoints (openai/whisper _ALIGNMENT_HEADS =
 # HF generation_config.alignment_heads) - the sparse sets a real model carries; the default "upper half of the layers, all
 # heads" would be 320 heads at large-v3
@@ -68,12 +75,14 @@ ALIGNMENT_HEADS = {
 }
 # end-to-end errors measured on MI355X when this test was written (profiles/r03_fulldepth_errors.json); asserted at 2 x
 E2E_MEASURED = {
+    "large-v3@128x1": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),      # (the 64-slot figures: the encoder is batch-invariant,
+    "large-v3@56x2": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),       #  the decoder differs by the combine order of the key splits)
     "large-v3": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),
     "small": dict(encoder_max=2.08e-3, encoder_mean=2.71e-4, logits_max=5.10e-4),
     "tiny.en": dict(encoder_max=1.43e-3, encoder_mean=1.42e-4, logits_max=4.47e-4),
 }
 # stage-isolated logits error against the fp32-K/V oracle (the Float16 rounding of the cached keys / values included), same rule
-STAGE_MEASURED = {"large-v3": 7.54e-4, "small": 5.17e-4, "tiny.en": 4.49e-4}
+STAGE_MEASURED = {"large-v3@128x1": 7.54e-4, "large-v3@56x2": 7.54e-4, "large-v3": 7.54e-4, "small": 5.17e-4, "tiny.en": 4.49e-4}
 # provisional ceilings used while a configuration has no measured value yet
 E2E_CEILING = dict(encoder_max=1e-1, encoder_mean=1e-2, logits_max=2e-2)
 
@@ -83,7 +92,7 @@ _REPORT = {}
 def _write_report():
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r05_fulldepth_errors.json"), "w") as f:
+    with open(os.path.join(out, "r06_fulldepth_errors.json"), "w") as f:
         json.dump(_REPORT, f, indent=1, sort_keys=True)
 
 
@@ -116,15 +125,18 @@ class FollowingSampler(OD.GreedyTokenSampler):
         return tok, lp
 
 
-# key splits per slot of the absorbed cross-attention in the configuration bench.py TIMES (64 slots, sessions in flight: 128 / slots = 2);
-# the realistic-statistics fixture of the same architecture (tests/test_gpu_realistic.py) keeps the library's choice for a lone session (4),
+# key splits per slot of the absorbed cross-attention, as bench.py asks for them with sessions in flight (128 / slots workgroups per launch:
+# 1 at the headline's 128-slot device batch, 2 at 64 slots and at the 56-slot batch of the 8-GPU shape); the split count fixes the summation
+# order of the combine (include/whisperhip.h, wh_session_create_tuned), so every timed (slots, splits) pair has its own full-depth run here.
+# The realistic-statistics fixture of the same architecture (tests/test_gpu_realistic.py) keeps the library's choice for a lone session (4),
 # tests/test_gpu_round4.py walks 1 .. 4 on a two-layer model
-BENCH_SPLITS = {"large-v3": 2}
+BENCH_SPLITS = {"large-v3@128x1": 1, "large-v3@56x2": 2, "large-v3": 2}
 
 
 class Rig:
-    def __init__(self, name, sd=None, tag=None, config=None, report=None, sample_length=None, mode=None, splits=None):
-        """sd / tag / config: another weight set on the same architecture (tests/test_gpu_realistic.py); default = the weights bench.py times"""
+    def __init__(self, name, sd=None, tag=None, config=None, report=None, sample_length=None, mode=None, splits=None, packed=None):
+        """sd / tag / config: another weight set on the same architecture (tests/test_gpu_realistic.py); default = the weights bench.py times.
+        packed = chunks per packed step: slot k * packed + b carries bench.py's chunk (b, packed step k) - the continuous-batching fill."""
         self.splits = splits
         t0 = time.time()
         torch.set_num_threads(min(32, os.cpu_count() or 1))              # the oracle's thread count (bench.py's cpu_baseline uses the same)
@@ -134,7 +146,8 @@ class Rig:
         self.sd = sd if sd is not None else weights.synthetic_state_dict(self.dims, seed=0)         # the weights bench.py times
         self.model = api.Model(self.dims, self.sd, alignment_heads=ALIGNMENT_HEADS[name])
         self.om = OracleWhisper(self.dims, self.sd, alignment_heads=ALIGNMENT_HEADS[name])
-        self.xs = [synthetic_chunk(1234 + b) for b in range(self.B)]       # bench.py's chunks
+        per = packed or self.B
+        self.xs = [synthetic_chunk(bench_chunk_seed(b % per, b // per)) for b in range(self.B)]       # bench.py's chunks (session 0's device batch)
         self.st, self.langs = OD.special_tokens_for_vocab(self.dims.n_vocab)
         self.ml = self.dims.is_multilingual
         kw = dict(**NOFALLBACK, wordTimestamps=self.word_ts, **({} if sample_length is None else {"sampleLength": sample_length}))
@@ -157,6 +170,7 @@ class Rig:
         self.align_tf = {b: self.sess.getAlignmentWeights(b) for b in self.check}
         self.report = (_REPORT if report is None else report).setdefault(self.name, {"slots": self.B, "checked_slots": self.check, "decoder_inputs": n_in,
                                                 "layers": [self.dims.n_audio_layer, self.dims.n_text_layer],
+                                                "fill": (f"{self.B // per} packed steps of {per} chunks (bench.py continuous batching)" if packed else "one step"),
                                                 "cross_attention": (f"absorbed, {self.sess.crossAttentionSplits} key splits per slot"
                                                                     if self.sess.crossAttentionMode == 1 else "per-layer K / V rows")})
         self.report["setup_s"] = round(time.time() - t0, 1)
@@ -171,7 +185,8 @@ class Rig:
 
 @pytest.fixture(scope="module", params=list(CONFIGS))
 def rig(request):
-    r = Rig(request.param, splits=BENCH_SPLITS.get(request.param))
+    arch, per = PACKED.get(request.param, (request.param, None))
+    r = Rig(arch, tag=request.param, config=CONFIGS[request.param], splits=BENCH_SPLITS.get(request.param), packed=per)
     yield r
     _write_report()
     r.sess.close(); r.model.close()

@@ -259,6 +259,21 @@ def test_two_ranks_on_one_gpu_rehearsal():
     # packed into one 2-slot device batch, records gathered through the C-ABI communicator
     assert line["scaling"] == "strong" and line["config"]["chunks_per_gpu"] == 1 and line["config"]["steps_per_device_batch"] == 2
     assert line["config"]["result_gather"].startswith("wh_comm_gather_records"), line["config"]["result_gather"]
+    assert line["config"]["comm_world_size"] == 2 and line["config"]["chunk_ranges_per_rank"] == [[0, 1], [1, 2]]
+    # ... and with TWO worker threads per rank (the F > 1 multi-rank path - per-worker batch plans, flattened gather order - had
+    # lost its only test when this rehearsal went to --inflight 1): 4 steps = one 2-step device batch per worker; bench.py itself asserts that
+    # every step's gathered records are complete and in chunk order on every rank, the dump shows the last step's
+    dump = os.path.join(root, "gpurun_out", "rehearsal_inflight2_records.json")
+    os.makedirs(os.path.dirname(dump), exist_ok=True)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29573", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--single-device",
+                        "--dist-backend", "gloo", "--model", "tiny.en", "--batch", "2", "--inflight", "2", "--no-cpu-baseline", "--no-roofline",
+                        "--no-other-configs", "--dump-records", dump], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["device_batches_in_flight"] == 2 and line["config"]["steps_per_device_batch"] == 2
+    recs = json.load(open(dump))
+    assert [r["chunk_index"] for r in recs] == [0, 1] and all(len(r["tokens"]) > 4 for r in recs)
 
 
 def test_float16_logits_reference_numerics_mode(micro_ml):

@@ -1,0 +1,131 @@
+"""Round-6 GPU tests.
+
+  * the batch entry points with one Result and one DecodingOptions PER AUDIO (VERDICT r05 "what's missing" 1):
+    WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) returns [Result<[TranscriptionResult], Error>] and an audio that fails
+    is `.failure(error)` beside its neighbours' `.success` (Core/WhisperKit.swift:716-812, the catch at :786-790);
+    transcribe(audioArrays:) maps the failures to nil (:660-688); the VAD-chunked path skips a failed chunk (Core/Audio/AudioChunker.swift:14-39);
+  * a Python exception raised inside the progress callback comes out of EVERY entry point that can run it.
+"""
+import numpy as np
+import pytest
+
+from whisperkit_amd import api, weights
+from whisperkit_amd.synth import synthetic_chunk
+
+pytestmark = pytest.mark.gpu
+
+NOFALLBACK = dict(firstTokenLogProbThreshold=None, logProbThreshold=None, compressionRatioThreshold=None, temperatureFallbackCount=0)
+
+
+@pytest.fixture(scope="module")
+def micro():
+    dims = weights.MODEL_DIMS["test-micro"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
+    yield dims, model
+    model.close()
+
+
+def _same(a, b):
+    return a.tokens == b.tokens and a.seeks == b.seeks and [(g.start, g.end, g.tokens) for g in a.segments] == [(g.start, g.end, g.tokens) for g in b.segments]
+
+
+def test_one_result_per_audio_a_failing_audio_does_not_fail_its_neighbours(micro):
+    dims, model = micro
+    sess = api.Session(model, 4)
+    a0, a1, a2 = synthetic_chunk(71), synthetic_chunk(72), np.concatenate([synthetic_chunk(73), synthetic_chunk(74)[:200000]])
+    base = api.DecodingOptions(**NOFALLBACK, sampleLength=12)
+    alone = [sess.transcribe([a], base)[0] for a in (a0, a1, a2)]
+    # audio 1 is asked for a clip that ends beyond its samples: its first window is fine, the second one starts at sample 480000 = the buffer
+    # size, where the reference's slice is empty, AudioProcessor.padOrTrimAudio returns nil and the task throws transcriptionFailed("Audio
+    # samples are nil") - audio 1 fails, after having shared a device batch with the others for a whole window
+    bad = api.DecodingOptions(**NOFALLBACK, sampleLength=12, clipTimestamps=(0.0, 35.0))
+    res = sess.transcribeWithOptions([a0, a1, a2], [base, bad, base])
+    assert isinstance(res[1], api.WhisperError) and res[1].code == 9 and "Audio samples are nil" in str(res[1])
+    assert _same(res[0], alone[0]) and _same(res[2], alone[2])                 # bit-identical to the audios transcribed alone
+    assert len(res[2].seeks) == 2
+    # the reference's transcribe(audioArrays:) -> [[TranscriptionResult]?]: the 30 s audios cannot hold a 35 s clip, the 42.5 s audio can
+    opt = sess.transcribe([a0, a1, a2], bad, optional=True)
+    assert opt[0] is None and opt[1] is None
+    assert opt[2] is not None and _same(opt[2], sess.transcribe([a2], bad)[0]) and opt[2].seeks[0] == 0 and max(opt[2].seeks) < 560000
+    with pytest.raises(api.WhisperError):
+        sess.transcribe([a0, a1, a2], bad)                                     # the default Python convenience raises the first failure
+    # every audio failing: the per-audio entry point still returns (one Result each), the shared-options one reports the failure
+    allbad = sess.transcribeWithOptions([a0, a1], [bad, bad])
+    assert all(isinstance(r, api.WhisperError) for r in allbad)
+    # the session is usable afterwards
+    assert _same(sess.transcribe([a0], base)[0], alone[0])
+    sess.close()
+
+
+def test_one_decoding_options_per_audio(micro):
+    """decodeOptionsArray: audios with different options run as different TranscribeTasks in the reference; here they form groups that share
+    device batches - a result never depends on its neighbours' options."""
+    dims, model = micro
+    sess = api.Session(model, 4)
+    xs = [synthetic_chunk(81 + i) for i in range(4)]
+    o_short = api.DecodingOptions(**NOFALLBACK, sampleLength=8)
+    o_long = api.DecodingOptions(**NOFALLBACK, sampleLength=20, withoutTimestamps=True)
+    o_clip = api.DecodingOptions(**NOFALLBACK, sampleLength=8, clipTimestamps=(5.0,))         # differs from o_short by its clip only: same group
+    opts = [o_short, o_long, o_clip, None]
+    alone = [sess.transcribe([x], o or api.DecodingOptions())[0] for x, o in zip(xs, opts)]
+    got = sess.transcribeWithOptions(xs, opts)
+    assert all(not isinstance(r, api.WhisperError) for r in got)
+    for g, a in zip(got, alone):
+        assert _same(g, a)
+    assert got[2].seeks == [80000] and got[0].seeks == [0]
+    assert len(got[1].tokens) > len(got[0].tokens)
+    with pytest.raises(api.WhisperError):
+        sess.transcribeWithOptions(xs, [o_short])                              # "must be balanced" (WhisperKit.swift:724-726)
+    # hooks see the caller's audio index whatever group the audio ran in
+    seen = []
+    sess.setWindowHooks(windowPreprocess=lambda ai, x, seek, size: seen.append((ai, seek)))
+    sess.transcribeWithOptions(xs, opts)
+    sess.setWindowHooks()
+    assert sorted(seen) == [(0, 0), (1, 0), (2, 80000), (3, 0)]
+    sess.close()
+
+
+def test_chunked_transcription_over_the_per_audio_batch_entry_point(micro):
+    """WhisperKit.transcribe(audioArray:) with .vad chunking hands the chunks to transcribeWithOptions and updateSeekOffsetsForResults keeps the
+    `.success` chunks (`case .failure`: logged and skipped - wh_transcribe_chunked compacts its output the same way).  The chunks of a healthy
+    audio all succeed: order and offsets as before the batch entry point learned per-audio results."""
+    dims, model = micro
+    sess = api.Session(model, 4)
+    audio = np.concatenate([synthetic_chunk(91), synthetic_chunk(92), synthetic_chunk(93)[:100000]])
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=10)
+    chunks = sess.transcribeChunked(audio, opts)
+    assert len(chunks) >= 2 and [o for o, _ in chunks] == sorted(o for o, _ in chunks) and chunks[0][0] == 0
+    cuts = api.vadChunkAll(audio, options=opts)
+    assert [o for o, _ in chunks] == [c0 for c0, _ in cuts]
+    for (off, r), (c0, c1) in zip(chunks, cuts):
+        alone = sess.transcribe([audio[c0:c1]], opts)[0]
+        assert r.tokens == alone.tokens
+    sess.close()
+
+
+def test_callback_exception_comes_out_of_every_entry_point_that_runs_the_callback(micro):
+    dims, model = micro
+    sess = api.Session(model, 5)
+    sess.padOrTrim(synthetic_chunk(95)); sess.logMelSpectrogram(1); sess.encodeFeatures(1); sess.prepareDecoderInputs(1)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=24)
+    prompt = sess.prefillPrompt(opts)
+
+    class Boom(Exception):
+        pass
+
+    def cb(*_a):
+        raise Boom("progress callback failed")
+    sess.setProgressCallback(cb)
+    with pytest.raises(Boom):
+        sess.decodeText(prompt, opts)
+    sess.prepareDecoderInputs(1)
+    with pytest.raises(Boom):
+        sess.decodeTextCustom(prompt, opts)
+    with pytest.raises(Boom):
+        sess.transcribe([synthetic_chunk(95)], opts)
+    # nothing is left behind for a later, unrelated call
+    sess.setProgressCallback(None)
+    sess.padOrTrim(synthetic_chunk(95)); sess.logMelSpectrogram(1); sess.encodeFeatures(1); sess.prepareDecoderInputs(1)
+    assert len(sess.decodeText(prompt, opts)[0].tokens) > 4
+    sess.detectLanguage(1)
+    sess.close()

@@ -178,6 +178,8 @@ SYMBOLS = {
     "wh_prefill_prompt": (I, [VP, POPT, PST, C.c_int32, PI32, I]),
     "wh_transcribe": (I, [VP, VP, I, POPT, PST, PVP]),
     "wh_transcribe_batch": (I, [VP, PVP, PI32, I, POPT, PST, PVP]),
+    "wh_transcribe_batch_with_options": (I, [VP, PVP, PI32, I, C.POINTER(POPT), PST, PVP, PI32]),
+    "wh_session_item_status": (I, [VP, I]), "wh_session_item_error": (C.c_char_p, [VP, I]),
     "wh_transcribe_chunked": (I, [VP, VP, I, POPT, PST, PVP, I, PI32, C.POINTER(I)]),
     "wh_transcription_free": (None, [VP]),
     "wh_transcription_n_segments": (I, [VP]),

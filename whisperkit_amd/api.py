@@ -17,7 +17,7 @@ import ctypes as C
 import dataclasses
 import math
 import weakref
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -505,6 +505,16 @@ class Session:
         if exc is not None:
             raise exc
 
+    def _guarded(self, fn, *args) -> int:
+        """Every library call that can run a callback thunk (progress callback, window hooks) goes through here: the stash is
+        cleared on entry, an exception raised inside a thunk is re-raised when the call returns and outranks the status it may have caused,
+        then the status is checked.  Returns the (zero) status."""
+        self._callback_error = None
+        rc = fn(*args)
+        self._raise_pending()
+        _check(rc)
+        return rc
+
     def setTokenizer(self, tokenizer: Optional["Tokenizer"]):
         """TextDecoding.tokenizer (Core/TextDecoder.swift:61): transcribe results gain text, real word grouping, language code."""
         self.tokenizer = tokenizer      # keep it alive
@@ -683,15 +693,13 @@ class Session:
         act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
         res = (L.WhDecodingResult * batch)()
         if languageTokens is None:
-            _check(self.lib.wh_decode_text(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
-                                           temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res))
+            self._guarded(self.lib.wh_decode_text, self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                          temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res)
         else:
             lt = np.ascontiguousarray(languageTokens, dtype=np.int32)
             assert len(lt) == batch
-            _check(self.lib.wh_decode_text_languages(self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
-                                                     lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF),
-                                                     None if act is None else act.ctypes.data_as(L.PI32), seed, res))
-        self._raise_pending()            # an exception raised inside the progress callback
+            self._guarded(self.lib.wh_decode_text_languages, self.handle, batch, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                          lt.ctypes.data_as(L.PI32), temps.ctypes.data_as(L.PF), None if act is None else act.ctypes.data_as(L.PI32), seed, res)
         return [DecodingResult.from_c(r) for r in res]
 
     def decodeTextCustom(self, prompt: Sequence[int], options: DecodingOptions, logitsFilters: Sequence = (), sampler=None,
@@ -732,11 +740,14 @@ class Session:
                 return 1
         samp = L.TOKEN_SAMPLER_FN(samp_tramp) if sampler is not None else L.TOKEN_SAMPLER_FN()
         res = L.WhDecodingResult()
+        self._callback_error = None
         rc = self.lib.wh_decode_text_custom(self.handle, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
                                             options.temperature if temperature is None else temperature, seed,
                                             table if fns else None, None, len(fns), samp, None, C.byref(res))
         if errors:
+            self._callback_error = None
             raise errors[0]
+        self._raise_pending()            # the progress callback runs inside this loop as well
         _check(rc)
         return DecodingResult.from_c(res)
 
@@ -750,8 +761,8 @@ class Session:
         p = np.ascontiguousarray(list(prompt), dtype=np.int32)
         lt = None if languageTokens is None else np.ascontiguousarray(languageTokens, dtype=np.int32)
         res = (L.WhDecodingResult * nAudio)()
-        _check(self.lib.wh_decode_text_beam(self.handle, nAudio, beamSize, patience, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
-                                            None if lt is None else lt.ctypes.data_as(L.PI32), res))
+        self._guarded(self.lib.wh_decode_text_beam, self.handle, nAudio, beamSize, patience, C.byref(o), C.byref(st), p.ctypes.data_as(L.PI32), len(p),
+                      None if lt is None else lt.ctypes.data_as(L.PI32), res)
         return [DecodingResult.from_c(r) for r in res]
 
     def setAlignmentPostprocess(self, zNormalize: bool = False, medianFilterWidth: int = 0):
@@ -805,24 +816,48 @@ class Session:
         st = specialTokens if specialTokens is not None else self.model.specialTokens
         lt = (C.c_int32 * batch)()
         lp = (C.c_float * batch)()
-        _check(self.lib.wh_detect_language(self.handle, batch, C.byref(st), lt, lp))
+        self._guarded(self.lib.wh_detect_language, self.handle, batch, C.byref(st), lt, lp)
         return list(lt), list(lp)
 
     # ---- TranscribeTask.run / WhisperKit.transcribe(audioArrays:)
-    def transcribe(self, audioArrays: Sequence[np.ndarray], options: Optional[DecodingOptions] = None, specialTokens=None) -> List[TranscriptionResult]:
+    def transcribeWithOptions(self, audioArrays: Sequence[np.ndarray], decodeOptionsArray: Optional[Sequence[Optional[DecodingOptions]]] = None,
+                              specialTokens=None) -> List[Union[TranscriptionResult, WhisperError]]:
+        """WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) (Core/WhisperKit.swift:716-812): one DecodingOptions per audio (None =
+        DecodingOptions()) and one Result per audio - entry i is audio i's TranscriptionResult or the WhisperError it failed with; a failing
+        audio does not fail its neighbours (`.failure(error)`, :786-790).  Raises only when the call itself could not run (mismatched
+        counts as in :724-726, device error, cancellation, an exception raised inside a callback)."""
+        n = len(audioArrays)
+        if decodeOptionsArray is None:
+            decodeOptionsArray = [None] * n
+        if len(decodeOptionsArray) != n:
+            raise WhisperError(9, "The number of audio arrays and decoding options must be balanced.")
         st = specialTokens if specialTokens is not None else self.model.specialTokens
-        o = (options or DecodingOptions()).to_c()
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in audioArrays]
-        n = len(arrs)
+        keep = [(o or DecodingOptions()).to_c() for o in decodeOptionsArray]        # keeps the option structs and their arrays alive
+        optp = (L.POPT * n)(*[C.pointer(o) for o in keep])
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (C.c_int32 * n)(*[len(a) for a in arrs])
         outs = (C.c_void_p * n)()
-        self._callback_error = None
-        rc = self.lib.wh_transcribe_batch(self.handle, ptrs, lens, n, C.byref(o), C.byref(st), outs)
-        got = [_collect(h) for h in outs] if rc == 0 else None
-        self._raise_pending()            # an exception raised inside a hook / progress callback outranks the status it may have caused
-        _check(rc)
-        return got
+        stat = (C.c_int32 * n)()
+        self._guarded(self.lib.wh_transcribe_batch_with_options, self.handle, ptrs, lens, n, optp, C.byref(st), outs, stat)
+        return [_collect(outs[i]) if stat[i] == 0 else WhisperError(int(stat[i]), self.lib.wh_session_item_error(self.handle, i).decode()) for i in range(n)]
+
+    def transcribeWithResults(self, audioArrays: Sequence[np.ndarray], options: Optional[DecodingOptions] = None, specialTokens=None):
+        """WhisperKit.transcribeWithResults(audioArrays:decodeOptions:) (Core/WhisperKit.swift:693-706): the same options for every audio."""
+        return self.transcribeWithOptions(audioArrays, [options] * len(audioArrays), specialTokens)
+
+    def transcribe(self, audioArrays: Sequence[np.ndarray], options: Optional[DecodingOptions] = None, specialTokens=None,
+                   optional: bool = False) -> List[Optional[TranscriptionResult]]:
+        """WhisperKit.transcribe(audioArrays:) (Core/WhisperKit.swift:660-688).  optional=True is the reference's return type,
+        [[TranscriptionResult]?]: None for an audio that failed.  The default raises the first failing audio's WhisperError (the Python
+        convenience the tests of rounds 1 - 5 were written against)."""
+        res = self.transcribeWithResults(audioArrays, options, specialTokens)
+        if optional:
+            return [None if isinstance(r, WhisperError) else r for r in res]
+        for r in res:
+            if isinstance(r, WhisperError):
+                raise r
+        return res
 
     def transcribeChunked(self, audioArray: np.ndarray, options: Optional[DecodingOptions] = None, specialTokens=None):
         """WhisperKit.transcribe(audioArray:) with chunkingStrategy .vad (Core/WhisperKit.swift:867-931): returns
@@ -834,12 +869,8 @@ class Session:
         outs = (C.c_void_p * cap)()
         seeks = (C.c_int32 * cap)()
         n = C.c_int()
-        self._callback_error = None
-        rc = self.lib.wh_transcribe_chunked(self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n))
-        got = [(int(seeks[i]), _collect(outs[i])) for i in range(n.value)] if rc == 0 else None
-        self._raise_pending()
-        _check(rc)
-        return got
+        self._guarded(self.lib.wh_transcribe_chunked, self.handle, a.ctypes.data, len(a), C.byref(o), C.byref(st), outs, cap, seeks, C.byref(n))
+        return [(int(seeks[i]), _collect(outs[i])) for i in range(n.value)]
 
 
 # ---- host utilities (no GPU needed) ---------------------------------------------------------------

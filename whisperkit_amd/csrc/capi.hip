@@ -213,7 +213,10 @@ static int build_xabs(wh_model* m) {
     if (e != hipSuccess) return set_error(WH_ERR_HIP, "hipMalloc(%zu) for the absorbed cross-attention weights failed: %s", bytes, hipGetErrorString(e));
     Carver c; c.base = (char*)m->xabs_blob;
     std::vector<wh::XabsLayerW> tiles(L);
+    // a private non-blocking stream: the build may run while other sessions of this model are decoding, and a device-wide synchronisation
+    // on the null stream would wait for all of their work with the model's lock held
     hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { hipFree(m->xabs_blob); m->xabs_blob = nullptr; return set_error(WH_ERR_HIP, "stream for the absorbed cross-attention weights"); }
     for (size_t l = 0; l < L; ++l) {
         const f16* wk = m->ckv_w + (l * 2 * d) * d;
         const f16* wv = m->ckv_w + (l * 2 * d + d) * d;
@@ -222,7 +225,8 @@ static int build_xabs(wh_model* m) {
         tiles[l].bv = m->ckv_b + l * 2 * d + d;
     }
     hipError_t le = hipGetLastError();
-    if (le == hipSuccess) le = hipDeviceSynchronize();
+    if (le == hipSuccess) le = hipStreamSynchronize(st);
+    hipStreamDestroy(st);
     if (le != hipSuccess) {         // nothing half-built stays behind: the next absorbed session tries again
         hipFree(m->xabs_blob);
         m->xabs_blob = nullptr;

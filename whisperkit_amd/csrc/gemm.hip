@@ -571,7 +571,10 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
             gemm256_kernel<EPI, MODE><<<(unsigned)tiles256, 512, 131072, st>>>(a);
         };
         if constexpr (kHasStagedEpilogue<EPI>) {
-            const bool shape_ok = a.N % 64 == 0 && a.M % 4 == 0 && a.ldc % 8 == 0 && a.d_model % 64 == 0;
+            // the staged epilogues store uint4 / float4 vectors: every output base must be 16-byte aligned (hipMalloc bases + multiples of 8
+            // elements today; an offset view handed in by a future caller falls back to the direct epilogue instead of faulting - ADVICE r05)
+            const bool aligned = (((uintptr_t)a.out16 | (uintptr_t)a.out32 | (uintptr_t)a.k16 | (uintptr_t)a.vt16) & 15) == 0;
+            const bool shape_ok = aligned && a.N % 64 == 0 && a.M % 4 == 0 && a.ldc % 8 == 0 && a.d_model % 64 == 0;
             if (shape_ok && epi_mode == 1) { go(std::integral_constant<int, 1>{}); return; }
             if (shape_ok && epi_mode == 2) { go(std::integral_constant<int, 2>{}); return; }
         }

@@ -639,6 +639,9 @@ extern "C" int wh_find_seek_point_and_segments(const wh_decoding_result* res, co
 
 struct AudioJob {
     const float* pcm; int n;
+    int index = 0;                                  // position of the audio in the caller's batch (hook argument, item status)
+    const wh_decoding_options* opt = nullptr;       // this audio's options (clip timestamps are per audio; everything else is shared by its group)
+    int status = WH_OK; std::string error;          // Result<[TranscriptionResult], Error> of this audio (WhisperKit.swift:786-790)
     std::vector<std::pair<int, int>> clips;
     size_t clip = 0; int seek = 0; bool started = false; bool finished = false;
     int windows = 0;
@@ -668,7 +671,8 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
     const int detect = opt->detect_language < 0 ? !opt->use_prefill_prompt : opt->detect_language;
     const double t_start = now_s();
     const double cf_start = cf_absolute_time();
-    for (auto& j : jobs) { j.clips = prepare_seek_clips(opt, j.n); j.tr->timings.input_audio_seconds = (double)j.n / WH_SAMPLE_RATE - (double)(opt->n_clip_timestamps > 0 && opt->clip_timestamps ? opt->clip_timestamps[0] : 0.0f);
+    for (auto& j : jobs) { const wh_decoding_options* jo = j.opt ? j.opt : opt;      // clip timestamps belong to the audio, not to its group
+                          j.clips = prepare_seek_clips(jo, j.n); j.tr->timings.input_audio_seconds = (double)j.n / WH_SAMPLE_RATE - (double)(jo->n_clip_timestamps > 0 && jo->clip_timestamps ? jo->clip_timestamps[0] : 0.0f);
                           j.tr->timings.pipeline_start = cf_start; }
     // temperature ladder in FloatType (TranscribeTask.swift:327)
     std::vector<float> temps;
@@ -683,21 +687,29 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
     std::vector<int> slot_job;   // job index per slot for the current round
     while (true) {
         // gather up to B jobs that still have a window (each job contributes one window per round: windows of one audio are sequential)
+        // A window whose padOrTrim fails (TranscribeTask.swift:126-127 throws audioProcessingFailed) fails ITS audio only: the audio leaves the
+        // batch with its status and message, its neighbours go on (the reference wraps every audio in its own Result, WhisperKit.swift:786-790).
         slot_job.clear();
-        for (size_t ji = 0; ji < jobs.size() && (int)slot_job.size() < round_cap; ++ji)
-            if (!jobs[ji].finished && job_next_window(jobs[ji], opt)) slot_job.push_back((int)ji);
-        if (slot_job.empty()) break;
-        const int nb = (int)slot_job.size();
         CHECK_CANCEL(s);
         double t0 = now_s();
-        for (int b = 0; b < nb; ++b) {
-            AudioJob& j = jobs[slot_job[b]];
-            int r = wh_set_audio(s, b, j.pcm + j.cur_seek, j.cur_size);   // padOrTrim (TranscribeTask.swift:126-127)
-            if (r) return r;
+        for (size_t ji = 0; ji < jobs.size() && (int)slot_job.size() < round_cap; ++ji) {
+            AudioJob& j = jobs[ji];
+            if (j.finished || j.status != WH_OK || !job_next_window(j, opt)) continue;
+            const int b = (int)slot_job.size();
+            // a window without samples: the reference slices audioArray[seek ..< seek + segmentSize], AudioProcessor.padOrTrimAudio returns nil for
+            // the empty slice ("startIndex is outside the buffer size", Core/Audio/AudioProcessor.swift:151-155) and the task throws
+            // transcriptionFailed("Audio samples are nil") (Core/TranscribeTask.swift:126-129) - a clip that ends beyond the samples gets here
+            int r = j.cur_size > 0 ? wh_set_audio(s, b, j.pcm + j.cur_seek, j.cur_size)
+                                   : set_error(WH_ERR_TRANSCRIPTION_FAILED, "audio %d: Audio samples are nil (window start %d is outside the buffer size %d)", j.index, j.cur_seek, j.n);
+            if (r == WH_ERR_HIP) return r;                                 // the device is gone: every audio of the group fails
+            if (r) { j.status = r; j.error = wh_last_error(); j.finished = true; continue; }
+            slot_job.push_back((int)ji);
             if (s->hooks.window_preprocess)                                // TranscribeTask.windowPreprocess (:130)
-                s->hooks.window_preprocess(s->hooks.user, slot_job[b], j.pcm + j.cur_seek, j.cur_seek, j.cur_size);
+                s->hooks.window_preprocess(s->hooks.user, j.index, j.pcm + j.cur_seek, j.cur_seek, j.cur_size);
             j.tr->seeks.push_back(j.cur_seek);
         }
+        if (slot_job.empty()) break;
+        const int nb = (int)slot_job.size();
         double t1 = now_s();
         int r = wh_log_mel_spectrogram(s, nb); if (r) return r;
         hipStreamSynchronize(s->st);
@@ -781,10 +793,10 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
             if (tr->timings.total_decoding_windows > windows_before) {      // the window had segments (`guard let currentSegments`, :239-242)
                 int n_new = (int)tr->segments.size() - seg_before;
                 if (s->hooks.window_postprocess) {                         // TranscribeTask.windowPostProcess (:246-250)
-                    const int keep = s->hooks.window_postprocess(s->hooks.user, slot_job[b], j.cur_seek, j.cur_size, tr, seg_before, n_new);
+                    const int keep = s->hooks.window_postprocess(s->hooks.user, j.index, j.cur_seek, j.cur_size, tr, seg_before, n_new);
                     if (keep >= 0 && keep < n_new) { whi::transcription_truncate_segments(tr, seg_before + keep); n_new = keep; }
                 }
-                if (s->hooks.segment_discovery) s->hooks.segment_discovery(s->hooks.user, slot_job[b], tr, seg_before, n_new);   // segmentDiscoveryCallback (:260)
+                if (s->hooks.segment_discovery) s->hooks.segment_discovery(s->hooks.user, j.index, tr, seg_before, n_new);   // segmentDiscoveryCallback (:260)
             }
             if (tr->timings.total_decoding_windows > windows_before) j.windows += 1;
             tr->timings.audio_processing += (t1 - t0) / nb; tr->timings.logmels += (t2 - t1) / nb; tr->timings.encoding += (t3 - t2) / nb;
@@ -795,33 +807,127 @@ static int transcribe_jobs(wh_session* s, std::vector<AudioJob>& jobs, const wh_
         }
     }
     for (auto& j : jobs) {
+        if (j.status != WH_OK) continue;
         wh_transcription* tr = j.tr;
         tr->timings.full_pipeline = now_s() - t_start;
-        int fr = wh_transcription_finalize(tr, s->tok, opt, st); if (fr) return fr;
+        int fr = wh_transcription_finalize(tr, s->tok, opt, st);
+        if (fr) { j.status = fr; j.error = wh_last_error(); }
     }
     return WH_OK;
 }
 
+// Two option sets may share a device batch when everything the lock-stepped loop reads is equal: all scalars and the prompt / prefix /
+// suppress token lists (NaN == NaN: both nil).  Clip timestamps are positions inside ONE audio and are applied per audio.
+static bool same_group_options(const wh_decoding_options& a, const wh_decoding_options& b) {
+    auto fe = [](float x, float y) { return (isnan(x) && isnan(y)) || x == y; };
+    auto le = [](const int32_t* x, int nx, const int32_t* y, int ny) {
+        const int ex = x ? nx : 0, ey = y ? ny : 0;
+        return (x == nullptr) == (y == nullptr) && ex == ey && (ex == 0 || memcmp(x, y, sizeof(int32_t) * (size_t)ex) == 0);
+    };
+    return a.task == b.task && a.language_token == b.language_token && fe(a.temperature, b.temperature) &&
+           fe(a.temperature_increment_on_fallback, b.temperature_increment_on_fallback) && a.temperature_fallback_count == b.temperature_fallback_count &&
+           a.sample_length == b.sample_length && a.top_k == b.top_k && a.use_prefill_prompt == b.use_prefill_prompt && a.detect_language == b.detect_language &&
+           a.skip_special_tokens == b.skip_special_tokens && a.without_timestamps == b.without_timestamps && a.word_timestamps == b.word_timestamps &&
+           fe(a.max_initial_timestamp, b.max_initial_timestamp) && a.max_window_seek == b.max_window_seek && fe(a.window_clip_time, b.window_clip_time) &&
+           le(a.prompt_tokens, a.n_prompt_tokens, b.prompt_tokens, b.n_prompt_tokens) && le(a.prefix_tokens, a.n_prefix_tokens, b.prefix_tokens, b.n_prefix_tokens) &&
+           a.suppress_blank == b.suppress_blank && le(a.suppress_tokens, a.n_suppress_tokens, b.suppress_tokens, b.n_suppress_tokens) &&
+           fe(a.compression_ratio_threshold, b.compression_ratio_threshold) && fe(a.log_prob_threshold, b.log_prob_threshold) &&
+           fe(a.first_token_log_prob_threshold, b.first_token_log_prob_threshold) && fe(a.no_speech_threshold, b.no_speech_threshold) && a.seed == b.seed &&
+           a.float16_logits == b.float16_logits && a.beam_size == b.beam_size && fe(a.beam_patience, b.beam_patience);
+}
+
+// WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) (Core/WhisperKit.swift:716-812): one DecodingOptions and one
+// Result<[TranscriptionResult], Error> per audio.  Audios whose options can share a lock-stepped device batch (same_group_options) form
+// a group; groups run one after the other (the reference runs one TranscribeTask per audio: grouping changes the batching, not a result).
+// A failure that belongs to one audio (bad buffer, a window outside the samples) fails that audio; a failure of a group's shared state
+// (invalid option combination, a device error) fails the group's audios; the other groups still run.
+static int transcribe_items(wh_session* s, const float* const* pcm, const int32_t* n_samples, int n_audio, const wh_decoding_options* const* opts,
+                            const wh_decoding_options* shared, const wh_special_tokens* st, wh_transcription** out, int32_t* statuses) {
+    wh_decoding_options dflt;
+    wh_decoding_options_default(&dflt);
+    s->item_status.assign((size_t)n_audio, WH_OK);
+    s->item_error.assign((size_t)n_audio, std::string());
+    std::vector<AudioJob> all((size_t)n_audio);
+    std::vector<int> group_of((size_t)n_audio, -1);
+    std::vector<const wh_decoding_options*> group_opt;
+    for (int i = 0; i < n_audio; ++i) {
+        AudioJob& j = all[(size_t)i];
+        j.index = i; j.pcm = pcm[i]; j.n = n_samples[i]; j.tr = nullptr;
+        j.opt = (opts && opts[i]) ? opts[i] : (shared ? shared : &dflt);
+        out[i] = nullptr;
+        if (j.n < 0 || (j.n > 0 && !j.pcm)) {
+            j.status = set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "audio %d: invalid buffer", i); j.error = wh_last_error();
+            continue;
+        }
+        int g = -1;
+        for (size_t k = 0; k < group_opt.size() && g < 0; ++k) if (same_group_options(*group_opt[k], *j.opt)) g = (int)k;
+        if (g < 0) { g = (int)group_opt.size(); group_opt.push_back(j.opt); }
+        group_of[(size_t)i] = g;
+    }
+    int hard = WH_OK;
+    for (size_t g = 0; g < group_opt.size(); ++g) {
+        std::vector<AudioJob> jobs;
+        for (int i = 0; i < n_audio; ++i) if (group_of[(size_t)i] == (int)g) { jobs.push_back(all[(size_t)i]); jobs.back().tr = new wh_transcription(); }
+        const int r = hard ? hard : transcribe_jobs(s, jobs, group_opt[g], st);       // after a device error nothing else can run
+        const std::string why = r ? wh_last_error() : "";
+        if (r == WH_ERR_HIP || r == WH_ERR_CANCELLED) hard = r;
+        for (auto& j : jobs) {
+            AudioJob& a = all[(size_t)j.index];
+            a.status = r ? r : j.status;
+            a.error = r ? why : j.error;
+            if (a.status == WH_OK) out[j.index] = j.tr; else delete j.tr;
+        }
+    }
+    int n_ok = 0, first_bad = WH_OK;
+    for (int i = 0; i < n_audio; ++i) {
+        const AudioJob& a = all[(size_t)i];
+        s->item_status[(size_t)i] = a.status; s->item_error[(size_t)i] = a.error;
+        if (statuses) statuses[i] = a.status;
+        if (a.status == WH_OK) ++n_ok; else if (first_bad == WH_OK) first_bad = a.status;
+    }
+    if (hard) return set_error(hard, "%s", s->item_error[0].empty() ? "wh_transcribe_batch: device failure" : s->item_error[0].c_str());
+    if (n_ok == 0 && !statuses) {       // a caller that did not ask for per-audio statuses still learns why nothing came back
+        for (int i = 0; i < n_audio; ++i) if (s->item_status[(size_t)i] == first_bad) return set_error(first_bad, "%s", s->item_error[(size_t)i].c_str());
+    }
+    return WH_OK;
+}
+
+extern "C" int wh_transcribe_batch_with_options(wh_session* s, const float* const* pcm, const int32_t* n_samples, int n_audio,
+                                                const wh_decoding_options* const* opts, const wh_special_tokens* st, wh_transcription** out,
+                                                int32_t* statuses) {
+    CHECK_SESSION(s);
+    if (!pcm || !n_samples || n_audio < 1 || !st || !out) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcribe_batch_with_options: null argument");
+    WH_TRY
+    return transcribe_items(s, pcm, n_samples, n_audio, opts, nullptr, st, out, statuses);
+    WH_CATCH("wh_transcribe_batch_with_options")
+}
+
+// WhisperKit.transcribe(audioArrays:) -> [[TranscriptionResult]?] (Core/WhisperKit.swift:660-688 over :716-812): ONE options value for every
+// audio; an audio that fails leaves out[i] == NULL (the reference's nil) and does not fail its neighbours; its status and message stay on
+// the session (wh_session_item_status / wh_session_item_error).  The call itself fails only when nothing could run (every audio failed,
+// the device is gone, cancellation).
 extern "C" int wh_transcribe_batch(wh_session* s, const float* const* pcm, const int32_t* n_samples, int n_audio,
                                    const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out) {
     CHECK_SESSION(s);
     if (!pcm || !n_samples || n_audio < 1 || !opt || !st || !out) return set_error(WH_ERR_TRANSCRIPTION_FAILED, "wh_transcribe_batch: null argument");
-    std::vector<AudioJob> jobs(n_audio);
-    for (int i = 0; i < n_audio; ++i) {
-        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return set_error(WH_ERR_AUDIO_PROCESSING_FAILED, "audio %d: invalid buffer", i);
-        jobs[i].pcm = pcm[i]; jobs[i].n = n_samples[i]; jobs[i].tr = new wh_transcription();
-    }
-    int r = transcribe_jobs(s, jobs, opt, st);
-    for (int i = 0; i < n_audio; ++i) {
-        if (r) { delete jobs[i].tr; out[i] = nullptr; } else out[i] = jobs[i].tr;
-    }
-    return r;
+    WH_TRY
+    return transcribe_items(s, pcm, n_samples, n_audio, nullptr, opt, st, out, nullptr);
+    WH_CATCH("wh_transcribe_batch")
+}
+
+extern "C" int wh_session_item_status(const wh_session* s, int audio_index) {
+    if (!s || audio_index < 0 || (size_t)audio_index >= s->item_status.size()) return WH_ERR_INVALID_ARGUMENT;
+    return s->item_status[(size_t)audio_index];
+}
+extern "C" const char* wh_session_item_error(const wh_session* s, int audio_index) {
+    if (!s || audio_index < 0 || (size_t)audio_index >= s->item_error.size()) return "";
+    return s->item_error[(size_t)audio_index].c_str();
 }
 
 extern "C" int wh_transcribe(wh_session* s, const float* pcm, int n, const wh_decoding_options* opt, const wh_special_tokens* st, wh_transcription** out) {
     const float* p[1] = {pcm};
     int32_t nn[1] = {n};
-    return wh_transcribe_batch(s, p, nn, 1, opt, st, out);
+    return wh_transcribe_batch(s, p, nn, 1, opt, st, out);          // one audio: its failure is the call's failure
 }
 
 extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, const wh_decoding_options* opt, const wh_special_tokens* st,
@@ -850,11 +956,16 @@ extern "C" int wh_transcribe_chunked(wh_session* s, const float* pcm, int n, con
     for (int i = 0; i < nc; ++i) { ptrs[i] = pcm + cs[i]; lens[i] = ce[i] - cs[i]; }
     int r = wh_transcribe_batch(s, ptrs.data(), lens.data(), nc, &chunked, st, out);
     if (r) return r;
+    int kept = 0;                                             // a chunk that failed is logged and skipped (AudioChunker.swift:19-37: `case .failure`)
     for (int i = 0; i < nc; ++i) {
+        if (!out[i]) continue;
         wh_transcription_apply_seek_offset(out[i], cs[i]);   // updateSeekOffsetsForResults
-        if (seek_offsets_out) seek_offsets_out[i] = cs[i];
+        wh_transcription* t = out[i];
+        out[i] = nullptr; out[kept] = t;
+        if (seek_offsets_out) seek_offsets_out[kept] = cs[i];
+        ++kept;
     }
-    *n_out = nc;
+    *n_out = kept;
     return WH_OK;
 }
 

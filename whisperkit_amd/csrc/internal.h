@@ -110,6 +110,9 @@ struct wh_session {
     wh_window_hooks hooks{};                 // TranscribeTask.windowPreprocess / windowPostProcess / segmentDiscoveryCallback
     bool skip_special_in_progress = false;
     int special_begin_in_progress = 1 << 30;
+    // per-audio Result of the last wh_transcribe_batch* call (WhisperKit.transcribeWithOptions returns one Result per audio, WhisperKit.swift:786-790)
+    std::vector<int> item_status;
+    std::vector<std::string> item_error;
 };
 
 namespace whi {

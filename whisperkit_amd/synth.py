@@ -20,6 +20,14 @@ def synthetic_chunk(seed: int, n: int = WINDOW_SAMPLES) -> np.ndarray:
     return np.clip(x, -1.0, 1.0).astype(np.float32)
 
 
+def bench_chunk_seed(chunk_index: int, audio_set: int = 0) -> int:
+    """Seed of chunk `chunk_index` of audio set `audio_set`.  bench.py cycles its run steps through a small pool of sets, so the packed steps
+    of one device batch and the sessions in flight carry DIFFERENT audio (VERDICT r05 "what's weak" 9: identical halves let the embedding
+    kernel read one row for two slots).  Set 0 keeps the seeds of rounds 1 - 5 (1234 + chunk index): the CPU baseline's token check and
+    tests/test_gpu_fulldepth.py use it."""
+    return 1234 + chunk_index + 1000 * audio_set
+
+
 # ------------------------------------------------------------------------------------------------ tokenizer fixture
 # Whisper language codes in openai/whisper token order (same set as Constants.languages, Core/Models.swift:1335-1449).
 LANGUAGE_CODES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta no th ur hr bg lt la mi "
