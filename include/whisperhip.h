@@ -206,9 +206,11 @@ int wh_session_max_batch(const wh_session* s);
    wh_prepare_decoder_inputs.  Fixed at creation: automatic = absorbed when the width supports it (512 / 768 / 1024 / 1280) and
    max_batch >= wh_xabs_auto_min_slots() (28; WH_XABS_MIN_SLOTS), or WH_XABS=0 / 1.  The choice is made from max_batch alone, so
    Session(m, 27) and Session(m, 28) run different kernels: both modes meet the 1e-3 relative logits contract against the fp32
-   model, bit-identity across batch sizes holds within a mode.  Mode 1 streams the encoder output once per SLOT: callers whose slots
-   share encoder outputs (beam search: beam_size slots per audio) should ask for mode 0 (wh_session_create_with_mode), whose rows
-   are shared through the L2.  Mode 1 reads the session's encoder output LIVE at every decoder step (mode 0 snapshots it into the K / V
+   model, bit-identity across batch sizes holds within a mode.  Slots that share an encoder output (beam search: beam_size slots per
+   audio) need no special request: mode 1 reads the shared tensor with cacheable loads then (the beams of an audio are dispatched back to
+   back onto one XCD) and measures the same as mode 0 with its 24-bit rows shared through the L2 - 250.2 vs 249.9 audio-s/s on
+   BASELINE configs[4] with beam = 5 (profiles/r06a_beam5_cross_attention_mode_ab_24bit_rows.jsonl) - so beam sessions take the
+   automatic choice like every other session.  Mode 1 reads the session's encoder output LIVE at every decoder step (mode 0 snapshots it into the K / V
    rows in wh_prepare_decoder_inputs): wh_encode_features / wh_set_encoder_output between wh_prepare_decoder_inputs and the last
    decoder step of a window change the results in mode 1 - the reference passes encoder_output_embeds to every call as well. */
 int wh_session_cross_attention_mode(const wh_session* s);

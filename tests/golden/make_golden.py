@@ -15,6 +15,10 @@ Outputs (all small, strided subsets of the full tensors; the stride is stored wi
   hf_mel_synth.npz        HF log-mel of the bench's synthetic chunk (seed 1234), frames ::7
   hf_model_micro.npz      HF encoder output rows ::25 and decoder logits[::13] for a teacher-forced
                           8-token sequence, `test-micro` dims, synthetic weights seed 0, mel = HF mel of jfk
+  hf_model_large_v3_l2.npz  (round 6; `python tests/golden/make_golden.py large`) the same at the HEADLINE width - `test-large-v3-l2`:
+                          d = 1280, 20 heads, 128 mel, V = 51866, 2 + 2 layers, synthetic weights seed 0 - encoder rows ::50, logits[::29]
+                          of 8 teacher-forced tokens, and the CROSS-ATTENTION WEIGHTS (HF output_attentions, eager attention) of the
+                          heads (layer 0, head 3) and (layer 1, head 17), frames ::3: the golden of the alignment (word-timestamp) path
 """
 import os
 import sys
@@ -27,6 +31,50 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 
 from whisperkit_amd import weights as W  # noqa: E402
 from whisperkit_amd.synth import synthetic_chunk  # noqa: E402
+
+
+def hf_model(dims, sd, attn="sdpa"):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(vocab_size=dims.n_vocab, num_mel_bins=dims.n_mels, d_model=dims.n_audio_state,
+                        encoder_layers=dims.n_audio_layer, encoder_attention_heads=dims.n_audio_head,
+                        decoder_layers=dims.n_text_layer, decoder_attention_heads=dims.n_text_head,
+                        encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
+                        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
+                        activation_function="gelu", scale_embedding=False, dropout=0.0, attention_dropout=0.0,
+                        activation_dropout=0.0, pad_token_id=50256, bos_token_id=50257, eos_token_id=50256,
+                        decoder_start_token_id=50257, attn_implementation=attn)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    missing, unexpected = model.load_state_dict(W.to_hf_state_dict(sd), strict=False)
+    assert not unexpected, unexpected
+    assert all("embed_positions" in m or "proj_out" in m for m in missing), missing
+    return model
+
+
+LARGE_HEADS = [(0, 3), (1, 17)]            # (decoder layer, head) whose cross-attention weights are kept
+
+
+def large():
+    """the headline width (VERDICT r05 "what's weak" 3: the oracle was pinned to HF at d = 128 only, the alignment path not at all)"""
+    import torch
+    from transformers import WhisperFeatureExtractor
+    jfk = np.load(os.path.join(HERE, "jfk_pcm16.npz"))["pcm16"].astype(np.float32) / 32768.0
+    dims = W.MODEL_DIMS["test-large-v3-l2"]
+    sd = W.synthetic_state_dict(dims, seed=0)
+    model = hf_model(dims, sd, attn="eager")           # eager attention returns the weights
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    mel = fe(jfk, sampling_rate=16000, return_tensors="pt")["input_features"]
+    tokens = [50258, 50259, 50360, 464, 1282, 50365, 2, 50401]   # <|sot|> <|en|> <|transcribe|> + text and timestamp ids of the 51866 vocabulary
+    with torch.no_grad():
+        enc = model.model.encoder(mel).last_hidden_state
+        out = model(input_features=mel, decoder_input_ids=torch.tensor([tokens]), output_attentions=True)
+    logits = out.logits[0]
+    xatt = np.stack([out.cross_attentions[l][0, h].numpy() for l, h in LARGE_HEADS])        # [2 heads][8 tokens][1500]
+    assert xatt.shape == (2, len(tokens), 1500) and np.allclose(xatt.sum(-1), 1.0, atol=1e-4)
+    np.savez_compressed(os.path.join(HERE, "hf_model_large_v3_l2.npz"), tokens=np.array(tokens, np.int32),
+                        enc_stride=np.int32(50), enc=enc[0, ::50].numpy().astype(np.float32),
+                        logit_stride=np.int32(29), logits=logits[:, ::29].numpy().astype(np.float32),
+                        heads=np.array(LARGE_HEADS, np.int32), xatt_stride=np.int32(3), xatt=xatt[:, :, ::3].astype(np.float32))
+    print("hf_model_large_v3_l2.npz written:", os.path.getsize(os.path.join(HERE, "hf_model_large_v3_l2.npz")), "bytes")
 
 
 def main():
@@ -79,4 +127,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["large"]:
+        large()
+    else:
+        main()
+        large()

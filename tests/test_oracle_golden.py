@@ -99,3 +99,30 @@ def test_forward_full_equals_stepped_decoder(jfk_pcm):
     sub = m.new_state(enc).forward_full(toks, logits_at=[0, 5, n - 1])
     assert sorted(sub) == [0, 5, n - 1]
     np.testing.assert_allclose(sub[5], full[5], atol=1e-6, rtol=0)
+
+
+def test_headline_width_encoder_decoder_and_alignment_rows_match_hf(jfk_pcm):
+    """VERDICT r05 "what's weak" 3: the oracle's model math was pinned to HF at d = 128 only and its alignment (cross-attention weight) output
+    not at all.  `test-large-v3-l2` is the headline width - d = 1280, 20 heads, 128 mel bands, V = 51866 - with 2 + 2 layers: encoder rows,
+    logits of 8 teacher-forced tokens and the cross-attention weights of two heads (HF output_attentions), which are the rows the decoder
+    writes into DecodingCache.alignmentWeights at tokenIndex + 1 (Core/TextDecoder.swift:272-296)."""
+    g = golden("hf_model_large_v3_l2.npz")
+    dims = W.MODEL_DIMS["test-large-v3-l2"]
+    heads = [tuple(int(v) for v in h) for h in g["heads"]]
+    m = OracleWhisper(dims, W.synthetic_state_dict(dims, seed=0), alignment_heads=heads)
+    mel = omel.log_mel_spectrogram(jfk_pcm, dims.n_mels).astype(np.float32)
+    enc = m.encode(mel)
+    assert enc.shape == (1500, 1280)
+    es, ls, xs = int(g["enc_stride"]), int(g["logit_stride"]), int(g["xatt_stride"])
+    np.testing.assert_allclose(enc[::es], g["enc"], atol=5e-4, rtol=0)
+    toks = [int(t) for t in g["tokens"]]
+    stepped, full = m.new_state(enc), m.new_state(enc)
+    out = full.forward_full(toks)
+    for pos, tok in enumerate(toks):
+        logits = stepped.step(tok, pos)
+        np.testing.assert_allclose(logits[::ls], g["logits"][pos], atol=5e-4, rtol=0)
+        np.testing.assert_allclose(out[pos][::ls], g["logits"][pos], atol=5e-4, rtol=0)
+        for st in (stepped, full):                              # row pos + 1 = the weights of the token fed at `pos`, per alignment head
+            for k in range(len(heads)):
+                np.testing.assert_allclose(st.alignment_heads[pos + 1, k, ::xs], g["xatt"][k, pos], atol=2e-6, rtol=0)
+            np.testing.assert_allclose(st.alignment[pos + 1, ::xs], g["xatt"][:, pos].mean(0), atol=2e-6, rtol=0)

@@ -450,8 +450,9 @@ class Session:
         """crossAttentionMode: None = the library's choice (absorbed from `xabsAutoMinSlots()` = 28 slots at the widths that support it: the
         choice looks at maxBatch only, so Session(m, 27) and Session(m, 28) run different kernels; both meet the 1e-3 relative logits
         contract), 0 = per-layer cross K / V rows (24-bit: Float16 + 8-bit residual), 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
-        Beam search (decodeTextBeam, DecodingOptions.beamSize): ask for 0 - the absorbed kernel streams the encoder output once per slot,
-        i.e. beamSize times per audio, while the K / V rows of an audio are shared by its beams.  Mode 1 reads the encoder output live
+        Beam search (decodeTextBeam, DecodingOptions.beamSize) takes the library's choice like any other session: the beams of an audio
+        share one encoder output, which mode 1 then reads with cacheable loads - 250.2 vs 249.9 audio-s/s against mode 0 on BASELINE
+        configs[4] (profiles/r06a_beam5_cross_attention_mode_ab_24bit_rows.jsonl).  Mode 1 reads the encoder output live
         at every decoder step: do not call encodeFeatures / setEncoderOutput between prepareDecoderInputs and the end of the decode.
         crossAttentionSplits: key splits per slot of the absorbed form (None = the library's choice): slots x splits workgroups each own a CU
         while they stream, so this is the share of the GPU the session's cross-attention takes - 4 for a session running alone, 2 when
