@@ -167,3 +167,21 @@ def test_headline_width_against_the_hf_golden_logits_and_cross_attention_weights
     print("headline-width HF golden: mode -> (encoder rows, logits, alignment rows) max abs err", report)
     for mode, (e_enc, e_log, e_al) in report.items():
         assert e_enc <= 5e-3 and e_log <= 1e-3 and e_al <= 1e-4, report
+
+
+def test_persistent_gemm_tile_loop_is_bit_identical_to_one_workgroup_per_tile():
+    """csrc/gemm.hip, round 6: gemm256p_kernel (WH_GEMM_PERSIST=1: one workgroup per CU loops over tiles, the next tile's first K-tile is requested
+    under the epilogue, the staged epilogues move to [64 KB, 160 KB) of the LDS) must produce the encoder output of gemm256_kernel bit for bit -
+    ragged M, a partial 256-column tile at width 384, every staged epilogue (tools/enc_epi_ab.py, quick cases)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for persist in ("0", "1"):
+        env = dict(os.environ, PYTHONPATH=root, WH_GEMM_PERSIST=persist, WH_EPI_AB_QUICK="1")
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "enc_epi_ab.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        got[persist] = {k: v for k, v in json.loads(p.stdout.strip().splitlines()[-1]).items() if k != "mode"}
+    assert got["0"] == got["1"] and len(got["0"]) >= 4, got

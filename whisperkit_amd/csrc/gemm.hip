@@ -12,6 +12,7 @@
 //
 // gemm256_kernel (below) is the large-problem path; since round 5 its row-major epilogues turn the tile through the dead LDS stages
 // so that store instructions write whole 128-byte lines (epi_stage.h; bit-identical outputs, encoder 2.79 -> 2.57 ms per chunk).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -555,6 +556,196 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- persistent tile loop (round 6; opt-in: WH_GEMM_PERSIST=1)
+// gemm256_kernel as a loop over tiles: one workgroup per CU walks its XCD's share of the grouped tile order, and the first K-tile of tile
+// i + 1 is requested (LDS-DMA into stage 0, dead since the K loop's last barrier) BEFORE the epilogue of tile i runs, so the store
+// acknowledgements of a tile, the workgroup launch, the address set-up and the first DMA's latency of the next one no longer sit between two
+// tiles' matrix work.  The staged epilogues turn their passes through [64 KB, 160 KB) - stage 1 plus the 32 KB of the CU's LDS that the two
+// stages leave free, 12 KB per wave (a pass needs 9 216 bytes) - so they never touch the stage the prefetch lands in; the next tile's K-tile 1
+// goes into stage 1 only after the barrier that follows every wave's epilogue.  The arithmetic of a tile is gemm256_kernel's, instruction for
+// instruction: the outputs are the same bits (encoder-output MD5s of 7 width / slot cases equal, profiles/r06d_*).
+//
+// MEASURED, AND NOT FASTER (profiles/r06d_encoder_time_persist*.jsonl, 128 chunks): encoder 2.538 -> 2.531 ms per chunk (qkv 1773 -> 1753, out
+// projection 782 -> 812, fc1 2669 -> 2624, fc2 2342 -> 2366 us): the tile boundary was not what the K loop waits for.  The same kernel then served
+// as the probe that says what is (profiles/r06e_*; `probe` argument, WH_GEMM_STAGGER): per 64-wide K-tile and CU the loop takes ~4 800 cycles
+// for 2 048 cycles of matrix work; with the operand fetch removed from the loop (probe -1, garbage results) ~3 000 (the X / Y slot structure:
+// fragment reads + barriers); with the fetch issued but never waited for (probe -2) ~4 000.  So of the 1 800 cycles the fetch costs, ~1 000 are
+// interference of the LDS-DMA stream with the loop (the landing 64 KB per K-tile share the LDS with 192 KB of fragment reads) and ~800 are the
+// wait itself; staggering the workgroups that share a panel by 0.05 .. 1 us (so that followers find the leader's lines resident in the L2) and
+// re-shaping the XCD's resident tile block from 8 x 4 to 4 x 8, 2 x 16, 1 x 32 (m x n tiles: who shares what) change nothing (+- 1 %).  The
+// next step for this GEMM is therefore fewer LDS bytes per matrix instruction (one wave per SIMD with 128 x 128 wave tiles and 512 registers, or
+// weight fragments from global memory in fragment order), not its boundary.  Default stays one workgroup per tile.
+constexpr int kPersistWaveRegion = 12288;      // 8 waves x 12 KB = [64 KB, 160 KB)
+static_assert(64 * epi::kRow16 <= kPersistWaveRegion && 32 * epi::kRow32 <= kPersistWaveRegion && 32 * epi::kRowT <= kPersistWaveRegion, "a pass fits the wave's slice");
+template <int EPI, int MODE>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int n_tiles, int stagger, int GM) {
+    constexpr int TM = 4, TN = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [2 stages][A 32 KB | B 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // XCD x (= id % 8) owns the contiguous range [lo, lo + cnt) of the grouped tile order (the ranges of gemm256_kernel); its workgroups
+    // (gridDim / 8 of them) take the range's tiles round robin, so an XCD's resident workgroups sit on neighbouring tiles at any time
+    const int orig = blockIdx.x, xcd = orig & 7, q = n_tiles >> 3, r = n_tiles & 7;
+    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+    const int per_xcd = gridDim.x >> 3;
+    int it = orig >> 3;
+    if (it >= cnt) return;
+    // A/B probe (WH_GEMM_STAGGER, default 0): the workgroups of an XCD that share a weight panel (local ids j .. j + 7) or an A panel (j, j + 8, ...) start
+    // `stagger` x 64 cycles apart, so that a panel's lines are resident in the L2 when the followers ask for them instead of pending behind the leader's miss
+    if (stagger > 0) {
+        const int rank = (it & 7) * 4 + ((it >> 3) & 3);
+        for (int i = 0; i < rank * stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    const int tiles_n = (a.N + 255) >> 8, tiles_m = (a.M + 255) >> 8;
+    int m0, n0;               // GM: m-tiles per group of the walk (GM x tiles_n tiles, m fastest): an XCD's 32 resident tiles are GM m-tiles x 32 / GM n-tiles
+    auto tile_origin = [&](int wg, int& m0_, int& n0_) {
+        const int gsz = GM * tiles_n, grp = wg / gsz, first_m = grp * GM;
+        const int gm = min(tiles_m - first_m, GM), in_g = wg - grp * gsz;
+        m0_ = (first_m + in_g % gm) << 8; n0_ = (in_g / gm) << 8;
+    };
+    const int srow = tid >> 3;
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const f16* src[8];      // pieces 0..3: A rows j*64 + srow, 4..7: W rows
+    auto set_src = [&](int m0_, int n0_) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(m0_ + j * 64 + srow, a.M - 1);
+            src[j] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + chunk * 8;
+            const int n = min(n0_ + j * 64 + srow, a.N - 1);
+            src[4 + j] = a.W + (long long)n * a.K + chunk * 8;
+        }
+    };
+    tile_origin(lo + it, m0, n0);
+    set_src(m0, n0);
+    auto piece = [&](int p, int kt) {
+        unsigned char* dst = smem + (kt & 1) * 65536 + wave * 1024 + (p >> 2) * 32768 + (p & 3) * 8192;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
+    const int a_row_off = (wm * 128 + fr) * 128, b_row_off = 32768 + (wn * 64 + fr) * 128;
+    const int nk = a.K >> 6;
+#define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_XBAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_VMWAIT() do { __builtin_amdgcn_sched_barrier(0); if (stagger != -2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)      /* (stagger -2: timing probe that never waits for its operands, garbage results) */
+    bool have_next = false;
+    int m0n = 0, n0n = 0;
+    auto body = [&](auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        f16x8 af[2][TM], bf[2][TN];
+        auto X = [&](int kt, int h) {
+            const unsigned char* sb = smem + (kt & 1) * 65536;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int slot = ((2 * (2 * h + s2) + fh) ^ swz) * 16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[s2][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 4096 + slot);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[s2][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
+            }
+        };
+        auto Y = [&](auto dma_tag, int dma_kt) {   // 16 MFMAs; DMA: the wave's 8 LDS-DMA pieces of K-tile dma_kt go out among them
+            constexpr bool DMA = decltype(dma_tag)::value;
+            __builtin_amdgcn_s_setprio(1);      // the matrix cluster outranks the partner wave's fetch slot
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+                    }
+                    if constexpr (DMA) { __builtin_amdgcn_sched_barrier(0); if (stagger != -1) piece(s2 * 4 + i, dma_kt); __builtin_amdgcn_sched_barrier(0); }   // (stagger < 0: fetch-ablation probe, garbage results)
+                }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        constexpr std::true_type kDma{};
+        constexpr std::false_type kNoDma{};
+        // prologue: K-tile 0 (all waves) - requested by the previous tile's tail (or before the loop) - landed and visible; the barrier also
+        // ends every wave's epilogue of the previous tile: stage 1 is free for K-tile 1 from here on
+        PP_VMWAIT();
+        PP_BAR();
+        if (wm == 0) {
+            for (int t = 0; t + 1 < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kDma, t + 1); PP_BAR();
+                X(t, 1); PP_XBAR();
+                Y(kNoDma, 0); PP_VMWAIT(); PP_BAR();
+            }
+            X(nk - 1, 0); PP_XBAR();
+            Y(kNoDma, 0); PP_BAR();
+            X(nk - 1, 1); PP_XBAR();
+            Y(kNoDma, 0); PP_BAR();
+            PP_BAR();
+        } else {
+            if (nk > 1) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) piece(p, 1);
+            }
+            PP_BAR();
+            for (int t = 0; t + 2 < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
+                X(t, 1); PP_VMWAIT(); PP_XBAR();
+                Y(kDma, t + 2); PP_BAR();
+            }
+            for (int t = max(nk - 2, 0); t < nk; ++t) {
+                X(t, 0); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
+                X(t, 1); PP_VMWAIT(); PP_XBAR();
+                Y(kNoDma, 0); PP_BAR();
+            }
+        }
+        // every wave is past its last fragment read and its last LDS-DMA wait here (both precede the final barrier): the stages are dead.
+        // The next tile's first K-tile goes out now, under this tile's epilogue.
+        const int m0c = m0, n0c = n0;
+        {
+            const int nx = it + per_xcd;
+            have_next = nx < cnt;
+            if (have_next) {
+                tile_origin(lo + nx, m0n, n0n);
+                set_src(m0n, n0n);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) piece(p, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (MODE == 1 && kHasStagedEpilogue<EPI>) {
+            unsigned char* wl = smem + 65536 + wave * kPersistWaveRegion;
+            if constexpr (!SWAP) epi_staged_vt(a, acc, wl, m0c + wm * 128, n0c + wn * 64, lane);
+            else if constexpr (EPI == EPI_RESID_F32) epi_staged_resid(a, acc, wl, m0c + wm * 128, n0c + wn * 64, lane);
+            else epi_staged_f16<EPI>(a, acc, wl, m0c + wm * 128, n0c + wn * 64, lane);
+        } else if constexpr (SWAP) gemm_epilogue_swapped<EPI, TM, TN, MODE == 2>(a, acc, m0c + wm * 128, n0c + wn * 64, lane);
+        else gemm_epilogue<EPI, TM, TN>(a, acc, m0c + wm * 128, n0c + wn * 64, lane);
+    };
+#undef PP_BAR
+#undef PP_XBAR
+#undef PP_VMWAIT
+#pragma unroll
+    for (int p = 0; p < 8; ++p) piece(p, 0);              // the first tile's first K-tile
+    while (true) {
+        if constexpr (EPI == EPI_QKV_ENC) {
+            if (n0 + wn * 64 >= 2 * a.d_model) body(std::false_type{});
+            else body(std::true_type{});
+        } else {
+            body(std::true_type{});
+        }
+        if (!have_next) break;                             // (workgroup-uniform)
+        it += per_xcd; m0 = m0n; n0 = n0n;
+    }
+}
+
 template <int EPI>
 static void launch_epi(const GemmArgs& a, hipStream_t st) {
     // large problems: 256 x 256 x 64 LDS-DMA kernel (needs whole 64-wide K tiles and 16-byte aligned rows)
@@ -564,8 +755,24 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
         // measured and rejected (profiles/r02s_*): staggering the first-round workgroups by up to a tile time to spread the store
         // epilogues of the 256 CUs over each other's K loops - no change (1476 vs 1475 us, large-v3 fc1 at 64 chunks)
         static const int epi_mode = [] { const char* e = getenv("WH_GEMM_EPI_MODE"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+        // WH_GEMM_PERSIST=1: the persistent tile loop (gemm256p_kernel: one workgroup per CU, the next tile's first K-tile requested under the epilogue;
+        // bit-identical, measured no faster: the comment above the kernel); default 0 = one workgroup per tile (rounds 2 - 5).
+        // WH_GEMM_PERSIST_WGS: workgroups of the persistent grid (default = the CUs, a multiple of 8: a smaller grid confines the encoder to that many CUs)
+        static const int persist = [] { const char* e = getenv("WH_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
+        static const int persist_wgs = [] { const char* e = getenv("WH_GEMM_PERSIST_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
         auto go = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
+            if (persist) {
+                static PerDeviceOnce raised_p;
+                static int cus = 256;
+                raised_p.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                                  int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) cus = n / 8 * 8; });
+                const int grid = (int)std::min<long long>(persist_wgs ? persist_wgs : cus, (tiles256 + 7) / 8 * 8);
+                static const int stagger = [] { const char* e = getenv("WH_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+                static const int gm_env = [] { const char* e = getenv("WH_GEMM_GM"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
+                gemm256p_kernel<EPI, MODE><<<(unsigned)grid, 512, 163840, st>>>(a, (int)tiles256, stagger, gm_env);
+                return;
+            }
             static PerDeviceOnce raised;
             raised.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
             gemm256_kernel<EPI, MODE><<<(unsigned)tiles256, 512, 131072, st>>>(a);
