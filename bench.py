@@ -9,19 +9,22 @@ encoder -> cross-K/V projection -> greedy token loop (WhisperKit decodeText sema
 findSeekPointAndSegments per chunk on the host -> result records (+ all-gather over RCCL when N > 1).
 
 Default workload = BASELINE.json configs[3]'s model and chunk set: whisper-large-v3 (128 mel), 64 x 30 s chunks per step, greedy.  The engine
-batches continuously: TWO consecutive 64-chunk steps share one 128-slot device batch (four 32-slot MFMA batch tiles per decode launch: the
-decoder's weight stream and its latency-bound launch chain are paid once per 128 windows), and 3 device batches are in flight (one session / HIP
-stream / host thread each: the encoder GEMMs and the projection kernels of one batch run in the gaps of the HBM-bound cross-attention stream of
-the others).  `--device-batch 64` is the round-4 configuration (one step per batch).  Measured on one MI355X (profiles/r05a_*, r05d_*):
-64-slot batches x 3 in flight 2350 audio-s/s, 128 x 3 2647, 128 x 2 2569, 192 x 3 2470, 256 x 3 2584, 256 x 2 2609.  Weights are random-init (no checkpoints in
+batches continuously: FOUR consecutive 64-chunk steps share one 256-slot device batch (eight 32-slot MFMA batch tiles per decode launch: the
+decoder's weight stream and its latency-bound launch chain are paid once per 256 windows; a workgroup of the HBM-bound cross-attention streams
+two slots one after the other, so that launch still takes 128 workgroups = half of the CUs), and 3 device batches are in flight (one session /
+HIP stream / host thread each: the encoder GEMMs and the projection kernels of one batch run beside the cross-attention stream of the others) -
+12 steps = 768 chunks are resident on the GPU, and a step is a unit of THROUGHPUT: one 64-chunk step alone takes `serial_ms_per_step`.
+`--device-batch 128` is the round-5 configuration (two steps per batch), `--device-batch 64` round 4's.  Measured on one MI355X: 64-slot batches x 3
+in flight 2350 audio-s/s, 128 x 3 2647 - 2660, 256 x 3 with 256 workgroups per launch 2584 - 2692 (profiles/r05a_*, r05d_*), 256 x 3 with two slots per
+workgroup 2749 (profiles/r06i_*).  Weights are random-init (no checkpoints in
 the image), so EOT is never the argmax and the loop runs to the reference's length cap (sampleLength 224 -> 223 decoder forward
 passes per chunk): the decode length is fixed and comparable across runs.  Round 1's configuration (8 chunks per step, 3 in
-flight) and the other BASELINE configs are measured after the headline and reported under "other_configs".
+flight) and the other BASELINE configs are measured after the headline and reported under "other_configs", each with its own `roofline`.
 
 N > 1 (configs[3]: "64 x 30 s chunks sharded across 8 x MI355X"): STRONG scaling by default - a step is still 64 chunks in total,
 block-partitioned over the ranks (64 / N per GPU, no data-path collective), the per-chunk result records of every step are
 all-gathered through the C-ABI communicator (wh_comm_*: ncclAllGather over xGMI, librccl dlopen'ed by libwhisperhip).  A GPU packs
-its shares of up to G consecutive steps into one device batch of at most 128 slots (continuous batching, as at one GPU; never more steps
+its shares of up to G consecutive steps into one device batch of at most 256 slots (continuous batching, as at one GPU; never more steps
 than a session's share of the run: plan_batches); `--scaling weak` is the old mode (64 chunks per step AND GPU).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
@@ -46,8 +49,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
-AUDIO_SETS = 6             # distinct chunk sets a run cycles through (3 device batches in flight x 2 packed steps)
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"
+AUDIO_SETS = 8             # distinct chunk sets a run cycles through (the 4 packed steps of a device batch carry 4 different sets, consecutive batches differ)
 T_START = time.perf_counter()
 
 
@@ -219,7 +222,11 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     # sessions in flight: the cross-attention of one session takes about half of the 256 CUs (slots x splits = 128 workgroups), the other
     # sessions' kernels keep the rest (64 slots x 3: 2049 -> 2270 audio-s/s against 4 splits, 128 slots x 3: 2240 -> 2537; profiles/r04ad..af)
     xsplits = args.cross_attention_splits if args.cross_attention_splits >= 0 else (max(1, min(4, 128 // max(slots, 1))) if F > 1 else 0)
-    sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None) for _ in range(F)]
+    # ... and beyond 128 slots a workgroup streams several slots one after the other, so the launch stays at 128 workgroups (round 6,
+    # wh_session_options.cross_attention_slots_per_workgroup: 256-slot batches x 2 slots per workgroup 2749 audio-s/s against 2660 with 128-slot batches
+    # and 2692 with 256 workgroups per launch, profiles/r06i_*)
+    xspw = args.cross_attention_slots_per_workgroup if args.cross_attention_slots_per_workgroup > 0 else (max(1, slots * max(xsplits, 1) // 128) if F > 1 else 1)
+    sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None, crossAttentionSlotsPerWorkgroup=xspw) for _ in range(F)]
     sess = sessions[0]
     # host float32 PCM: a pool of AUDIO_SETS chunk sets; step n of a run (steps numbered worker by worker, batch by batch: the order the records are
     # gathered in) carries set n % AUDIO_SETS, so the packed steps of a device batch and the sessions in flight carry DIFFERENT audio (VERDICT r05
@@ -328,7 +335,8 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     lat = [l for _, l in durs]
     durs = [d for d, _ in durs]
     out = {"value": audio_s / elapsed, "elapsed": elapsed, "audio_s": audio_s, "dec_steps": dec_steps[0], "B": B, "inflight": F,
-           "cross_attention": (f"absorbed, {sess.crossAttentionSplits} key splits per slot ({slots * sess.crossAttentionSplits} workgroups = CUs per launch)"
+           "cross_attention": (f"absorbed, {sess.crossAttentionSplits} key splits per slot, {sess.crossAttentionSlotsPerWorkgroup} slot(s) per workgroup "
+                               f"({-(-slots // sess.crossAttentionSlotsPerWorkgroup) * sess.crossAttentionSplits} workgroups = CUs per launch)"
                                if sess.crossAttentionMode == 1 else "per-layer K / V rows"),
            "total": total, "n_local": n_local, "steps_per_batch": G, "slots": slots, "audio_sets": n_sets,
            "median_step_latency_ms": float(np.median(lat)) * 1e3, "median_ms_per_step": float(np.median(durs)) * 1e3 / Fe, "n_median": int(len(durs))}
@@ -371,19 +379,22 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         if ns:
             # the cross-attention takes slots x splits workgroups, one per CU: with several sessions in flight it is configured to leave CUs to
             # the other sessions' kernels.  The same kernel with 4 splits (the whole chip at 64 slots) is timed beside it, alone on the GPU.
-            rf["workgroups"] = slots * ns
-            rf["cu_share"] = round(min(1.0, slots * ns / 256.0), 3)
-            if ns != 4 and whole_chip_leg:
-                s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=4)
+            spw = max(1, sess.crossAttentionSlotsPerWorkgroup)
+            rf["slots_per_workgroup"] = spw
+            rf["workgroups"] = -(-slots // spw) * ns
+            rf["cu_share"] = round(min(1.0, rf["workgroups"] / 256.0), 3)
+            if (ns != 4 or spw != 1) and whole_chip_leg:
+                s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=4, crossAttentionSlotsPerWorkgroup=max(1, slots * 4 // 256))
                 for k in range(G):
                     for b, x in enumerate(audio[k % n_sets]):
                         s4.padOrTrim(x, k * n_local + b)
                 s4.logMelSpectrogram(slots); s4.encodeFeatures(slots); s4.prepareDecoderInputs(slots)
                 s4.decodeText(prompt, opts, batch=slots)          # (wh_measure_kernels re-arms the slot state the last decodeText left)
                 r4 = measure_kernels(s4, dims, slots, 16, dec_steps[0], model_name, steps_per_batch=G)
+                s4_spw = max(1, s4.crossAttentionSlotsPerWorkgroup)
                 s4.close()
                 k4 = r4["kernels"]["dec_cross_attn"]
-                rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "workgroups": slots * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
+                rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "slots_per_workgroup": s4_spw, "workgroups": -(-slots // s4_spw) * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
                                                               "achieved": k4["achieved"], "unit": k4["unit"], "frac": k4["frac"]}
                 # (the same figures as scalars: a reader that keeps only the flat keys of `roofline` still carries them)
                 rf["whole_chip_splits"], rf["whole_chip_avg_us"], rf["whole_chip_achieved"], rf["whole_chip_frac"] = 4, k4["avg_us"], k4["achieved"], k4["frac"]
@@ -525,8 +536,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="30 s chunks per step (one decode batch = batch / 32 MFMA batch tiles): in total over the GPUs "
                     "with --scaling strong (BASELINE configs[3]: 64 chunks sharded across the GPUs), per GPU with --scaling weak")
     ap.add_argument("--device-batch", type=int, default=-1, help="slots of one device batch: the rank's shares of consecutive steps are packed into batches of "
-                    "at most this many chunks (continuous batching; one session holds at most 256 windows, no gain was measured beyond 128).  -1 = automatic: 128 when a step has >= 64 chunks (two "
-                    "64-chunk steps per batch at one GPU: the decoder's weight stream is shared by four batch tiles), else --batch (one step per batch)")
+                    "at most this many chunks (continuous batching; one session holds at most 256 windows).  -1 = automatic: 256 when a step has >= 64 chunks (four "
+                    "64-chunk steps per batch at one GPU: the decoder's weight stream and launch chain are shared by eight batch tiles, a cross-attention workgroup streams two slots), "
+                    "else --batch (one step per batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: strong = --batch chunks per step in total, block-partitioned "
                     "over the ranks (SURVEY 8d c4; the default); weak = --batch chunks per step and GPU")
     ap.add_argument("--gather", choices=["wh_comm", "torch"], default="wh_comm", help="N > 1: result-record all-gather through the C-ABI communicator "
@@ -534,6 +546,8 @@ def main():
     ap.add_argument("--cross-attention-splits", type=int, default=-1, help="key splits per slot of the absorbed cross-attention = the share of the CUs one "
                     "session's cross-attention takes (wh_session_create_tuned): -1 = 128 / slots (2 at 64 slots) when several device batches are in "
                     "flight (the other sessions' kernels keep half of the chip; profiles/r04ad_*, r04ae_*), the library's choice (4) for one")
+    ap.add_argument("--cross-attention-slots-per-workgroup", type=int, default=-1, help="slots one workgroup of the absorbed cross-attention streams one after the other "
+                    "(wh_session_options): -1 = slots x splits / 128 with several device batches in flight (the launch stays at 128 workgroups: 2 at 256 slots), 1 for one")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")
@@ -602,7 +616,7 @@ def main():
         comm_transport = "rccl" if comm.lib.wh_comm_transport(comm.handle) == comm._L.COMM_RCCL else "tcp"
     else:
         comm_transport = "torch.distributed" if world > 1 else "none"
-    dev_batch = args.device_batch if args.device_batch > 0 else (128 if args.batch >= 64 else args.batch)
+    dev_batch = args.device_batch if args.device_batch > 0 else (256 if args.batch >= 64 else args.batch)
     main_cfg = run_config(args, args.model, args.batch, args.inflight, args.steps, args.warmup, world, rank, local_rank, dev,
                           want_roofline=not args.no_roofline, want_cpu=(world == 1 and not args.no_cpu_baseline), comm=comm, scaling=args.scaling,
                           device_batch=dev_batch)

@@ -43,15 +43,28 @@ public final class HIPSession {
     /// slots from which `.automatic` picks the absorbed path (wh_xabs_auto_min_slots: 28 since the K / V rows carry 24 bits; WH_XABS_MIN_SLOTS overrides)
     public static var absorbedFromSlots: Int { Int(wh_xabs_auto_min_slots()) }
 
-    public init(model: HIPModel, maxBatch: Int = 1, crossAttention: CrossAttentionMode = .automatic, keySplits: Int = 0) throws {
+    /// slotsPerWorkgroup (wh_session_options, round 6): a workgroup of the absorbed cross-attention streams this many slots one after the other, so a
+    /// launch takes ceil(batch / n) x keySplits workgroups whatever the batch (256-slot device batches, 1 split, 2 slots per workgroup = half of the
+    /// chip: what bench.py keeps in flight three times); 0 = automatic (1).  Results do not depend on it, bit for bit.
+    public init(model: HIPModel, maxBatch: Int = 1, crossAttention: CrossAttentionMode = .automatic, keySplits: Int = 0, slotsPerWorkgroup: Int = 0) throws {
         var h: OpaquePointer?
-        try check(wh_session_create_tuned(model.handle, Int32(maxBatch), crossAttention.rawValue, Int32(keySplits), &h))
+        if slotsPerWorkgroup > 0 {
+            var o = wh_session_options()
+            wh_session_options_default(&o)
+            o.cross_attention_mode = crossAttention.rawValue
+            o.cross_attention_splits = Int32(keySplits)
+            o.cross_attention_slots_per_workgroup = Int32(slotsPerWorkgroup)
+            try check(wh_session_create_with_options(model.handle, Int32(maxBatch), &o, &h))
+        } else {
+            try check(wh_session_create_tuned(model.handle, Int32(maxBatch), crossAttention.rawValue, Int32(keySplits), &h))
+        }
         handle = h!; self.model = model
     }
     deinit { wh_session_set_window_hooks(handle, nil); hookBox?.release(); wh_session_destroy(handle) }
 
     public var crossAttentionMode: CrossAttentionMode { CrossAttentionMode(rawValue: wh_session_cross_attention_mode(handle)) ?? .automatic }
     public var crossAttentionKeySplits: Int { Int(wh_session_cross_attention_splits(handle)) }
+    public var crossAttentionSlotsPerWorkgroup: Int { Int(wh_session_cross_attention_slots_per_workgroup(handle)) }
     public var capturedStepGraphs: Int { Int(wh_session_step_graph_count(handle)) }
 
     /// WhisperKit.transcribeWithOptions(audioArrays:decodeOptionsArray:) (Core/WhisperKit.swift:716-812) on the library's own orchestrator:

@@ -226,6 +226,24 @@ int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_
    (64 slots: 256 workgroups), 2 when several sessions are in flight on the GPU (the other sessions' kernels keep the other half;
    profiles/r04ad_*).  Ignored in K / V-row mode. */
 int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
+/* ... and, since round 6, every creation knob in one struct (zero-initialise or wh_session_options_default; NULL = defaults):
+     cross_attention_mode                 -1 automatic, 0 K / V rows, 1 absorbed          (as wh_session_create_with_mode)
+     cross_attention_splits               0 automatic, 1 .. 4 key splits per slot          (as wh_session_create_tuned)
+     cross_attention_slots_per_workgroup  0 automatic (1), 1 .. 16: a workgroup of the absorbed cross-attention streams this many slots one
+                                          after the other, so a launch takes ceil(batch / n) x splits workgroups = CUs whatever the batch.
+                                          A process that keeps several sessions in flight gives every session's cross-attention about half of
+                                          the chip (128 workgroups): with 256-slot device batches that is 1 split and 2 slots per workgroup
+                                          (bench.py: 2660 -> 2749 audio-s/s against 128-slot batches, profiles/r06i_*).  A slot is processed
+                                          exactly as by a workgroup of its own: results do not depend on this number, bit for bit. */
+typedef struct wh_session_options {
+    int32_t cross_attention_mode;
+    int32_t cross_attention_splits;
+    int32_t cross_attention_slots_per_workgroup;
+    int32_t reserved_[5];
+} wh_session_options;
+void wh_session_options_default(wh_session_options* out);
+int wh_session_create_with_options(wh_model* m, int max_batch, const wh_session_options* opt, wh_session** out);
+int wh_session_cross_attention_slots_per_workgroup(const wh_session* s);      /* 0 in K / V-row mode */
 /* development aid (kernel bring-up, tools/xabs_check.py): the first nbytes of a named decode-step device buffer ("q", "zb_hi", ...);
    nbytes beyond the buffer's size is WH_ERR_INVALID_ARGUMENT */
 int wh_debug_peek(wh_session* s, const char* name, void* out_host, size_t nbytes);

@@ -325,11 +325,12 @@ def test_swift_shim_source_names_the_session_entry_points_of_the_header():
     declared = set(re.findall(r"\b(wh_[a-z0-9_]+)\s*\(", header))
     code = "\n".join(l.split("//")[0] for l in swift.splitlines())                     # calls in code, not in comments
     called = set(re.findall(r"\b(wh_[a-z0-9_]+)\s*\(", code))
-    types = {"wh_special_tokens", "wh_decoding_options", "wh_decoding_result", "wh_window_hooks", "wh_dims", "wh_timings", "wh_progress"}
+    types = {"wh_special_tokens", "wh_decoding_options", "wh_decoding_result", "wh_window_hooks", "wh_dims", "wh_timings", "wh_progress", "wh_session_options"}
     assert called - types <= declared, sorted(called - types - declared)
     for fn in ("wh_session_create_tuned", "wh_session_set_window_hooks", "wh_xabs_auto_min_slots", "wh_session_cross_attention_mode",
                "wh_session_cross_attention_splits", "wh_session_step_graph_count",
-               "wh_transcribe_batch_with_options", "wh_session_item_status", "wh_session_item_error"):       # round 6: one Result per audio
+               "wh_transcribe_batch_with_options", "wh_session_item_status", "wh_session_item_error",        # round 6: one Result per audio
+               "wh_session_create_with_options", "wh_session_options_default", "wh_session_cross_attention_slots_per_workgroup"):
         assert fn in called, fn
     # the shim's comments quote the library's behaviour: they went stale once ("48 slots", "fp32 K / V rows")
     from whisperkit_amd import _lib

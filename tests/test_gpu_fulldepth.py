@@ -1,7 +1,9 @@
 """GPU parity at the configurations the benchmark TIMES, at full depth (VERDICT r02 "next round" item 1):
 
-  * whisper-large-v3, 32 + 32 layers, 128 slots x 1 key split, filled as TWO packed 64-chunk steps - the device batch bench.py's headline
-    TIMES since round 5 (continuous batching: slots 0..63 = step k, 64..127 = step k + 1, each with its own audio, synth.bench_chunk_seed)
+  * whisper-large-v3, 32 + 32 layers, 256 slots x 1 key split x 2 slots per cross-attention workgroup, filled as FOUR packed 64-chunk steps - the
+    device batch bench.py's headline TIMES since round 6 (continuous batching: slots 64 k .. 64 k + 63 = step n + k, each with its own audio,
+    synth.bench_chunk_seed; a workgroup streams slot b and then slot b + 128)
+  * whisper-large-v3, 128 slots x 1 key split, two packed steps - the round-5 headline batch (`bench.py --device-batch 128`)
   * whisper-large-v3, 56 slots x 2 key splits - the device batch of one GPU of the 8-GPU shape (7 packed steps of 8 chunks)
   * whisper-large-v3, 32 + 32 layers, 64 slots x 2 key splits (two batch tiles of the decoder kernels) - BASELINE configs[3], the round-4 headline batch
   * whisper-small, 12 + 12 layers, 8 slots, word-timestamp alignment rows                - BASELINE configs[2]
@@ -57,14 +59,17 @@ POSITIONS = [0, 1, 2, 3, 129, 222]
 
 # name -> (slots in the session, slots checked against the oracle, word timestamps)
 CONFIGS = {
-    "large-v3@128x1": (128, [0, 63, 64, 127], False),       # what bench.py TIMES: two packed 64-chunk steps, 1 key split per slot
+    "large-v3@256x1s2": (256, [0, 127, 128, 255], False),   # what bench.py TIMES: four packed 64-chunk steps, 1 key split per slot, 2 slots per workgroup
+    "large-v3@128x1": (128, [0, 63, 64, 127], False),       # the round-5 headline batch: two packed 64-chunk steps, 1 key split per slot
     "large-v3@56x2": (56, [0, 55], False),                  # one GPU's device batch of the 8-GPU shape: 7 packed steps of 8 chunks, 2 key splits
     "large-v3": (64, [0, 31, 32, 63], False),
     "small": (8, [0, 7], True),
     "tiny.en": (1, [0], False),
 }
 # configuration -> (architecture, chunks per packed step): slot k * chunks + b carries the chunk bench.py puts there (synth.bench_chunk_seed)
-PACKED = {"large-v3@128x1": ("large-v3", 64), "large-v3@56x2": ("large-v3", 8)}
+PACKED = {"large-v3@256x1s2": ("large-v3", 64), "large-v3@128x1": ("large-v3", 64), "large-v3@56x2": ("large-v3", 8)}
+# slots per workgroup of the absorbed cross-attention (wh_session_options; results must not depend on it: the batch-invariance test decodes the last slot alone)
+BENCH_SPW = {"large-v3@256x1s2": 2}
 # word-timestamp heads: the (layer, head) sets published with the checkpoints (openai/whisper _ALIGNMENT_HEADS =
 # HF generation_config.alignment_heads) - the sparse sets a real model carries; the default "upper half of the layers, all
 # heads" would be 320 heads at large-v3
@@ -75,6 +80,7 @@ ALIGNMENT_HEADS = {
 }
 # end-to-end errors measured on MI355X when this test was written (profiles/r03_fulldepth_errors.json); asserted at 2 x
 E2E_MEASURED = {
+    "large-v3@256x1s2": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),
     "large-v3@128x1": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),      # (the 64-slot figures: the encoder is batch-invariant,
     "large-v3@56x2": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),       #  the decoder differs by the combine order of the key splits)
     "large-v3": dict(encoder_max=2.40e-3, encoder_mean=3.28e-4, logits_max=7.32e-4),
@@ -82,7 +88,7 @@ E2E_MEASURED = {
     "tiny.en": dict(encoder_max=1.43e-3, encoder_mean=1.42e-4, logits_max=4.47e-4),
 }
 # stage-isolated logits error against the fp32-K/V oracle (the Float16 rounding of the cached keys / values included), same rule
-STAGE_MEASURED = {"large-v3@128x1": 7.54e-4, "large-v3@56x2": 7.54e-4, "large-v3": 7.54e-4, "small": 5.17e-4, "tiny.en": 4.49e-4}
+STAGE_MEASURED = {"large-v3@256x1s2": 7.54e-4, "large-v3@128x1": 7.54e-4, "large-v3@56x2": 7.54e-4, "large-v3": 7.54e-4, "small": 5.17e-4, "tiny.en": 4.49e-4}
 # provisional ceilings used while a configuration has no measured value yet
 E2E_CEILING = dict(encoder_max=1e-1, encoder_mean=1e-2, logits_max=2e-2)
 
@@ -130,14 +136,14 @@ class FollowingSampler(OD.GreedyTokenSampler):
 # order of the combine (include/whisperhip.h, wh_session_create_tuned), so every timed (slots, splits) pair has its own full-depth run here.
 # The realistic-statistics fixture of the same architecture (tests/test_gpu_realistic.py) keeps the library's choice for a lone session (4),
 # tests/test_gpu_round4.py walks 1 .. 4 on a two-layer model
-BENCH_SPLITS = {"large-v3@128x1": 1, "large-v3@56x2": 2, "large-v3": 2}
+BENCH_SPLITS = {"large-v3@256x1s2": 1, "large-v3@128x1": 1, "large-v3@56x2": 2, "large-v3": 2}
 
 
 class Rig:
-    def __init__(self, name, sd=None, tag=None, config=None, report=None, sample_length=None, mode=None, splits=None, packed=None):
+    def __init__(self, name, sd=None, tag=None, config=None, report=None, sample_length=None, mode=None, splits=None, packed=None, spw=None):
         """sd / tag / config: another weight set on the same architecture (tests/test_gpu_realistic.py); default = the weights bench.py times.
         packed = chunks per packed step: slot k * packed + b carries bench.py's chunk (b, packed step k) - the continuous-batching fill."""
-        self.splits = splits
+        self.splits, self.spw = splits, spw
         t0 = time.time()
         torch.set_num_threads(min(32, os.cpu_count() or 1))              # the oracle's thread count (bench.py's cpu_baseline uses the same)
         self.name = tag or name
@@ -171,12 +177,12 @@ class Rig:
         self.report = (_REPORT if report is None else report).setdefault(self.name, {"slots": self.B, "checked_slots": self.check, "decoder_inputs": n_in,
                                                 "layers": [self.dims.n_audio_layer, self.dims.n_text_layer],
                                                 "fill": (f"{self.B // per} packed steps of {per} chunks (bench.py continuous batching)" if packed else "one step"),
-                                                "cross_attention": (f"absorbed, {self.sess.crossAttentionSplits} key splits per slot"
+                                                "cross_attention": (f"absorbed, {self.sess.crossAttentionSplits} key splits per slot, {self.sess.crossAttentionSlotsPerWorkgroup} slot(s) per workgroup"
                                                                     if self.sess.crossAttentionMode == 1 else "per-layer K / V rows")})
         self.report["setup_s"] = round(time.time() - t0, 1)
 
     def _session(self, B, chunk_ids, mode=None):
-        s = api.Session(self.model, B, crossAttentionMode=mode, crossAttentionSplits=self.splits)
+        s = api.Session(self.model, B, crossAttentionMode=mode, crossAttentionSplits=self.splits, crossAttentionSlotsPerWorkgroup=self.spw)
         for b, i in enumerate(chunk_ids):
             s.padOrTrim(self.xs[i], b)
         s.logMelSpectrogram(B); s.encodeFeatures(B); s.prepareDecoderInputs(B)
@@ -186,7 +192,7 @@ class Rig:
 @pytest.fixture(scope="module", params=list(CONFIGS))
 def rig(request):
     arch, per = PACKED.get(request.param, (request.param, None))
-    r = Rig(arch, tag=request.param, config=CONFIGS[request.param], splits=BENCH_SPLITS.get(request.param), packed=per)
+    r = Rig(arch, tag=request.param, config=CONFIGS[request.param], splits=BENCH_SPLITS.get(request.param), packed=per, spw=BENCH_SPW.get(request.param))
     yield r
     _write_report()
     r.sess.close(); r.model.close()
@@ -299,7 +305,8 @@ def test_fulldepth_three_sessions_on_three_threads_equal_alone(rig):
     thread start order reversed, so the interleavings differ."""
     F = 3
     ids = [[(b + 5 * f) % rig.B for b in range(rig.B)] for f in range(F)]            # session f's audio order (slot b <- chunk ids[f][b])
-    sessions = [api.Session(rig.model, rig.B, crossAttentionMode=rig.sess.crossAttentionMode, crossAttentionSplits=rig.splits) for _ in range(F)]
+    sessions = [api.Session(rig.model, rig.B, crossAttentionMode=rig.sess.crossAttentionMode, crossAttentionSplits=rig.splits,
+                            crossAttentionSlotsPerWorkgroup=rig.spw) for _ in range(F)]
     probe = sorted({0, rig.B - 1})
 
     def hot_path(f):

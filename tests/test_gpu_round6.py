@@ -185,3 +185,40 @@ def test_persistent_gemm_tile_loop_is_bit_identical_to_one_workgroup_per_tile():
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         got[persist] = {k: v for k, v in json.loads(p.stdout.strip().splitlines()[-1]).items() if k != "mode"}
     assert got["0"] == got["1"] and len(got["0"]) >= 4, got
+
+
+def test_cross_attention_slots_per_workgroup_do_not_change_a_bit():
+    """wh_session_options.cross_attention_slots_per_workgroup (round 6): a workgroup of the absorbed cross-attention streams n slots one after the
+    other, so the launch takes ceil(batch / n) x splits workgroups.  A slot is processed exactly as by a workgroup of its own: tokens, log-probs,
+    teacher-forced logits and alignment rows of a ragged 70-slot batch (three batch tiles; 35 / 24 / 14 first-pass slots at n = 2 / 3 / 5) are the
+    bits of n = 1, at the headline width (d = 1280, 20 heads; 2 + 2 layers) with 2 key splits per slot."""
+    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    heads = [(0, 3), (1, 17)]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=5), alignment_heads=heads)
+    B = 70
+    xs = [synthetic_chunk(300 + b) for b in range(B)]
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=20, wordTimestamps=True)
+    ref = None
+    for n in (1, 2, 3, 5):
+        sess = api.Session(model, B, crossAttentionMode=1, crossAttentionSplits=2, crossAttentionSlotsPerWorkgroup=n)
+        assert sess.crossAttentionSlotsPerWorkgroup == n and sess.crossAttentionSplits == 2
+        for b, x in enumerate(xs):
+            sess.padOrTrim(x, b)
+        sess.logMelSpectrogram(B); sess.encodeFeatures(B); sess.prepareDecoderInputs(B)
+        prompt = sess.prefillPrompt(opts)
+        res = sess.decodeText(prompt, opts, batch=B)
+        got = ([r.tokens for r in res], [r.tokenLogProbs for r in res], [sess.getAlignmentWeights(b)[:20].copy() for b in (0, 34, 35, 69)])
+        sess.resetDecoderInputs(B)
+        lg = sess.predictLogits([res[b].tokens[0] for b in range(B)], [0] * B)
+        got = got + (lg.copy(),)
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0] and got[1] == ref[1], n
+            for a, b_ in zip(got[2], ref[2]):
+                np.testing.assert_array_equal(a, b_)
+            np.testing.assert_array_equal(got[3], ref[3])
+        sess.close()
+    with pytest.raises(api.WhisperError):
+        api.Session(model, 4, crossAttentionMode=1, crossAttentionSlotsPerWorkgroup=17)
+    model.close()

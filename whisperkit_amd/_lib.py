@@ -53,6 +53,11 @@ class WhDecodingResult(C.Structure):
     ]
 
 
+class WhSessionOptions(C.Structure):
+    _fields_ = [("cross_attention_mode", C.c_int32), ("cross_attention_splits", C.c_int32), ("cross_attention_slots_per_workgroup", C.c_int32),
+                ("reserved_", C.c_int32 * 5)]
+
+
 class WhTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4), ("device", C.c_int32),
                 ("reserved_", C.c_int32)]
@@ -137,6 +142,9 @@ SYMBOLS = {
     "wh_transcription_set_segment_times": (I, [VP, I, F, F]),
     "wh_session_create_with_mode": (I, [VP, I, I, PVP]),
     "wh_session_create_tuned": (I, [VP, I, I, I, PVP]),
+    "wh_session_options_default": (None, [C.POINTER(WhSessionOptions)]),
+    "wh_session_create_with_options": (I, [VP, I, C.POINTER(WhSessionOptions), PVP]),
+    "wh_session_cross_attention_slots_per_workgroup": (I, [VP]),
     "wh_debug_peek": (I, [VP, C.c_char_p, VP, C.c_size_t]),
     "wh_session_synchronize": (I, [VP]),
     "wh_session_stream": (VP, [VP]),

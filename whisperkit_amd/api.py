@@ -446,7 +446,8 @@ class Model:
 class Session:
     """Per-task state for up to `maxBatch` windows in flight (= DecodingInputs x maxBatch, one HIP stream)."""
 
-    def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None, crossAttentionSplits: Optional[int] = None):
+    def __init__(self, model: Model, maxBatch: int = 1, crossAttentionMode: Optional[int] = None, crossAttentionSplits: Optional[int] = None,
+                 crossAttentionSlotsPerWorkgroup: Optional[int] = None):
         """crossAttentionMode: None = the library's choice (absorbed from `xabsAutoMinSlots()` = 28 slots at the widths that support it: the
         choice looks at maxBatch only, so Session(m, 27) and Session(m, 28) run different kernels; both meet the 1e-3 relative logits
         contract), 0 = per-layer cross K / V rows (24-bit: Float16 + 8-bit residual), 1 = weight-absorbed cross-attention over the encoder output (csrc/xabs.hip).
@@ -456,10 +457,20 @@ class Session:
         at every decoder step: do not call encodeFeatures / setEncoderOutput between prepareDecoderInputs and the end of the decode.
         crossAttentionSplits: key splits per slot of the absorbed form (None = the library's choice): slots x splits workgroups each own a CU
         while they stream, so this is the share of the GPU the session's cross-attention takes - 4 for a session running alone, 2 when
-        several sessions share the GPU."""
+        several sessions share the GPU.
+        crossAttentionSlotsPerWorkgroup (wh_session_options, round 6): a workgroup of the absorbed cross-attention streams this many slots one
+        after the other, so a launch takes ceil(batch / n) x splits workgroups whatever the batch: 256-slot device batches with 2 slots per
+        workgroup keep the launch at half of the chip (bench.py's headline).  Results do not depend on it, bit for bit."""
         self.model, self.lib, self.B = model, model.lib, maxBatch
         self.handle = C.c_void_p()
-        if crossAttentionMode is None and crossAttentionSplits is None:
+        if crossAttentionSlotsPerWorkgroup is not None:
+            o = L.WhSessionOptions()
+            self.lib.wh_session_options_default(C.byref(o))
+            o.cross_attention_mode = -1 if crossAttentionMode is None else int(crossAttentionMode)
+            o.cross_attention_splits = 0 if crossAttentionSplits is None else int(crossAttentionSplits)
+            o.cross_attention_slots_per_workgroup = int(crossAttentionSlotsPerWorkgroup)
+            _check(self.lib.wh_session_create_with_options(model.handle, maxBatch, C.byref(o), C.byref(self.handle)))
+        elif crossAttentionMode is None and crossAttentionSplits is None:
             _check(self.lib.wh_session_create(model.handle, maxBatch, C.byref(self.handle)))
         else:
             _check(self.lib.wh_session_create_tuned(model.handle, maxBatch, -1 if crossAttentionMode is None else int(crossAttentionMode),
@@ -469,6 +480,10 @@ class Session:
     def xabsAutoMinSlots() -> int:
         """slots from which a session created without a crossAttentionMode runs the absorbed cross-attention"""
         return int(L.load().wh_xabs_auto_min_slots())
+
+    @property
+    def crossAttentionSlotsPerWorkgroup(self) -> int:
+        return int(self.lib.wh_session_cross_attention_slots_per_workgroup(self.handle))
 
     @property
     def crossAttentionMode(self) -> int:

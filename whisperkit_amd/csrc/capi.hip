@@ -412,21 +412,37 @@ static int dalloc(T** p, size_t n, bool zero = true) {
 }
 #define DALLOC(ptr, n) do { int _r = dalloc(&(ptr), (size_t)(n)); if (_r) { wh_session_destroy(s); return _r; } } while (0)
 
-static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
-extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) { return session_create_impl(m, max_batch, -1, 0, out); }
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, int slots_per_workgroup, wh_session** out);
+extern "C" int wh_session_create(wh_model* m, int max_batch, wh_session** out) { return session_create_impl(m, max_batch, -1, 0, 0, out); }
 extern "C" int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out) {
+    wh_session_options o{};
+    o.cross_attention_mode = cross_attention_mode; o.cross_attention_splits = cross_attention_splits;
+    return wh_session_create_with_options(m, max_batch, &o, out);
+}
+extern "C" void wh_session_options_default(wh_session_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->cross_attention_mode = -1;
+}
+extern "C" int wh_session_create_with_options(wh_model* m, int max_batch, const wh_session_options* opt, wh_session** out) {
+    wh_session_options dflt;
+    wh_session_options_default(&dflt);
+    if (!opt) opt = &dflt;
+    const int cross_attention_mode = opt->cross_attention_mode, cross_attention_splits = opt->cross_attention_splits;
+    if (opt->cross_attention_slots_per_workgroup < 0 || opt->cross_attention_slots_per_workgroup > kXabsMaxSlotsPerWorkgroup)
+        return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_slots_per_workgroup %d (expected 0 auto, 1 .. %d)", opt->cross_attention_slots_per_workgroup, kXabsMaxSlotsPerWorkgroup);
     if (cross_attention_mode < -1 || cross_attention_mode > 1)
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_mode %d (expected -1 auto, 0 K / V rows, 1 absorbed)", cross_attention_mode);
     if (cross_attention_splits < 0 || cross_attention_splits > kXabsSplits)
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: cross_attention_splits %d (expected 0 auto, 1 .. %d)", cross_attention_splits, kXabsSplits);
     if (cross_attention_mode == 1 && m && !xabs_supported(m->dims.n_text_state, m->dims.n_text_head))
         return set_error(WH_ERR_INVALID_ARGUMENT, "wh_session_create: the absorbed cross-attention needs a model width of 512 / 768 / 1024 / 1280 (this model: %d)", m->dims.n_text_state);
-    return session_create_impl(m, max_batch, cross_attention_mode, cross_attention_splits, out);
+    return session_create_impl(m, max_batch, cross_attention_mode, cross_attention_splits, opt->cross_attention_slots_per_workgroup, out);
 }
 extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
     return wh_session_create_tuned(m, max_batch, cross_attention_mode, 0, out);
 }
-static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out) {
+static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, int slots_per_workgroup, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
     if (max_batch < 1 || max_batch > kMaxSessionSlots) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, %d]", max_batch, kMaxSessionSlots);
     WH_HIP(hipSetDevice(m->device));
@@ -463,6 +479,8 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
         Carver c; c.base = (char*)s->xabs_blob;
         s->xabs.layers_host = m->xabs.data();
         s->xabs.n_split = cross_attention_splits > 0 ? cross_attention_splits : xabs_splits(max_batch);
+        s->xabs.spw = slots_per_workgroup > 0 ? slots_per_workgroup : 1;
+        { const char* e = getenv("WH_XABS_SPW"); const int v = e ? atoi(e) : 0; if (v >= 1 && v <= kXabsMaxSlotsPerWorkgroup) s->xabs.spw = v; }      // A/B override
         s->xabs.qf_hi = c.take<f16>(B * nht * (d / 32) * 512); s->xabs.qf_lo = c.take<f16>(B * nht * (d / 32) * 512);
         s->xabs.part = c.take<float>(S * H * (d / 8) * B * 8);
         s->xabs.ml = c.take<float2>(S * H * B);
@@ -525,6 +543,7 @@ extern "C" int wh_session_max_batch(const wh_session* s) { return s ? s->B : -1;
 extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ? (s->use_xabs ? 1 : 0) : -1; }
 extern "C" int wh_session_step_graph_count(const wh_session* s) { return s ? (int)s->graphs.size() : -1; }
 extern "C" int wh_session_cross_attention_splits(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.n_split : 0) : -1; }
+extern "C" int wh_session_cross_attention_slots_per_workgroup(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.spw : 0) : -1; }
 // slots from which wh_session_create picks the absorbed cross-attention on its own (models whose width supports it)
 extern "C" int wh_xabs_auto_min_slots(void) {
     const char* e = getenv("WH_XABS_MIN_SLOTS");

@@ -37,7 +37,10 @@ namespace wh {
 // ---------------------------------------------------------------------------------------------- fused greedy sampler, part 1
 // Filter rules of one sampling step as scalars (restating LogitsFilter.swift): r[0] SuppressBlank active,
 // r[1] TimestampRules active, [r2, r3) and [r4, r5) id ranges masked by the timestamp rules.
-__device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, const SeqState* sq, int n_tok, int V, int* r) {
+// last_ts_hint: -2 = scan the history for the last timestamp token (TimestampRulesFilter walks it backwards); >= -1 = the caller already knows the
+// index of the last token >= time_token_begin in [0, n_tok) (-1: none) - sampler_final_kernel finds it with all of its threads, because with
+// text-only histories (random-init weights: the benchmark) the one-thread backward walk over <= 223 LDS words was 9 of the kernel's 12 us
+__device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, const SeqState* sq, int n_tok, int V, int* r, int last_ts_hint = -2) {
     const int tb = cfg.time_token_begin;
     int blank = 0, ts_active = 0, r1lo = 0, r1hi = 0, r2lo = 0, r2hi = 0;
     blank = cfg.suppress_blank && (n_tok == cfg.prefilled_index);            // SuppressBlankFilter :44-50
@@ -58,8 +61,12 @@ __device__ __forceinline__ void compute_filter_rules(const SamplerCfg& cfg, cons
                     else { r1lo = 0; r1hi = cfg.end_token; }     // cannot be normal text
                 }
                 int lastTimestamp = -1;
-                for (int i = n_tok - 1; i >= sb; --i)
-                    if (sq->tokens[i] >= tb) { lastTimestamp = sq->tokens[i]; break; }
+                if (last_ts_hint >= -1) {
+                    if (last_ts_hint >= sb) lastTimestamp = sq->tokens[last_ts_hint];
+                } else {
+                    for (int i = n_tok - 1; i >= sb; --i)
+                        if (sq->tokens[i] >= tb) { lastTimestamp = sq->tokens[i]; break; }
+                }
                 if (lastTimestamp >= 0) {
                     int tl = (lastTs && !penTs) ? lastTimestamp : lastTimestamp + 1;
                     r2lo = tb; r2hi = tl;
@@ -464,7 +471,8 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, int counter)
 }
 
 // decodeText bookkeeping after one sampled token (TextDecoder.swift:573-757), then the filter rules of the next step
-__device__ __forceinline__ void advance_decode_state(const SamplerCfg& cfg, SeqState* sq, int tok, float lp, int n_tok) {
+// last_ts_pre: index of the last timestamp token in [0, n_tok) BEFORE this step's token is appended (-1 none), or -2 = unknown (scan)
+__device__ __forceinline__ void advance_decode_state(const SamplerCfg& cfg, SeqState* sq, int tok, float lp, int n_tok, int last_ts_pre = -2) {
     const int tb = cfg.time_token_begin;
     const int ti_cur = sq->token_index;
     const bool isFirstToken = ti_cur == cfg.prefilled_index;
@@ -495,7 +503,10 @@ __device__ __forceinline__ void advance_decode_state(const SamplerCfg& cfg, SeqS
     }
     sq->token_index = ti_next;
     sq->next_token = next;
-    compute_filter_rules(cfg, sq, nt, cfg.n_vocab, sq->f_rules);
+    // (the prompt-timestamp replacement above writes a timestamp over a timestamp: an index found before it still points at one)
+    int hint = last_ts_pre;
+    if (hint >= -1 && nt > n_tok && tok >= tb) hint = nt - 1;          // the token appended by this step is the newest timestamp
+    compute_filter_rules(cfg, sq, nt, cfg.n_vocab, sq->f_rules, hint);
 }
 
 // MODE bit 0: apply filters; bit 1: sample; bit 2: advance decodeText state; bit 3: write filtered logits back
@@ -699,14 +710,21 @@ __device__ __forceinline__ void stat_wave_reduce(SoftStat& a) {
 __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __restrict__ cfgp, SeqState* __restrict__ seqs,
                                                             const float* __restrict__ stats, int nblk) {
     __shared__ float sm[4][4];
-    __shared__ int si[4][2];
+    __shared__ int si[4][3];
     __shared__ SeqState sq_l;     // the slot's whole decode state: thread 0's bookkeeping (token history scans, appends) runs on
                                   // this LDS copy instead of a chain of dependent global round trips
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SeqState* sq = seqs + b;
     if (!slot_live(sq)) return;
     constexpr int kWords = sizeof(SeqState) / 4;
+    static_assert(kMaxTok <= 256, "one history token per thread");
     for (int i = tid; i < kWords; i += 256) reinterpret_cast<int*>(&sq_l)[i] = reinterpret_cast<const int*>(sq)[i];
+    // index of the last timestamp token of the history, found by all threads (the rules of the NEXT step need it: compute_filter_rules)
+    const int n_hist = sq->n_tokens;
+    const int tbeg = cfgp->time_token_begin;
+    int last_ts = (tid < n_hist && tid < kMaxTok && sq->tokens[tid] >= tbeg) ? tid : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last_ts = max(last_ts, __shfl_xor(last_ts, o, 64));
     SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
     constexpr int NR = kStatBlocks / 256;      // records per thread: all loads are issued before the first merge (one L2 round
     float4 lo[NR];                             // trip instead of NR dependent ones)
@@ -727,10 +745,10 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
     }
     stat_wave_reduce(t);
     stat_wave_reduce(u);
-    if (lane == 0) { sm[wave][0] = t.m; sm[wave][1] = t.s; si[wave][0] = t.i; sm[wave][2] = u.m; sm[wave][3] = u.s; si[wave][1] = u.i; }
+    if (lane == 0) { sm[wave][0] = t.m; sm[wave][1] = t.s; si[wave][0] = t.i; sm[wave][2] = u.m; sm[wave][3] = u.s; si[wave][1] = u.i; si[wave][2] = last_ts; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) { stat_merge(t, sm[w][0], sm[w][1], si[w][0]); stat_merge(u, sm[w][2], sm[w][3], si[w][1]); }
+        for (int w = 1; w < 4; ++w) { stat_merge(t, sm[w][0], sm[w][1], si[w][0]); stat_merge(u, sm[w][2], sm[w][3], si[w][1]); last_ts = max(last_ts, si[w][2]); }
         const SamplerCfg cfg = *cfgp;
         const bool ts_active = sq_l.f_rules[1] != 0;
         int tok; float lp;
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(const SamplerCfg* __
             stat_merge(g, u.m, u.s, u.i);        // equal maxima: the text id (smaller index) wins, like a first-maximum argmax
             tok = g.i; lp = -logf(g.s);
         }
-        advance_decode_state(cfg, &sq_l, tok, lp, sq_l.n_tokens);
+        advance_decode_state(cfg, &sq_l, tok, lp, sq_l.n_tokens, last_ts);
     }
     __syncthreads();
     for (int i = tid; i < kWords; i += 256) reinterpret_cast<int*>(sq)[i] = reinterpret_cast<const int*>(&sq_l)[i];
@@ -884,6 +902,7 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             xa.qf_hi = X.qf_hi; xa.qf_lo = X.qf_lo; xa.part = X.part; xa.ml = X.ml; xa.att_hi = D.zb_hi; xa.att_lo = D.zb_lo;
             xa.align = db.align; xa.align_slot = db.align_slot; xa.n_align = db.n_align; xa.seq = db.seq; xa.kpart = D.part; xa.ticket = D.ticket;
             xa.gate = db.xattn_gate;
+            xa.spw = X.spw;
             xa.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
             launch_xabs_qk(xa, n_bt, st);
             launch_xabs_attn(xa, st);

@@ -274,6 +274,7 @@ void dec32_fold_vectors(const f16* W, int N, int K, const float* gamma, const fl
 int dec32_ksplit(int mode, int N, int K, bool f16_input);
 
 // ---------------------------------------------------------------------------------------------- absorbed cross-attention (xabs.hip)
+constexpr int kXabsMaxSlotsPerWorkgroup = 16;   // slots one xabs_attn workgroup streams one after the other (wh_session_options)
 constexpr int kMaxSessionSlots = 256;    // windows one session decodes in lock-step (eight 32-slot batch tiles of the decoder projections)
 constexpr int kXabsAutoMinSlots = 28;   // wh_session_create picks the absorbed path from this many slots (WH_XABS_MIN_SLOTS overrides): measured large-v3,
                                         // one stream, ms per decoder step with 24-bit K / V rows vs absorbed (4 splits): 16 slots 3.27 / 3.91, 24 slots 3.88 / 4.00, 28 slots
@@ -294,6 +295,7 @@ struct Xabs {
     float* part;         // [splits][H][d / 8][Bmax][8] unnormalised O' of every key split
     float2* ml;          // [splits][H][Bmax] (running maximum, sum)
     int n_split;         // key splits per slot (1 .. kXabsSplits), a constant of the session (the combine order fixes the bits)
+    int spw;             // slots per xabs_attn workgroup (>= 1), a constant of the session: workgroups per launch = ceil(batch / spw) x n_split
 };
 struct XabsArgs {
     int batch, max_batch, d, n_head, layer, n_split, cross_div;
@@ -307,6 +309,7 @@ struct XabsArgs {
     unsigned long long* dbg;         // WH_DBG=1 timeline stamps of xabs_attn
     int ablate;                      // WH_XABS_ABLATE (timing probe, results are garbage): bit 0 no LDS-DMA, bit 1 no S / softmax / P V work
     int* gate;                       // cross-attention gate (dec_shared.h, WH_XATT_GATE=1): xabs_qk takes it, xabs_attn's last workgroup returns it
+    int spw;                         // xabs_attn: slots per workgroup (round 6): the launch has ceil(batch / spw) x n_split workgroups, each streams its slots one after the other
 };
 bool xabs_supported(int d, int n_head);
 void xabs_tile_wk(const f16* Wk, int d, int H, f16* out, hipStream_t st);

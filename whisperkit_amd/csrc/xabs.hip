@@ -203,16 +203,22 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     // partial sectors share 128-byte lines (part[split][head][c / 8][slot][8]): the lines are assembled in one L2
     const int xr = blockIdx.x & 7, xq = blockIdx.x >> 3;
     const int S = a.n_split, H = a.n_head;
-    const int n_grp = (a.batch + 3) >> 2, grp = (xq >> 2) * 8 + xr;        // group = (split, 4 consecutive slots); group % 8 = its XCD
-    const int sp = grp / n_grp, b = ((grp - sp * n_grp) << 2) + (xq & 3);
+    // slots per workgroup (round 6): the grid covers the first `b1` slots; a workgroup then goes on to slots b + b1, b + 2 b1, ... - the share of
+    // the CUs a launch takes (workgroups = b1 x splits) no longer grows with the batch, so a session's device batch can be larger than the half
+    // of the chip its cross-attention is given.  Every slot is processed exactly as by a workgroup of its own: same bits.
+    const int spw = max(a.spw, 1), b1 = (a.batch + spw - 1) / spw;
+    const int n_grp = (b1 + 3) >> 2, grp = (xq >> 2) * 8 + xr;        // group = (split, 4 consecutive slots); group % 8 = its XCD
+    const int sp = grp / n_grp, b_first = ((grp - sp * n_grp) << 2) + (xq & 3);
     if (a.gate && blockIdx.x == gridDim.x - 1 && tid == 0) xattn_gate_release(a.gate);     // the grid is draining from here on
-    if (sp >= S || b >= a.batch) return;
+    if (sp >= S || b_first >= b1) return;
     // WH_DBG=1: shader-clock stamps (tools/xabs_timeline.py): 9 entry, 10 slot state known, 11 loop entry, 12 loop exit, 13 partials stored
 #define XPHASE(k) do { if constexpr (DBG) if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 64) \
         a.dbg[((blockIdx.x * 2 + (wave == 5)) * 2) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-    XPHASE(9);
     constexpr int NT = (kCtx + 15) / 16;
     const int tile_lo = sp * NT / S, tile_hi = (sp + 1) * NT / S, n = tile_hi - tile_lo;
+  for (int b = b_first; b < a.batch; b += b1) {            // (workgroup-uniform)
+    if (b != b_first) __syncthreads();                    // every wave is done with the previous slot's ring, partial tiles and P^T before they are written again
+    XPHASE(9);
     const int bc = a.cross_div > 1 ? b / a.cross_div : b;
     const unsigned char* enc = reinterpret_cast<const unsigned char*>(a.enc + (size_t)bc * kCtx * D);
 
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     pfrag[tid] = (f16)0.0f;
     if (!(s_act && !s_done)) {           // workgroup-uniform: a finished slot streams nothing more
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
+        continue;
     }
     const int pos = min(max(s_ti, 0), kMaxTok - 1);
     float* raw = nullptr;
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(512, 2) void xabs_attn_kernel(const XabsArgs a) {
     }
     if constexpr (DBG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XPHASE(13);
+  }     // slots of this workgroup
 #undef XPHASE
 }
 
@@ -604,7 +611,8 @@ static void launch_attn_k(const XabsArgs& a, hipStream_t st) {
     constexpr int lds = xabs_lds_bytes(CW);
     static PerDeviceOnce once;
     once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xabs_attn_kernel<CW, NHT, DBG, NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    const int n_grp = (a.batch + 3) / 4 * a.n_split;         // (split, 4 slots) groups, 8 of them (one per XCD) to every 32 workgroup ids
+    const int spw = a.spw > 1 ? a.spw : 1, b1 = (a.batch + spw - 1) / spw;
+    const int n_grp = (b1 + 3) / 4 * a.n_split;             // (split, 4 slots) groups, 8 of them (one per XCD) to every 32 workgroup ids
     xabs_attn_kernel<CW, NHT, DBG, NTL><<<dim3((unsigned)((n_grp + 7) / 8 * 32)), 512, lds, st>>>(a);
 }
 template <int CW, int NHT>
