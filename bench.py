@@ -189,12 +189,15 @@ def get_model(name, local_rank, keep_sd=False):
 
 def plan_batches(n_steps, F, G):
     """n_steps steps over F workers (sessions in flight) as device batches of at most G steps: every worker gets an equal share of the
-    steps (the first n_steps % F one more), cut into one shorter remainder batch (run first) and batches of G.  Returns [[steps per batch, ...] per worker]."""
+    steps (the first n_steps % F one more), cut into the fewest batches of at most G steps, as equal as possible (a share of 6 with G = 4 is
+    3 + 3, not 2 + 4: no batch is much smaller than the others), the shorter ones first.  Returns [[steps per batch, ...] per worker]."""
     F = max(1, min(F, n_steps))
     plan = []
     for w in range(F):
         mine = n_steps // F + (1 if w < n_steps % F else 0)
-        plan.append(([mine % G] if mine % G else []) + [G] * (mine // G))      # the short batch FIRST: the run ends on full batches (a 20-step run
+        nb = -(-mine // G)
+        base, rem = divmod(mine, nb) if nb else (0, 0)
+        plan.append([base] * (nb - rem) + [base + 1] * rem)                     # the short batches FIRST: the run ends on full batches (a 20-step run
     return plan                                                                 # that ended on two single-step batches was 5 % slower over all, profiles/r05f_*)
 
 

@@ -7,9 +7,10 @@
 #   (the positions bench.py's algorithmic bytes assume: VERDICT r04 weak 10)
 TAG=${1:-prof}
 XS=${XS:-1}
-SLOTS=${SLOTS:-128}
+SLOTS=${SLOTS:-256}
 export WH_PMC_STEPS=16
 export WH_XABS_SPLITS=$XS
+[ -n "$SPW" ] && export WH_XABS_SPW=$SPW      # slots per xabs_attn workgroup of the counter passes (bench.py: 2 at 256 slots)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $R
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --cross-attention-splits $XS > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?

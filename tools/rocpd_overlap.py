@@ -56,6 +56,18 @@ def main(path, f0=0.0, f1=1.0):
         print(f"  {k}{'+' if k == 4 else ' '} kernels running: {hist[k] / 1e6:9.2f} ms  {100.0 * hist[k] / span:5.1f} %")
     print(f"  >= 1 cross-attention running: {t_x / 1e6:.2f} ms ({100.0 * t_x / span:.1f} %);  >= 1 encoder GEMM / attention: {t_g / 1e6:.2f} ms "
           f"({100.0 * t_g / span:.1f} %);  both: {t_xg / 1e6:.2f} ms")
+    # idle time in front of a kernel ON ITS OWN QUEUE (start - end of the queue's previous kernel), by the kind of the kernel that waited:
+    # a dependent launch chain shows its kernel boundaries here, a launch that had to wait for CUs shows the wait
+    last_end, wait = {}, defaultdict(lambda: [0, 0])
+    for name, s_, e_, q in rows:
+        if q in last_end:
+            k = name.split("(")[0].replace("void wh::", "")[-44:]
+            wait[k][0] += max(0, s_ - last_end[q]); wait[k][1] += 1
+        last_end[q] = e_
+    tot_wait = sum(v[0] for v in wait.values())
+    print(f"  idle time in front of a kernel on its own queue, by kernel (total {tot_wait / 1e6:.1f} ms over {len(last_end)} queues):")
+    for k, (w, n_) in sorted(wait.items(), key=lambda kv: -kv[1][0])[:10]:
+        print(f"    {k:46s} n {n_:6d}  avg {w / max(n_, 1) / 1e3:7.1f} us  total {w / 1e6:8.1f} ms")
     per_q = defaultdict(list)
     for name, s, e, q in rows:
         per_q[q].append((s, e))
