@@ -9,18 +9,20 @@ TAG=${1:-prof}
 XS=${XS:-1}
 SLOTS=${SLOTS:-256}
 export WH_PMC_STEPS=16
-export WH_XABS_SPLITS=$XS
-[ -n "$SPW" ] && export WH_XABS_SPW=$SPW      # slots per xabs_attn workgroup of the counter passes (bench.py: 2 at 256 slots)
+SPW=${SPW:-2}                                   # slots per xabs_attn workgroup (bench.py: 2 at 256 slots)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $R
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --cross-attention-splits $XS > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?
+# (12 steps: three sessions x one full 4-step batch = the 256-slot device batch of the headline; fewer steps would pack smaller batches)
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --device-batch $SLOTS --no-cpu-baseline --no-other-configs --cross-attention-splits $XS --cross-attention-slots-per-workgroup $SPW > $R/${TAG}_prof_bench.json 2> $R/${TAG}_prof.err; echo prof rc=$?
 DB=$(ls /tmp/${TAG}_prof/*.db /tmp/${TAG}_prof/*/*.db 2>/dev/null | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats.csv 2> $R/${TAG}_summary.err; head -12 $R/${TAG}_kernel_stats.csv
 # the same command with ONE step in flight: the kernel's own duration (what bench.py's roofline leg times with HIP events on an otherwise
 # idle GPU); with three sessions in flight the streams share the HBM and the per-kernel averages above are stretched
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof1 -o ${TAG}1 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --cross-attention-splits $XS --no-cpu-baseline --no-other-configs --no-roofline > $R/${TAG}_prof_inflight1_bench.json 2> $R/${TAG}_prof_inflight1.err; echo prof1 rc=$?
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/${TAG}_prof1 -o ${TAG}1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 4 --inflight 1 --device-batch $SLOTS --cross-attention-splits $XS --cross-attention-slots-per-workgroup $SPW --no-cpu-baseline --no-other-configs --no-roofline > $R/${TAG}_prof_inflight1_bench.json 2> $R/${TAG}_prof_inflight1.err; echo prof1 rc=$?
 DB=$(ls /tmp/${TAG}_prof1/*.db /tmp/${TAG}_prof1/*/*.db 2>/dev/null | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB > $R/${TAG}_kernel_stats_inflight1.csv 2>> $R/${TAG}_summary.err; head -4 $R/${TAG}_kernel_stats_inflight1.csv
+[ -n "$SKIP_PMC" ] && exit 0
+export WH_XABS_SPLITS=$XS WH_XABS_SPW=$SPW      # the counter passes drive the library through tools/pmc_run.py
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace -d /tmp/${TAG}_pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_run.py large-v3 $SLOTS 16 > $R/${TAG}_pmc_$C.log 2>&1; echo pmc $C rc=$?
   DB=$(ls /tmp/${TAG}_pmc_$C/*.db /tmp/${TAG}_pmc_$C/*/*.db 2>/dev/null | head -1)
