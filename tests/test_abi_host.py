@@ -374,3 +374,30 @@ def test_library_carries_the_staged_epilogue_kernels():
             assert f"gemm256_kernelILi{epi}ELi{mode}EEE".encode() in blob, (epi, mode)
     for epi in (4, 5, 6, 7):                                     # conv1, conv2, plain fp32, cross K / V rows: direct only
         assert f"gemm256_kernelILi{epi}ELi0EEE".encode() in blob and f"gemm256_kernelILi{epi}ELi1EEE".encode() not in blob, epi
+
+
+def test_round6_bench_line_bookkeeping_of_the_256_slot_device_batch():
+    """The committed round-6 bench line (profiles/r06z_*: the final binary under the driver's command line): a 256-slot device batch carries FOUR 64-chunk bench steps and a
+    cross-attention workgroup streams two slots, so the launch takes 128 workgroups; launches_per_step is 32 layers x 223 decoder steps / 4 = 1784; the algorithmic bytes are the
+    formula's at 256 slots; the PMC pass of that configuration (profiles/r06_pmc_traffic.json) is not below them; every other_configs entry carries a roofline of its own."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r06z_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    r, cfg = line["roofline"], line["config"]
+    assert cfg["device_batch_slots"] == 256 and cfg["steps_per_device_batch"] == 4 and cfg["steps_in_flight"] == 12 and cfg["audio_sets"] >= 4
+    assert r["workgroups"] == 128 and r["slots_per_workgroup"] == 2 and r["cu_share"] == 0.5
+    k = r["kernels"]["dec_cross_attn"]
+    assert k["launches_per_step"] == 32 * 223 / 4 and k["launches_measured"] == 32 * 16
+    dims = weights.MODEL_DIMS["large-v3"]
+    d, H, B = dims.n_text_state, dims.n_text_head, 256
+    assert r["alg_per_launch"] == B * 1500 * d * 2 + B * H * d * 4 + 1 * B * H * (d * 4 + 8) == 1_035_509_760
+    assert r["frac"] == pytest.approx(r["alg_per_launch"] / (r["avg_us"] * 1e-6) / 8e12, rel=1e-3)
+    assert k["launches_per_step"] * k["avg_us"] * 1e-3 <= line["ms_per_step"]
+    assert r["whole_chip_frac"] == r["same_kernel_alone_on_the_whole_chip"]["frac"] and r["whole_chip_frac"] > r["frac"]
+    assert r["same_kernel_alone_on_the_whole_chip"]["workgroups"] == 256
+    tj = json.load(open(os.path.join(root, "profiles", "r06_pmc_traffic.json")))
+    assert tj["chunks_per_step"] == 256 and tj["cross_attention_splits"] == 1
+    assert 1.0 <= tj["bytes_per_launch"]["dec_cross_attn"] / r["alg_per_launch"] <= 1.05 and r["traffic"] == tj["bytes_per_launch"]["dec_cross_attn"]
+    assert line["cpu_baseline"]["first_tokens_equal_gpu"] is True and "of" in line["cpu_baseline"]["cores_of"]
+    for name, o in line["other_configs"].items():
+        rf = o["roofline"]
+        assert rf and rf["kernel"] and 0.0 < rf["frac"] < 1.0 and rf["whole_step"]["frac"] < 1.0 and len(rf["top_kernels"]) >= 3, name
