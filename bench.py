@@ -228,7 +228,7 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
     # ... and beyond 128 slots a workgroup streams several slots one after the other, so the launch stays at 128 workgroups (round 6,
     # wh_session_options.cross_attention_slots_per_workgroup: 256-slot batches x 2 slots per workgroup 2749 audio-s/s against 2660 with 128-slot batches
     # and 2692 with 256 workgroups per launch, profiles/r06i_*)
-    xspw = args.cross_attention_slots_per_workgroup if args.cross_attention_slots_per_workgroup > 0 else (max(1, slots * max(xsplits, 1) // 128) if F > 1 else 1)
+    xspw = args.cross_attention_slots_per_workgroup if args.cross_attention_slots_per_workgroup > 0 else (max(1, -(-slots * max(xsplits, 1) // 128)) if F > 1 else 1)
     sessions = [api.Session(model, slots, crossAttentionSplits=xsplits or None, crossAttentionSlotsPerWorkgroup=xspw) for _ in range(F)]
     sess = sessions[0]
     # host float32 PCM: a pool of AUDIO_SETS chunk sets; step n of a run (steps numbered worker by worker, batch by batch: the order the records are
@@ -550,7 +550,7 @@ def main():
                     "session's cross-attention takes (wh_session_create_tuned): -1 = 128 / slots (2 at 64 slots) when several device batches are in "
                     "flight (the other sessions' kernels keep half of the chip; profiles/r04ad_*, r04ae_*), the library's choice (4) for one")
     ap.add_argument("--cross-attention-slots-per-workgroup", type=int, default=-1, help="slots one workgroup of the absorbed cross-attention streams one after the other "
-                    "(wh_session_options): -1 = slots x splits / 128 with several device batches in flight (the launch stays at 128 workgroups: 2 at 256 slots), 1 for one")
+                    "(wh_session_options): -1 = ceil(slots x splits / 128) with several device batches in flight (the launch stays at <= 128 workgroups: 2 at 256 slots, 2 at the 224 slots of a 2-GPU run), 1 for one")
     ap.add_argument("--sample-length", type=int, default=224, help="DecodingOptions.sampleLength (224 -> 223 decoder steps)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks, together with --single-device)")

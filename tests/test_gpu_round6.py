@@ -222,3 +222,35 @@ def test_cross_attention_slots_per_workgroup_do_not_change_a_bit():
     with pytest.raises(api.WhisperError):
         api.Session(model, 4, crossAttentionMode=1, crossAttentionSlotsPerWorkgroup=17)
     model.close()
+
+
+@pytest.mark.parametrize("slots,spw", [(224, 2), (112, 1), (192, 2), (256, 2)])
+def test_device_batch_shapes_of_the_multi_gpu_runs_decode_every_slot_like_a_lone_session(slots, spw):
+    """bench.py at 2 / 4 GPUs packs 7 steps of 32 / 16 chunks into device batches of 224 / 112 slots (1 key split; 2 / 1 slots per cross-attention
+    workgroup), at one GPU a run's shorter batches have 192 slots, the full ones 256 x 2.  None of these has a full-depth rig of its own; what makes
+    the 128 x 1 and 256 x 1 x 2 rigs of tests/test_gpu_fulldepth.py speak for them is bit-identity: with one key split a slot's results do not depend on
+    the batch it sits in, nor on the slots per workgroup.  Checked here at the headline width (d = 1280, 20 heads; 2 + 2 layers, absorbed
+    cross-attention forced with 1 split): slots of the first, a middle and the last batch tile and both sides of the workgroup's slot boundary
+    against ONE-slot sessions of the same audio - encoder output, tokens, log-probs, bit for bit."""
+    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=7))
+    b1 = -(-slots // spw)
+    check = sorted({0, 31, 32, b1 - 1, min(b1, slots - 1), slots - 33, slots - 1})
+    xs = {b: synthetic_chunk(500 + b) for b in check}
+    filler = synthetic_chunk(499)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=16)
+    big = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=1, crossAttentionSlotsPerWorkgroup=spw)
+    for b in range(slots):
+        big.padOrTrim(xs.get(b, filler), b)
+    big.logMelSpectrogram(slots); big.encodeFeatures(slots); big.prepareDecoderInputs(slots)
+    prompt = big.prefillPrompt(opts)
+    res = big.decodeText(prompt, opts, batch=slots)
+    for b in check:
+        one = api.Session(model, 1, crossAttentionMode=1, crossAttentionSplits=1)
+        one.padOrTrim(xs[b], 0)
+        one.logMelSpectrogram(1); one.encodeFeatures(1); one.prepareDecoderInputs(1)
+        np.testing.assert_array_equal(one.getEncoderOutput(0), big.getEncoderOutput(b))
+        r1 = one.decodeText(prompt, opts)[0]
+        assert r1.tokens == res[b].tokens and r1.tokenLogProbs == res[b].tokenLogProbs, (slots, spw, b)
+        one.close()
+    big.close(); model.close()
