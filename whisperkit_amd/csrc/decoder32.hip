@@ -449,7 +449,13 @@ int dec32_ksplit(int mode, int N, int K, bool f16_input) {
 template <int MODE, bool HILO, bool NTW>
 static void launch_tc_w(const P32Args& a, dim3 grid, hipStream_t st) {
     const int tw = a.tw;
-    static const int tc_cap = env_int32("WH_D32_TC", 5);     // A/B knob: smaller chunks = fewer registers (TC 2: ~100) = room beside a cross-attention wave
+    // chunk size of the weight stream: 5 k-tiles (196 - 204 registers: two workgroups per CU) up to four batch tiles; beyond (160- to 256-slot device batches: 200 - 1280 workgroups
+    // per launch, which must find room while two cross-attention streams hold most CUs) chunks of 2 (114 - 132 registers: three to four workgroups per CU): on the driver's line
+    // 2661 -> 2681 (from 8 tiles) -> 2689 - 2701 audio-s/s (from 6 / 5 tiles; profiles/r06r_projection_chunk_threshold.jsonl, r06q_*; no difference at 128 slots, r05n).  The
+    // chunking does not touch the order of the matrix instructions: same bits.  WH_D32_TC (chunk cap) and WH_D32_TC_BT (first batch-tile count with small chunks) override.
+    static const int tc_env = env_int32("WH_D32_TC", 0);
+    static const int tc_bt = env_int32("WH_D32_TC_BT", 5);
+    const int tc_cap = tc_env > 0 ? tc_env : (a.n_bt >= tc_bt ? 2 : 5);
     // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
     if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW><<<grid, 256, 0, st>>>(a);
     else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW><<<grid, 256, 0, st>>>(a);
