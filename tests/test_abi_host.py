@@ -376,6 +376,22 @@ def test_library_carries_the_staged_epilogue_kernels():
         assert f"gemm256_kernelILi{epi}ELi0EEE".encode() in blob and f"gemm256_kernelILi{epi}ELi1EEE".encode() not in blob, epi
 
 
+def test_library_carries_the_grouped_row_tile_projection_kernels():
+    """csrc/decoder32.hip (round 6): from five batch tiles on a decoder projection workgroup multiplies its activation planes by TWO weight-row tiles (every
+    projection, the logits included) or FOUR (qkv, fc1, the residual projections = fc2) - dec32_proj_kernel<MODE, HILO, TC, NTW, RT>.  The one-tile kernels stay
+    for smaller batches (and are what the bit-identity tests of tests/test_gpu_round6.py compare the grouped ones with).  All three sets must be in the library."""
+    from whisperkit_amd import _lib
+    blob = open(os.path.join(os.path.dirname(_lib.__file__), "libwhisperhip.so"), "rb").read()
+    for mode in (0, 1, 2, 3, 4):                                 # QKV, Q, RESID, FC1, LOGITS (kernels.h)
+        for rt, tcs in ((1, (5, 2)), (2, (4, 2))):
+            for tc in tcs:
+                assert f"dec32_proj_kernelILi{mode}ELb1ELi{tc}ELb0ELi{rt}EEE".encode() in blob, (mode, tc, rt)
+    for mode in (0, 2, 3):
+        assert f"dec32_proj_kernelILi{mode}ELb1ELi1ELb0ELi4EEE".encode() in blob, mode
+    for mode in (1, 4):
+        assert f"dec32_proj_kernelILi{mode}ELb1ELi1ELb0ELi4EEE".encode() not in blob, mode
+
+
 def test_round6_bench_line_bookkeeping_of_the_256_slot_device_batch():
     """The committed round-6 bench line (profiles/r06z_*: the final binary under the driver's command line): a 256-slot device batch carries FOUR 64-chunk bench steps and a
     cross-attention workgroup streams two slots, so the launch takes 128 workgroups; launches_per_step is 32 layers x 223 decoder steps / 4 = 1784; the algorithmic bytes are the

@@ -224,14 +224,16 @@ def test_cross_attention_slots_per_workgroup_do_not_change_a_bit():
     model.close()
 
 
-@pytest.mark.parametrize("slots,spw", [(224, 2), (112, 1), (192, 2), (256, 2)])
+@pytest.mark.parametrize("slots,spw", [(224, 2), (112, 1), (192, 2), (256, 2), (160, 2)])
 def test_device_batch_shapes_of_the_multi_gpu_runs_decode_every_slot_like_a_lone_session(slots, spw):
     """bench.py at 2 / 4 GPUs packs 7 steps of 32 / 16 chunks into device batches of 224 / 112 slots (1 key split; 2 / 1 slots per cross-attention
     workgroup), at one GPU a run's shorter batches have 192 slots, the full ones 256 x 2.  None of these has a full-depth rig of its own; what makes
     the 128 x 1 and 256 x 1 x 2 rigs of tests/test_gpu_fulldepth.py speak for them is bit-identity: with one key split a slot's results do not depend on
     the batch it sits in, nor on the slots per workgroup.  Checked here at the headline width (d = 1280, 20 heads; 2 + 2 layers, absorbed
     cross-attention forced with 1 split): slots of the first, a middle and the last batch tile and both sides of the workgroup's slot boundary
-    against ONE-slot sessions of the same audio - encoder output, tokens, log-probs, bit for bit."""
+    against ONE-slot sessions of the same audio - encoder output, tokens, log-probs, bit for bit.
+    The same comparison pins the grouped projection kernels (csrc/decoder32.hip, round 6): from five batch tiles on (160 slots: the threshold case) a
+    projection workgroup handles two weight-row tiles, the qkv / fc1 / fc2 projections four; the ONE-slot sessions run the one-tile kernels."""
     dims = weights.MODEL_DIMS["test-large-v3-l2"]
     model = api.Model(dims, weights.synthetic_state_dict(dims, seed=7))
     b1 = -(-slots // spw)

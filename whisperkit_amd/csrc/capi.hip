@@ -442,6 +442,24 @@ extern "C" int wh_session_create_with_options(wh_model* m, int max_batch, const 
 extern "C" int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out) {
     return wh_session_create_tuned(m, max_batch, cross_attention_mode, 0, out);
 }
+
+// Session stream.  Default: a non-blocking stream on the whole chip.  WH_CU_PARTS = N (experiment, round 6): the sessions of a process take turns at N
+// compute-unit partitions - session k's stream carries the CU mask of bits [k' W, k' W + W + WH_CU_PART_EXTRA), k' = k % N, W = CUs / N - so that the kernels of
+// sessions in flight never wait for each other's workgroups (hipExtStreamCreateWithCUMask: "the first 32 bits represent the first 32 CUs").
+static hipError_t create_session_stream(hipStream_t* st) {
+    static std::atomic<int> counter{0};
+    const char* e = getenv("WH_CU_PARTS");
+    const int parts = e ? atoi(e) : 0;
+    if (parts < 2) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* x = getenv("WH_CU_PART_EXTRA");
+    const int extra = x ? atoi(x) : 0, k = counter.fetch_add(1) % parts, w = n_cu / parts;
+    uint32_t mask[16] = {};
+    for (int i = k * w; i < k * w + w + extra; ++i) { const int c = ((i % n_cu) + n_cu) % n_cu; mask[c >> 5] |= 1u << (c & 31); }
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)((n_cu + 31) / 32), mask);
+}
 static int session_create_impl(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, int slots_per_workgroup, wh_session** out) {
     if (!m || !out) return set_error(WH_ERR_MODELS_UNAVAILABLE, "wh_session_create: model is null");
     if (max_batch < 1 || max_batch > kMaxSessionSlots) return set_error(WH_ERR_INVALID_ARGUMENT, "max_batch %d out of range [1, %d]", max_batch, kMaxSessionSlots);
@@ -450,7 +468,7 @@ static int session_create_impl(wh_model* m, int max_batch, int cross_attention_m
     s->B = max_batch;
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.n_audio_state, L = D.n_text_layer, V = D.n_vocab, H = D.n_text_head;
-    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
+    if (create_session_stream(&s->st) != hipSuccess) { delete s; return set_error(WH_ERR_HIP, "hipStreamCreate failed"); }
     s->m = m;                       // from here on wh_session_destroy undoes the count
     m->n_sessions.fetch_add(1);
     DALLOC(s->pcm, B * kWindowSamples); DALLOC(s->n_valid, B);

@@ -133,36 +133,46 @@ __device__ __forceinline__ void chan_merge(float& cn, float& cm, float& cM2, flo
 // projections: two batch tiles per workgroup".)
 // NTW: non-temporal weight loads.  A slab is read by n_bt workgroups of ONE XCD (ids x + 8 t): with a single batch tile it is streamed
 // once (nt keeps it from displacing the activations in L2); with two or more, the later readers are meant to hit the first one's lines.
-template <int MODE, bool HILO, int TC, bool NTW>
+// RT (round 6): weight-row tiles per workgroup.  With RT = 2 a wave multiplies every plane fragment it loads by the fragments of TWO consecutive row tiles
+// (rt0, rt0 + 1): half as many workgroups per launch, each reading its activation planes once for 64 output channels instead of 32 (1.0 instead of 1.5 KB
+// through the CU's L1 per matrix instruction pair).  Why: with 5 - 8 batch tiles a launch is 320 - 1280 workgroups of a few microseconds of latency each, more than
+// the CUs that the cross-attention streams of the other sessions leave can hold at once; on half of the CUs the projection chain takes twice as long
+// (profiles/r06s_cu_partition_sweep.jsonl), i.e. its cost in flight is workgroup ROUNDS, and two row tiles per workgroup halve them.  The k-tiles of a row tile
+// are multiplied by the same wave in the same order as with RT = 1 and meet in LDS in the same order: the same bits (tests/test_gpu_round6.py).
+template <int MODE, bool HILO, int TC, bool NTW, int RT>
 __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     constexpr bool kLN = MODE == P32_QKV || MODE == P32_Q || MODE == P32_FC1 || MODE == P32_LOGITS;
-    __shared__ float red[4][16][64];                 // the four waves' partial tiles
+    constexpr int kXs = MODE == P32_LOGITS ? 256 * 6 : 32 * 33;
+    __shared__ float red[RT][4][16][64];             // the four waves' partial tiles
     __shared__ float st_l[8][32][3];                 // LayerNorm statistics: 8 partial (n, mean, M2) per slot
-    __shared__ float xs_raw[MODE == P32_LOGITS ? 256 * 6 : 32 * 33];   // RESID: the tile's new residual values; LOGITS: sampler records
-    float (*xs)[33] = reinterpret_cast<float (*)[33]>(xs_raw);
+    __shared__ float xs_raw[kXs];                    // RESID: the tile's new residual values; LOGITS: sampler records (one buffer: the row tiles of a workgroup use it in turn)
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_rt = (a.N + 31) >> 5;
+    const int n_rtp = (n_rt + RT - 1) / RT;           // row-tile groups (pairs with RT = 2; the last one may hold a single tile)
     // Workgroup id -> (row tile, K slice, batch tile): ids x + 8 t of one group of 8 share the weight slab x and differ in the batch
     // tile t, so the readers of a slab are dispatched back to back onto the SAME XCD (id % 8) and the slab crosses HBM once, whatever
     // the parity of the tile count (PMC at 64 slots before this: the 1621 logits tiles fetched 273 MB for 133 MB of weights).
     const int grp8 = blockIdx.x / (8 * a.n_bt), in8 = blockIdx.x % (8 * a.n_bt);
     const int xw = grp8 * 8 + (in8 & 7), bt = in8 >> 3;
-    if (xw >= n_rt * a.ks) return;          // padding of the last group (workgroup-uniform)
-    const int rt = xw % n_rt, ksi = xw / n_rt;
+    if (xw >= n_rtp * a.ks) return;         // padding of the last group (workgroup-uniform)
+    const int rt0 = (xw % n_rtp) * RT, ksi = xw / n_rtp;
+    const int n_mine = min(RT, n_rt - rt0);  // row tiles of this workgroup that exist (workgroup-uniform)
     const int KT = a.K >> 4;
     const int kt0 = (ksi * 4 + wave) * a.tw;
-    const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)rt * KT + kt0) * 64 + lane;
+    const u32x4* wp[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) wp[t] = reinterpret_cast<const u32x4*>(a.Wt) + ((size_t)min(rt0 + t, n_rt - 1) * KT + kt0) * 64 + lane;     // (a missing second tile re-reads the first: never stored)
     const size_t zoff = ((size_t)bt * KT + kt0) * 64 + lane;
     const u32x4* hp = reinterpret_cast<const u32x4*>(a.zhi) + zoff;
     const u32x4* lp = HILO ? reinterpret_cast<const u32x4*>(a.zlo) + zoff : nullptr;
-    // epilogue coordinates of this thread: slot j, channels n .. n + 3 (the accumulator rows 4 wave + i of half-wave h)
+    // epilogue coordinates of this thread: slot j, channels n .. n + 3 of every row tile (the accumulator rows 4 wave + i of half-wave h)
     const int j = tid & 31, sub = tid >> 5;
-    const int n = rt * 32 + 4 * sub;
     const int gb = bt * 32 + j;
     const bool valid = gb < a.batch;
+    const int xw_dbg = xw;
 
-#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(xw & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+#define D32_STAMP(i) do { if (a.dbg && tid == 0 && bt == 0) a.dbg[(size_t)(xw_dbg & 4095) * 8 + (i)] = wall_clock64(); } while (0)
     D32_STAMP(0);
     // ---- small epilogue operands, requested first (memory returns are in order per wave: they arrive under the weight stream)
     float2 sp[5] = {};
@@ -173,19 +183,25 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             sp[i] = a.stat_in[((size_t)bt * a.n_stat + idx) * 32 + j];
         }
     }
-    float4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};    // LN modes: g, c;  RESID: bias, old x
+    float4 e0[RT], e1[RT];                          // LN modes: g, c;  RESID: bias, old x
     int pos_l = 0, live_l = 0;
-    if constexpr (kLN) {
-        e0 = *reinterpret_cast<const float4*>(a.fold_g + n);
-        e1 = *reinterpret_cast<const float4*>(a.fold_c + n);
-    } else {
-        e0 = *reinterpret_cast<const float4*>(a.bias + n);
-        e1 = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int n = min(rt0 + t, n_rt - 1) * 32 + 4 * sub;
+        if constexpr (kLN) {
+            e0[t] = *reinterpret_cast<const float4*>(a.fold_g + n);
+            e1[t] = *reinterpret_cast<const float4*>(a.fold_c + n);
+        } else {
+            e0[t] = *reinterpret_cast<const float4*>(a.bias + n);
+            e1[t] = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
+        }
     }
     if (valid) { live_l = slot_live(a.seq + gb); if constexpr (MODE == P32_QKV) pos_l = a.seq[gb].token_index; }
     int rules[6] = {0, 0, 0, 0, 0, 0};
-    unsigned masked4 = 0xffffffffu;
+    unsigned masked4[RT];
     int tb = 0, ws_tok = 0, eot_tok = 0, nots_tok = 0, r16 = 0;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) masked4[t] = 0xffffffffu;
     if constexpr (MODE == P32_LOGITS) {
         if (a.cfg) r16 = a.cfg->f16_logits;
         if (a.stats) {
@@ -193,18 +209,26 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) rules[i] = a.seq[gb].f_rules[i];
             }
-            if (n + 3 < a.N) masked4 = *reinterpret_cast<const unsigned*>(a.sup_mask + n);
-            else {
-                masked4 = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) masked4 |= (unsigned)(n + i < a.N ? a.sup_mask[n + i] : 1) << (8 * i);
+            for (int t = 0; t < RT; ++t) {
+                const int n = min(rt0 + t, n_rt - 1) * 32 + 4 * sub;
+                if (n + 3 < a.N) masked4[t] = *reinterpret_cast<const unsigned*>(a.sup_mask + n);
+                else {
+                    masked4[t] = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) masked4[t] |= (unsigned)(n + i < a.N ? a.sup_mask[n + i] : 1) << (8 * i);
+                }
             }
             tb = a.cfg->time_token_begin; ws_tok = a.cfg->whitespace_token; eot_tok = a.cfg->end_token; nots_tok = a.cfg->no_timestamps_token;
         }
     }
 
     // ---- weight stream x activation planes on the matrix cores
-    f32x16 acc_h = {0}, acc_l = {0};
+    f32x16 acc_h[RT], acc_l[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_h[t][r] = 0.0f; acc_l[t][r] = 0.0f; }
     auto stats_to_lds = [&]() {
         // LayerNorm statistics: each thread Chan-combines its <= 5 row-tile partials (ascending), the 8 threads of a slot meet in LDS
         if constexpr (kLN) {
@@ -218,10 +242,12 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
         }
     };
     {
-        u32x4 wa[TC], ha[TC], la[HILO ? TC : 1], wb[TC], hb[TC], lb[HILO ? TC : 1];
-        auto ld = [&](u32x4 (&w)[TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
+        u32x4 wa[RT][TC], ha[TC], la[HILO ? TC : 1], wb[RT][TC], hb[TC], lb[HILO ? TC : 1];
+        auto ld = [&](u32x4 (&w)[RT][TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i) w[i] = NTW ? __builtin_nontemporal_load(wp + (size_t)(c * TC + i) * 64) : wp[(size_t)(c * TC + i) * 64];
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < TC; ++i) w[t][i] = NTW ? __builtin_nontemporal_load(wp[t] + (size_t)(c * TC + i) * 64) : wp[t][(size_t)(c * TC + i) * 64];
 #pragma unroll
             for (int i = 0; i < TC; ++i) h[i] = hp[(size_t)(c * TC + i) * 64];
             if constexpr (HILO) {
@@ -229,12 +255,15 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
                 for (int i = 0; i < TC; ++i) l[i] = lp[(size_t)(c * TC + i) * 64];
             }
         };
-        auto mm = [&](const u32x4 (&w)[TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
+        auto mm = [&](const u32x4 (&w)[RT][TC], const u32x4 (&h)[TC], const u32x4 (&l)[HILO ? TC : 1]) {
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
-                const f16x8 wf = __builtin_bit_cast(f16x8, w[i]);
-                acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h, 0, 0, 0);
-                if constexpr (HILO) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const f16x8 wf = __builtin_bit_cast(f16x8, w[t][i]);
+                    acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, h[i]), acc_h[t], 0, 0, 0);
+                    if constexpr (HILO) acc_l[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(f16x8, l[i]), acc_l[t], 0, 0, 0);
+                }
             }
         };
         const int nch = a.tw / TC;
@@ -254,27 +283,35 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
     stats_to_lds();       // after the stream: the statistics are epilogue operands (timeline probe: waiting for them up front cost 1 us per launch)
     D32_STAMP(3);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = HILO ? fmaf(acc_l[r], 1.0f / 2048.0f, acc_h[r]) : acc_h[r];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[t][wave][r][lane] = HILO ? fmaf(acc_l[t][r], 1.0f / 2048.0f, acc_h[t][r]) : acc_h[t][r];
     __syncthreads();
     D32_STAMP(4);
-    float v[4];
+    float v[RT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[t][i] = ((red[t][0][4 * wave + i][lane] + red[t][1][4 * wave + i][lane]) + red[t][2][4 * wave + i][lane]) + red[t][3][4 * wave + i][lane];
 
     // ---- K split across workgroups: publish, ticket, the last arriver sums the slices in index order.  Write-through (sc1)
     // 16-byte stores, a drained vmcnt in every storing wave, one relaxed ticket; the finisher reads the slabs with sc1 loads, which
     // bypass its L1 and are served by L2 - no agent-scope fence on either side (MI355X_MICROARCH.md "handoff-flag", R1).
     if (a.ks > 1) {
-        float* base = a.part + (((size_t)bt * n_rt + rt) * a.ks) * 1024 + tid * 4;
-        {
-            const f32x4 pv4 = {v[0], v[1], v[2], v[3]};
-            float* mine = base + (size_t)ksi * 1024;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
+        // (the slices of row tile rt0 + t live where a workgroup of its own would put them; ONE ticket per group of row tiles: its tiles always travel together)
+        float* base = a.part + (((size_t)bt * n_rt + rt0) * a.ks) * 1024 + tid * 4;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            if (t < n_mine) {
+                const f32x4 pv4 = {v[t][0], v[t][1], v[t][2], v[t][3]};
+                float* mine = base + ((size_t)t * a.ks + ksi) * 1024;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine), "v"(pv4) : "memory");
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            int* cnt = a.ticket + bt * n_rt + rt;
+            int* cnt = a.ticket + bt * n_rt + rt0;
             const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == a.ks - 1);
             if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
@@ -285,33 +322,45 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }
             return;
         }
-        float pv[8][4];
+        float pv[RT][8][4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {       // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
-            const float* p = base + (size_t)(s < a.ks ? s : 0) * 1024;
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pv[s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+            for (int s = 0; s < 8; ++s) {       // every load is issued before the first add; slices past ks re-read slice 0 and are dropped
+                const float* p = base + ((size_t)(t < n_mine ? t : 0) * a.ks + (s < a.ks ? s : 0)) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float t = pv[0][i];
+                for (int i = 0; i < 4; ++i) pv[t][s][i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
-            for (int s = 1; s < 8; ++s) t += (s < a.ks) ? pv[s][i] : 0.0f;
-            v[i] = t;
-        }
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x_ = pv[t][0][i];
+#pragma unroll
+                for (int s = 1; s < 8; ++s) x_ += (s < a.ks) ? pv[t][s][i] : 0.0f;
+                v[t][i] = x_;
+            }
     }
 
     D32_STAMP(5);
-    // ---- epilogues
-    float y[4];
+    // ---- epilogues (per row tile of this workgroup; every condition below is workgroup-uniform or guards stores only)
+    float mu = 0.0f, rstd = 0.0f;
     if constexpr (kLN) {
         float cn = 0.0f, cm = 0.0f, cM2 = 0.0f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) chan_merge(cn, cm, cM2, st_l[s][j][0], st_l[s][j][1], st_l[s][j][2]);
-        const float mu = cm, rstd = rsqrtf(cM2 / (float)a.d + 1e-5f);
-        const float g4[4] = {e0.x, e0.y, e0.z, e0.w}, c4[4] = {e1.x, e1.y, e1.z, e1.w};
+        mu = cm; rstd = rsqrtf(cM2 / (float)a.d + 1e-5f);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(rstd, v[i] - mu * g4[i], c4[i]);
+  for (int t = 0; t < RT; ++t) {
+    if (t >= n_mine) break;
+    if constexpr (MODE == P32_RESID || MODE == P32_LOGITS) { if (t > 0) __syncthreads(); }      // the previous tile's readers are done with xs_raw
+    const int rt = rt0 + t, n = rt * 32 + 4 * sub;
+    float y[4];
+    if constexpr (kLN) {
+        const float g4[4] = {e0[t].x, e0[t].y, e0[t].z, e0[t].w}, c4[4] = {e1[t].x, e1[t].y, e1[t].z, e1[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(rstd, v[t][i] - mu * g4[i], c4[i]);
     }
     if constexpr (MODE == P32_QKV) {
         if (valid && live_l) {
@@ -338,11 +387,12 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             *reinterpret_cast<f16x4*>(a.h_out_lo + o) = lo;
         }
     } else if constexpr (MODE == P32_RESID) {
-        const float b4[4] = {e0.x, e0.y, e0.z, e0.w}, x4[4] = {e1.x, e1.y, e1.z, e1.w};
+        const float b4[4] = {e0[t].x, e0[t].y, e0[t].z, e0[t].w}, x4[4] = {e1[t].x, e1[t].y, e1[t].z, e1[t].w};
         float xn[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[i] + b4[i]);
-        d32_resid_tail(xn, valid && live_l, bt, rt, n_rt, n, j, gb, tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out, xs);
+        for (int i = 0; i < 4; ++i) xn[i] = x4[i] + (v[t][i] + b4[i]);
+        d32_resid_tail(xn, valid && live_l, bt, rt, n_rt, n, j, gb, tid, a.d, a.x, a.gamma_next, a.zhi_out, a.zlo_out, a.stat_out,
+                       reinterpret_cast<float (*)[33]>(xs_raw));
     } else {    // P32_LOGITS
         if (r16) {      // reference-numerics switch: the TextDecoder output is a Float16 array (Core/Models.swift:1041)
 #pragma unroll
@@ -361,24 +411,25 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
         if (a.stats) {
             // fused greedy sampler, part 1 (decoder.hip logits_block_stats): the index-predicate filters of LogitsFilter.swift on this
             // thread's 4 ids, then (max, sum exp, argmax) separately for text and timestamp ids; the 8 threads of a slot meet in LDS
-            SoftStat t{-INFINITY, 0.0f, 0x7fffffff}, u{-INFINITY, 0.0f, 0x7fffffff};
+            SoftStat t_{-INFINITY, 0.0f, 0x7fffffff}, u_{-INFINITY, 0.0f, 0x7fffffff};
             const int blank = rules[0], ts_active = rules[1];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int id = n + i;
-                bool masked = ((masked4 >> (8 * i)) & 0xff) != 0 || id >= a.N;                                   // SuppressTokensFilter
+                bool masked = ((masked4[t] >> (8 * i)) & 0xff) != 0 || id >= a.N;                                   // SuppressTokensFilter
                 masked |= blank && (id == ws_tok || id == eot_tok);                                               // SuppressBlankFilter
                 masked |= ts_active && (id == nots_tok || (id >= rules[2] && id < rules[3]) || (id >= rules[4] && id < rules[5]));   // TimestampRulesFilter
-                if (!masked) { if (id < tb) stat_merge(t, y[i], 1.0f, id); else stat_merge(u, y[i], 1.0f, id); }
+                if (!masked) { if (id < tb) stat_merge(t_, y[i], 1.0f, id); else stat_merge(u_, y[i], 1.0f, id); }
             }
-            float* rec = xs_raw + (size_t)(sub * 32 + j) * 6;
-            rec[0] = t.m; rec[1] = t.s; rec[2] = __int_as_float(t.i); rec[3] = u.m; rec[4] = u.s; rec[5] = __int_as_float(u.i);
+            float* xr = xs_raw;
+            float* rec = xr + (size_t)(sub * 32 + j) * 6;
+            rec[0] = t_.m; rec[1] = t_.s; rec[2] = __int_as_float(t_.i); rec[3] = u_.m; rec[4] = u_.s; rec[5] = __int_as_float(u_.i);
             __syncthreads();
             if (tid < 32 && valid && live_l) {
                 SoftStat T{-INFINITY, 0.0f, 0x7fffffff}, U{-INFINITY, 0.0f, 0x7fffffff};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const float* r_ = xs_raw + (size_t)(s * 32 + tid) * 6;
+                    const float* r_ = xr + (size_t)(s * 32 + tid) * 6;
                     stat_merge(T, r_[0], r_[1], __float_as_int(r_[2]));
                     stat_merge(U, r_[3], r_[4], __float_as_int(r_[5]));
                 }
@@ -388,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             }
         }
     }
+  }     // row tiles of this workgroup
     D32_STAMP(6);
     if constexpr (MODE == P32_Q) { if (a.gate && blockIdx.x == 0 && tid == 0) xattn_gate_acquire(a.gate); }    // dec_shared.h
 }
@@ -456,12 +508,25 @@ static void launch_tc_w(const P32Args& a, dim3 grid, hipStream_t st) {
     static const int tc_env = env_int32("WH_D32_TC", 0);
     static const int tc_bt = env_int32("WH_D32_TC_BT", 5);
     const int tc_cap = tc_env > 0 ? tc_env : (a.n_bt >= tc_bt ? 2 : 5);
+    if constexpr (MODE != P32_LOGITS && MODE != P32_Q) {
+        if (a.rt == 4) {    // four row tiles per workgroup: chunks of 1 k-tile (230 - 244 registers: two workgroups per CU)
+            dec32_proj_kernel<MODE, HILO, 1, NTW, 4><<<grid, 256, 0, st>>>(a);
+            return;
+        }
+    }
+    if (a.rt >= 2) {        // two row tiles per workgroup (launch_dec32_proj decides): chunks of 4 k-tiles (236 - 256 registers, two workgroups per CU like chunks of 2: 2823 -> 2834 audio-s/s), else 2 or 1; WH_D32_RT2_TC: A/B
+        static const int tc2 = env_int32("WH_D32_RT2_TC", 4);
+        if (tw % 4 == 0 && tc2 >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW, 2><<<grid, 256, 0, st>>>(a);
+        else if (tw % 2 == 0 && tc2 >= 2) dec32_proj_kernel<MODE, HILO, 2, NTW, 2><<<grid, 256, 0, st>>>(a);
+        else dec32_proj_kernel<MODE, HILO, 1, NTW, 2><<<grid, 256, 0, st>>>(a);
+        return;
+    }
     // chunks of <= 5 k-tiles: 6 would put the LOGITS instantiation at 226 VGPRs + accumulators = one wave per SIMD (tiny.en: 22 -> 47 us)
-    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW><<<grid, 256, 0, st>>>(a);
-    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW><<<grid, 256, 0, st>>>(a);
-    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3, NTW><<<grid, 256, 0, st>>>(a);
-    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW><<<grid, 256, 0, st>>>(a);
-    else dec32_proj_kernel<MODE, HILO, 1, NTW><<<grid, 256, 0, st>>>(a);
+    if (tw % 5 == 0 && tc_cap >= 5) dec32_proj_kernel<MODE, HILO, 5, NTW, 1><<<grid, 256, 0, st>>>(a);
+    else if (tw % 4 == 0 && tc_cap >= 4) dec32_proj_kernel<MODE, HILO, 4, NTW, 1><<<grid, 256, 0, st>>>(a);
+    else if (tw % 3 == 0 && tc_cap >= 3) dec32_proj_kernel<MODE, HILO, 3, NTW, 1><<<grid, 256, 0, st>>>(a);
+    else if (tw % 2 == 0) dec32_proj_kernel<MODE, HILO, 2, NTW, 1><<<grid, 256, 0, st>>>(a);
+    else dec32_proj_kernel<MODE, HILO, 1, NTW, 1><<<grid, 256, 0, st>>>(a);
 }
 template <int MODE, bool HILO>
 static void launch_tc(const P32Args& a, dim3 grid, hipStream_t st) {
@@ -478,7 +543,19 @@ void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) 
     a.ks = dec32_ksplit(mode, a.N, a.K, a.K > a.N);      // K > N: the fc2 shape (its own split knob)
     a.tw = a.K / (64 * a.ks);
     a.n_bt = n_bt;
-    const int nx = ((a.N + 31) / 32) * a.ks;
+    // Row tiles per workgroup (round 6).  From five batch tiles on (160- to 256-slot device batches) a launch is 320 - 1280 workgroups and its time follows the CUs it gets
+    // (alone at 256 slots, whole chip / 128 / 64 CUs: qkv 21 / 33 / 56 us, fc1 23 / 36 / 64, fc2 28 / 44 / 80, profiles/r06t_chain_on_cus_ab.jsonl): the wide projections are bound by
+    // the bytes their workgroups pull through the CUs' L1s - 3 KB per pair of matrix instructions (1 KB weight tile + 2 KB hi | lo planes) - and beside two cross-attention
+    // streams they have half of the chip or less.  Two row tiles per workgroup share the planes (2 KB per pair), four (qkv, fc1, fc2) 1.5 KB: headline 2738 -> 2825 (two) -> 2837
+    // audio-s/s (four), profiles/r06u .. r06w_*.  Same bits (a row tile's k-tiles meet the same wave in the same order).  WH_D32_RT_BT / WH_D32_RT4_BT (first batch-tile count
+    // with 2 / 4 row tiles; 99 = never) and WH_D32_RT4_MODES (bit 0 qkv, 1 fc1, 2 fc2) are the A/B knobs.
+    static const int rt_bt = env_int32("WH_D32_RT_BT", 5), rt4_bt = env_int32("WH_D32_RT4_BT", 5), rt4_modes = env_int32("WH_D32_RT4_MODES", 7);
+    a.rt = n_bt >= rt_bt ? 2 : 1;
+    {
+        const int bit = mode == P32_QKV ? 1 : mode == P32_FC1 ? 2 : (mode == P32_RESID && a.K > a.N) ? 4 : 0;
+        if (n_bt >= rt4_bt && (rt4_modes & bit) && ((a.N + 31) / 32) % 4 == 0) a.rt = 4;
+    }
+    const int nx = (((a.N + 31) / 32 + a.rt - 1) / a.rt) * a.ks;
     const dim3 grid((unsigned)(((nx + 7) / 8) * 8 * n_bt));
     ProfScope ps_(a.prof_kind, st);
     switch (mode) {

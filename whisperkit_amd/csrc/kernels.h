@@ -252,6 +252,7 @@ struct P32Args {
     int batch, N, K, d, n_head, n_vocab;
     int ks, tw;              // K splits across workgroups; 16-wide k tiles per wave = K / (64 ks)
     int n_bt;                // batch tiles of this launch (set by the launcher)
+    int rt;                  // weight-row tiles per workgroup, 1 or 2 (set by the launcher)
     const f16* Wt;
     const f16 *zhi, *zlo;    // input planes (zlo == null: single f16 plane)
     const float2* stat_in; int n_stat; const float *fold_g, *fold_c;           // LayerNorm fold (QKV, Q, FC1, LOGITS)
