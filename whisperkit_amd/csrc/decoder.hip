@@ -905,6 +905,9 @@ void launch_decoder_step(const DecodeBuffers& db, const SamplerCfg* cfg_dev, con
             xa.spw = X.spw;
             xa.dbg = debug_buffer() ? debug_buffer() + (size_t)KK_DEC_CROSS_ATTN * 4096 * 8 : nullptr;
             launch_xabs_qk(xa, n_bt, st);
+            // (Round 6, measured and rejected, profiles/r06x_*, r06y_*: xabs_attn on a CU-masked HIP stream of its own - the stream kernels of all sessions confined to the first
+            // n CUs, the launch chain on the rest or everywhere - joined to the session stream by an event pair per layer, eager launches: 2796 -> 2314 - 2387 audio-s/s for
+            // n = 128 .. 255, i.e. the two cross-queue hops per layer cost 15 % before any partition can pay; with the chain confined to the other 96 CUs 1830.)
             launch_xabs_attn(xa, st);
             launch_xabs_vup(xa, n_bt, st);
         } else {
