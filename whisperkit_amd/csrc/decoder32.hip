@@ -183,19 +183,25 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
             sp[i] = a.stat_in[((size_t)bt * a.n_stat + idx) * 32 + j];
         }
     }
+    // (four row tiles: the 32 registers of these operands are needed by the third stage of the weight ring; they are requested behind the last chunk instead)
+    constexpr bool kLateOperands = RT >= 4;
+    constexpr int NB = RT >= 4 ? 3 : 2;             // stages of the weight / plane ring: NB - 1 chunks in flight under the MFMAs of the current one
     float4 e0[RT], e1[RT];                          // LN modes: g, c;  RESID: bias, old x
     int pos_l = 0, live_l = 0;
+    auto load_operands = [&]() {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int n = min(rt0 + t, n_rt - 1) * 32 + 4 * sub;
-        if constexpr (kLN) {
-            e0[t] = *reinterpret_cast<const float4*>(a.fold_g + n);
-            e1[t] = *reinterpret_cast<const float4*>(a.fold_c + n);
-        } else {
-            e0[t] = *reinterpret_cast<const float4*>(a.bias + n);
-            e1[t] = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
+        for (int t = 0; t < RT; ++t) {
+            const int n = min(rt0 + t, n_rt - 1) * 32 + 4 * sub;
+            if constexpr (kLN) {
+                e0[t] = *reinterpret_cast<const float4*>(a.fold_g + n);
+                e1[t] = *reinterpret_cast<const float4*>(a.fold_c + n);
+            } else {
+                e0[t] = *reinterpret_cast<const float4*>(a.bias + n);
+                e1[t] = *reinterpret_cast<const float4*>(a.x + (size_t)gb * a.d + n);
+            }
         }
-    }
+    };
+    if constexpr (!kLateOperands) load_operands();
     if (valid) { live_l = slot_live(a.seq + gb); if constexpr (MODE == P32_QKV) pos_l = a.seq[gb].token_index; }
     int rules[6] = {0, 0, 0, 0, 0, 0};
     unsigned masked4[RT];
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
         }
     };
     {
-        u32x4 wa[RT][TC], ha[TC], la[HILO ? TC : 1], wb[RT][TC], hb[TC], lb[HILO ? TC : 1];
+        u32x4 w_[NB][RT][TC], h_[NB][TC], l_[NB][HILO ? TC : 1];
         auto ld = [&](u32x4 (&w)[RT][TC], u32x4 (&h)[TC], u32x4 (&l)[HILO ? TC : 1], int c) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
@@ -266,20 +272,26 @@ __global__ __launch_bounds__(256, 2) void dec32_proj_kernel(const P32Args a) {
                 }
             }
         };
+        // ring of NB stages, the loop unrolled by NB so that every stage index is a constant: chunk c lives in stage c % NB; while chunk c is multiplied the
+        // chunks c + 1 .. c + NB - 1 are in flight (NB = 2: the double buffer of rounds 2 - 5, instruction for instruction)
         const int nch = a.tw / TC;
-        ld(wa, ha, la, 0);
+#pragma unroll
+        for (int u = 0; u + 1 < NB; ++u)
+            if (u < nch) ld(w_[u], h_[u], l_[u], u);
         D32_STAMP(1);
 #pragma unroll 1
-        for (int c = 0; c < nch; c += 2) {
-            if (c + 1 < nch) ld(wb, hb, lb, c + 1);
-            __builtin_amdgcn_sched_barrier(0);      // loads of the next chunk stay ahead of this chunk's MFMAs
-            mm(wa, ha, la);
-            if (c == 0) D32_STAMP(2);
-            if (c + 2 < nch) ld(wa, ha, la, c + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < nch) mm(wb, hb, lb);
+        for (int c = 0; c < nch; c += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                constexpr int kAhead = NB - 1;
+                if (c + u + kAhead < nch) ld(w_[(u + kAhead) % NB], h_[(u + kAhead) % NB], l_[(u + kAhead) % NB], c + u + kAhead);
+                __builtin_amdgcn_sched_barrier(0);      // loads of the next chunks stay ahead of this chunk's MFMAs
+                if (c + u < nch) mm(w_[u], h_[u], l_[u]);
+                if (u == 0 && c == 0) D32_STAMP(2);
+            }
         }
     }
+    if constexpr (kLateOperands) load_operands();
     stats_to_lds();       // after the stream: the statistics are epilogue operands (timeline probe: waiting for them up front cost 1 us per launch)
     D32_STAMP(3);
 #pragma unroll
