@@ -377,8 +377,8 @@ def test_library_carries_the_staged_epilogue_kernels():
 
 
 def test_library_carries_the_grouped_row_tile_projection_kernels():
-    """csrc/decoder32.hip (round 6): from five batch tiles on a decoder projection workgroup multiplies its activation planes by TWO weight-row tiles (every
-    projection, the logits included) or FOUR (qkv, fc1, the residual projections = fc2) - dec32_proj_kernel<MODE, HILO, TC, NTW, RT>.  The one-tile kernels stay
+    """csrc/decoder32.hip (round 6): from four batch tiles on a decoder projection workgroup multiplies its activation planes by TWO weight-row tiles (every
+    projection, the logits included) or, from five on, FOUR (qkv, fc1, the residual projections = fc2) - dec32_proj_kernel<MODE, HILO, TC, NTW, RT>.  The one-tile kernels stay
     for smaller batches (and are what the bit-identity tests of tests/test_gpu_round6.py compare the grouped ones with).  All three sets must be in the library."""
     from whisperkit_amd import _lib
     blob = open(os.path.join(os.path.dirname(_lib.__file__), "libwhisperhip.so"), "rb").read()

@@ -233,7 +233,7 @@ def test_device_batch_shapes_of_the_multi_gpu_runs_decode_every_slot_like_a_lone
     cross-attention forced with 1 split): slots of the first, a middle and the last batch tile and both sides of the workgroup's slot boundary
     against ONE-slot sessions of the same audio - encoder output, tokens, log-probs, bit for bit.
     The same comparison pins the grouped projection kernels (csrc/decoder32.hip, round 6): from five batch tiles on (160 slots: the threshold case) a
-    projection workgroup handles two weight-row tiles, the qkv / fc1 / fc2 projections four; the ONE-slot sessions run the one-tile kernels."""
+    projection workgroup handles two weight-row tiles (from four tiles on: the 112-slot case; 160 slots = the threshold of the four-tile form), the qkv / fc1 / fc2 projections four; the ONE-slot sessions run the one-tile kernels."""
     dims = weights.MODEL_DIMS["test-large-v3-l2"]
     model = api.Model(dims, weights.synthetic_state_dict(dims, seed=7))
     b1 = -(-slots // spw)

@@ -555,13 +555,14 @@ void launch_dec32_proj(int mode, const P32Args& a_in, int n_bt, hipStream_t st) 
     a.ks = dec32_ksplit(mode, a.N, a.K, a.K > a.N);      // K > N: the fc2 shape (its own split knob)
     a.tw = a.K / (64 * a.ks);
     a.n_bt = n_bt;
-    // Row tiles per workgroup (round 6).  From five batch tiles on (160- to 256-slot device batches) a launch is 320 - 1280 workgroups and its time follows the CUs it gets
+    // Row tiles per workgroup (round 6).  From four to five batch tiles on (128- to 256-slot device batches) a launch is 320 - 1280 workgroups and its time follows the CUs it gets
     // (alone at 256 slots, whole chip / 128 / 64 CUs: qkv 21 / 33 / 56 us, fc1 23 / 36 / 64, fc2 28 / 44 / 80, profiles/r06t_chain_on_cus_ab.jsonl): the wide projections are bound by
     // the bytes their workgroups pull through the CUs' L1s - 3 KB per pair of matrix instructions (1 KB weight tile + 2 KB hi | lo planes) - and beside two cross-attention
     // streams they have half of the chip or less.  Two row tiles per workgroup share the planes (2 KB per pair), four (qkv, fc1, fc2) 1.5 KB: headline 2738 -> 2825 (two) -> 2837
     // audio-s/s (four), profiles/r06u .. r06w_*.  Same bits (a row tile's k-tiles meet the same wave in the same order).  WH_D32_RT_BT / WH_D32_RT4_BT (first batch-tile count
-    // with 2 / 4 row tiles; 99 = never) and WH_D32_RT4_MODES (bit 0 qkv, 1 fc1, 2 fc2) are the A/B knobs.
-    static const int rt_bt = env_int32("WH_D32_RT_BT", 5), rt4_bt = env_int32("WH_D32_RT4_BT", 5), rt4_modes = env_int32("WH_D32_RT4_MODES", 7);
+    // with 2 / 4 row tiles; 99 = never) and WH_D32_RT4_MODES (bit 0 qkv, 1 fc1, 2 fc2) are the A/B knobs.  Thresholds (profiles/r06ad_*): 128-slot batches x 3 in flight 2666 -> 2744
+    // with two row tiles (four: 2737), 64-slot batches 2350 -> 2345 with two, 2229 with four: two from four batch tiles on, four from five.
+    static const int rt_bt = env_int32("WH_D32_RT_BT", 4), rt4_bt = env_int32("WH_D32_RT4_BT", 5), rt4_modes = env_int32("WH_D32_RT4_MODES", 7);
     a.rt = n_bt >= rt_bt ? 2 : 1;
     {
         const int bit = mode == P32_QKV ? 1 : mode == P32_FC1 ? 2 : (mode == P32_RESID && a.K > a.N) ? 4 : 0;
