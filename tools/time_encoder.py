@@ -10,7 +10,10 @@ from whisperkit_amd.synth import synthetic_chunk
 name = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
 batches = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "8").split(",")]
 dims = weights.MODEL_DIMS[name]
-model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0))
+sd = weights.synthetic_state_dict(dims, seed=0)
+if os.environ.get("WH_ZERO_WEIGHTS") == "1":       # DVFS probe: the same kernels, launches and bytes on all-zero operands (every GEMM multiplies zeros): a kernel that
+    sd = {k: np.zeros_like(v) for k, v in sd.items()}       # gets faster is power-limited, not schedule-limited (MI355X_MICROARCH.md "DVFS give-back")
+model = api.Model(dims, sd)
 for B in batches:
     s = api.Session(model, B)
     for b in range(B):

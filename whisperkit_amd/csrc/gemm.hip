@@ -556,152 +556,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- 256 x 256 x 64 tile, ONE wave per SIMD (round 6; WH_GEMM_W4)
-// The same tile, stages, LDS image, tile walk and epilogues as gemm256_kernel, with 4 waves (2 x 2) of 128 x 128 wave tiles instead of 8 waves of 128 x 64:
-// a K-tile costs the workgroup 128 KB of fragment reads instead of 192 KB (32 instead of 48 ds_read_b128 per SIMD), the 256 accumulator registers of a
-// lane live in the upper half of the 512-register file, and there is no partner wave: a wave hides its own fragment reads (the next 16-wide k-step's 8
-// ds_read_b128, double-buffered in registers) and its 16 LDS-DMA pieces per K-tile in the issue gaps of its 64 MFMAs.  ONE workgroup barrier per K-tile:
-// before the k-step-3 MFMAs of tile t every wave has its pieces of tile t + 1 landed (vmcnt) and its reads of tile t complete (lgkmcnt); behind the barrier
-// it reads k-step 0 of tile t + 1 and issues the pieces of tile t + 2 into the stage tile t has just left (half of them under these 16 MFMAs, half under
-// the next 16).  Per output element the k-steps accumulate in ascending order into one accumulator, operands in gemm256_kernel's order: the same bits.
-template <int EPI, int MODE>
-__global__ __launch_bounds__(256) void gemm256w_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [2 stages][A 32 KB | B 32 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int tiles_n = (a.N + 255) >> 8, tiles_m = (a.M + 255) >> 8;
-    constexpr int GM = 8;
-    const int gsz = GM * tiles_n, grp = wg / gsz, first_m = grp * GM;
-    const int gm = min(tiles_m - first_m, GM), in_g = wg - grp * gsz;
-    const int m0 = (first_m + in_g % gm) << 8, n0 = (in_g / gm) << 8;
-
-    const int srow = tid >> 3;                                  // 0 .. 31
-    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);             // (row >> 1) & 7 of row j * 32 + srow
-    const f16* src[16];      // pieces 0..7: A rows j * 32 + srow, 8..15: W rows
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int m = min(m0 + j * 32 + srow, a.M - 1);
-        src[j] = a.A + (long long)(m / a.a_rows_per_batch) * a.a_batch_stride + (long long)(m % a.a_rows_per_batch) * a.lda + chunk * 8;
-        const int n = min(n0 + j * 32 + srow, a.N - 1);
-        src[8 + j] = a.W + (long long)n * a.K + chunk * 8;
-    }
-    auto piece = [&](int p, int kt) {
-        unsigned char* dst = smem + (kt & 1) * 65536 + (p >> 3) * 32768 + (p & 7) * 4096 + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * 64),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-
-    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
-    const int a_row_off = (wm * 128 + fr) * 128, b_row_off = 32768 + (wn * 128 + fr) * 128;
-    const int nk = a.K >> 6;
-#define W4_SB() __builtin_amdgcn_sched_barrier(0)
-    auto body = [&](auto swap_tag) {
-        constexpr bool SWAP = decltype(swap_tag)::value;
-        f32x16 acc[2][4][2];                                    // [64-column half][32-row tile][32-column tile]: a half is gemm256_kernel's wave tile
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
-        f16x8 af[2][4], bf[2][4];
-        auto rd_pair = [&](auto buf_tag, int kt, int ks, int i) {   // fragments i (one of B, one of A) of 16-wide k-step ks of K-tile kt
-            constexpr int B = decltype(buf_tag)::value;
-            const unsigned char* sb = smem + (kt & 1) * 65536;
-            const int slot = ((2 * ks + fh) ^ swz) * 16;
-            bf[B][i] = *reinterpret_cast<const f16x8*>(sb + b_row_off + i * 4096 + slot);
-            af[B][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 4096 + slot);
-        };
-        // 16 MFMAs on the fragments in buffer B.  Among them go out: the 8 ds_read_b128 of the NEXT k-step into the other buffer (RD; two behind the second MFMA of every
-        // group of four - issued after this k-step's own operand wait, so that wait never includes them), and the wave's LDS-DMA pieces 0..7 / 8..15 of K-tile dma_kt (DMA = 0 / 1)
-        auto mm = [&](auto buf_tag, auto dma_tag, int dma_kt, auto rd_tag, int rkt, int rks) {
-            constexpr int B = decltype(buf_tag)::value, DMA = decltype(dma_tag)::value;
-            constexpr bool RD = decltype(rd_tag)::value;
-            constexpr std::integral_constant<int, 1 - B> other{};
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    f32x16& c = acc[jj >> 1][i][jj & 1];
-                    if constexpr (SWAP) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[B][jj], af[B][i], c, 0, 0, 0);
-                    else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[B][i], bf[B][jj], c, 0, 0, 0);
-                    if constexpr (RD) {
-                        if (jj == 1) { W4_SB(); rd_pair(other, rkt, rks, i); W4_SB(); }
-                    }
-                    if constexpr (DMA >= 0) {
-                        if (jj & 1) { W4_SB(); piece(DMA * 8 + 2 * i + (jj >> 1), dma_kt); W4_SB(); }
-                    }
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        constexpr std::integral_constant<int, 0> b0{};
-        constexpr std::integral_constant<int, 1> b1{};
-        constexpr std::integral_constant<int, -1> no_dma{};
-        constexpr std::true_type T{};
-        constexpr std::false_type F{};
-        // one K-tile.  A: the second half of tile t + 1's pieces goes out under k-step 0 (its first half went out behind the previous barrier; tile 1 is requested whole
-        // by the prologue); N: a tile t + 1 exists; B2: the first half of tile t + 2's pieces goes out under k-step 3, into the stage tile t has just left
-        auto ktile = [&](auto a_tag, auto n_tag, auto b_tag, int t) {
-            constexpr bool A = decltype(a_tag)::value, N = decltype(n_tag)::value, B2 = decltype(b_tag)::value;
-            if constexpr (A) mm(b0, b1, t + 1, T, t, 1); else mm(b0, no_dma, 0, T, t, 1);
-            W4_SB();
-            mm(b1, no_dma, 0, T, t, 2); W4_SB();
-            mm(b0, no_dma, 0, T, t, 3); W4_SB();
-            if constexpr (N) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); W4_SB();
-                if constexpr (B2) mm(b1, b0, t + 2, T, t + 1, 0); else mm(b1, no_dma, 0, T, t + 1, 0);
-            } else {
-                mm(b1, no_dma, 0, F, 0, 0);
-            }
-            W4_SB();
-        };
-        // prologue: tile 0 landed and visible, its k-step 0 in registers, tile 1 requested
-#pragma unroll
-        for (int p = 0; p < 16; ++p) piece(p, 0);
-        W4_SB(); asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W4_SB();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rd_pair(b0, 0, 0, i);
-        if (nk > 1) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p) piece(p, 1);
-        }
-        W4_SB();
-        if (nk >= 2) {
-            if (nk > 2) ktile(F, T, T, 0); else ktile(F, T, F, 0);
-#pragma unroll 1
-            for (int t = 1; t + 2 < nk; ++t) ktile(T, T, T, t);
-            if (nk > 2) ktile(T, T, F, nk - 2);
-        }
-        ktile(F, F, F, nk - 1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); W4_SB();      // every wave is past its last fragment read: the stages are dead
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int mw = m0 + wm * 128, nw = n0 + wn * 128 + h * 64;
-            if constexpr (MODE == 1 && kHasStagedEpilogue<EPI>) {
-                unsigned char* wl = smem + wave * epi::kWaveRegion;
-                if constexpr (!SWAP) epi_staged_vt(a, acc[h], wl, mw, nw, lane);
-                else if constexpr (EPI == EPI_RESID_F32) epi_staged_resid(a, acc[h], wl, mw, nw, lane);
-                else epi_staged_f16<EPI>(a, acc[h], wl, mw, nw, lane);
-            } else if constexpr (SWAP) gemm_epilogue_swapped<EPI, 4, 2, MODE == 2>(a, acc[h], mw, nw, lane);
-            else gemm_epilogue<EPI, 4, 2>(a, acc[h], mw, nw, lane);
-        }
-    };
-#undef W4_SB
-    if constexpr (EPI == EPI_QKV_ENC) {
-        if (n0 + wn * 128 >= 2 * a.d_model) body(std::false_type{});      // (2 d_model is a multiple of 256 at every width: a wave tile never straddles it)
-        else body(std::true_type{});
-    } else {
-        body(std::true_type{});
-    }
-}
+// (Round 6, built, measured and rejected, profiles/r06ae_*: gemm256w_kernel - the same tile, stages, LDS image, walk and epilogues with ONE wave per SIMD: 4 waves of 128 x 128
+// wave tiles, the 256 accumulators of a lane in AGPRs, 128 KB instead of 192 KB of fragment reads per K-tile, the next k-step's 8 ds_read_b128 and the wave's 16 LDS-DMA
+// pieces per K-tile in the issue gaps of its 64 MFMAs, one workgroup barrier per K-tile; 179 VGPRs + 256 AGPRs, no scratch, no accumulator copies in the loop.  Bit-identical
+// in every epilogue mode (7 width / slot cases) and NOT faster: qkv 3512 -> 3631 us, fc1 5354 -> 5542, fc2 4846 -> 4800, out projection 1590 -> 1668 at 256 chunks.  Two main
+// loops this different landing on the same time says the limit is not the loop: the same binary on all-zero operands runs the encoder in 2.05 instead of 2.55 ms per chunk
+// (qkv - 25 %, fc1 - 21 %, fc2 - 12 %, attention - 29 %; profiles/r06af_encoder_zero_operand_probe.jsonl) - the chip clocks these kernels to its power budget
+// (MI355X_MICROARCH.md "DVFS give-back").  Code in git history, commit "gemm256w_kernel".)
 
 // ---------------------------------------------------------------------------------------------- persistent tile loop (round 6; opt-in: WH_GEMM_PERSIST=1)
 // gemm256_kernel as a loop over tiles: one workgroup per CU walks its XCD's share of the grouped tile order, and the first K-tile of tile
@@ -918,13 +779,6 @@ static void launch_epi(const GemmArgs& a, hipStream_t st) {
                 static const int stagger = [] { const char* e = getenv("WH_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
                 static const int gm_env = [] { const char* e = getenv("WH_GEMM_GM"); int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
                 gemm256p_kernel<EPI, MODE><<<(unsigned)grid, 512, 163840, st>>>(a, (int)tiles256, stagger, gm_env);
-                return;
-            }
-            static const int w4 = [] { const char* e = getenv("WH_GEMM_W4"); return e ? atoi(e) : 0; }();
-            if (w4 && (2 * a.d_model) % 256 == 0) {       // one wave per SIMD, 128 x 128 wave tiles (gemm256w_kernel)
-                static PerDeviceOnce raised_w;
-                raised_w.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
-                gemm256w_kernel<EPI, MODE><<<(unsigned)tiles256, 256, 131072, st>>>(a);
                 return;
             }
             static PerDeviceOnce raised;
