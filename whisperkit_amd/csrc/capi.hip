@@ -450,6 +450,13 @@ static hipError_t create_session_stream(hipStream_t* st) {
     static std::atomic<int> counter{0};
     const char* e = getenv("WH_CU_PARTS");
     const int parts = e ? atoi(e) : 0;
+    // WH_STREAM_PRIORITIES = "p0,p1,..." (experiment, round 6): session k's stream gets hardware-queue priority p[k % n] (-1 high, 0 normal, 1 low) - a strict order
+    // between the sessions in flight instead of the queues' round robin when their workgroups compete for the same CUs.
+    if (const char* pr = getenv("WH_STREAM_PRIORITIES")) {
+        int p[8], n = 0;
+        for (const char* c = pr; *c && n < 8;) { p[n++] = atoi(c); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+        if (n > 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, p[counter.fetch_add(1) % n]);
+    }
     if (parts < 2) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
