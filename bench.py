@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (2495 TF measured, 32x32x16)
+MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA (v_mfma_f32_16x16x4_f32: exact f32, 64 FLOP/clk/SIMD; MI355X_MICROARCH.md) - the log-mel's DFT runs on it
 PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"
 AUDIO_SETS = 8             # distinct chunk sets a run cycles through (the 4 packed steps of a device batch carry 4 different sets, consecutive batches differ)
 T_START = time.perf_counter()
@@ -146,6 +147,13 @@ def measure_kernels(sess, dims, B, n_meas, decode_steps, model_name, steps_per_b
         table[name] = {"avg_us": round(avg[k], 3), "launches_measured": int(cnt[k]), "launches_per_step": round(per_step, 1),
                        "bound": bound, "alg_per_launch": int(amount), "achieved": round(ach, 2), "unit": unit,
                        "frac": round(ach / peak, 4), "share_of_step": None}
+    if "mel_power" in table:
+        # The log-mel's HBM figure above is what north_star asks for (GB/s on the mel path); what BOUNDS mel_power is its exact-f32 DFT on the f32 matrix
+        # cores (csrc/mel.hip: per frame two real GEMMs of K = 200 / 199 folded samples x 201 bins), so the entry carries that fraction as well.
+        flops = B * 3000 * (200 * 201 + 199 * 200) * 2.0
+        tf = flops / (table["mel_power"]["avg_us"] * 1e-6) / 1e12
+        table["mel_power"].update({"matrix_f32_flops_per_launch": int(flops), "matrix_f32_achieved_tflops": round(tf, 2), "matrix_f32_peak_tflops": MFMA_F32_PEAK_TF,
+                                   "matrix_f32_frac": round(tf / MFMA_F32_PEAK_TF, 4)})
     tot = sum(step_us.values())
     # HBM traffic per launch from the off-line PMC passes (profiles/*_pmc_traffic.json), when they were taken on this workload
     traffic = {}
