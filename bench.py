@@ -485,8 +485,8 @@ def long_audio_config(args, local_rank):
     kw = dict(firstTokenLogProbThreshold=None, compressionRatioThreshold=None, noSpeechThreshold=None, logProbThreshold=-1.0,
               temperatureFallbackCount=1, temperatureIncrementOnFallback=0.2, sampleLength=args.sample_length, seed=7)
 
-    def run(slots, mode=None, **extra):
-        sess = api.Session(model, slots, crossAttentionMode=mode)
+    def run(slots, mode=None, splits=None, **extra):
+        sess = api.Session(model, slots, crossAttentionMode=mode, crossAttentionSplits=splits)
         opts = api.DecodingOptions(**kw, **extra)
         sess.transcribeChunked(audio, opts)      # warm-up (graph capture)
         t0 = time.perf_counter()
@@ -523,7 +523,9 @@ def long_audio_config(args, local_rank):
                    "forced once per window (T = 0 greedy, then 0.2 with the seeded top-5 sampler) -> segments")
     # (the library's choice at 100 slots: the absorbed cross-attention, which reads the audio's one encoder output with cacheable loads when
     # slots share it - round 5, profiles/r05b_beam5_cross_attention_mode_ab.jsonl: 241 audio-s/s against 233 with fp32 K / V rows, the first round-5 form of the rows)
-    beam = run(100, beamSize=5)
+    # (4 key splits: the beams of an audio stream ONE encoder output as L2 hits, more workgroups win - 240 audio-s/s against 228 with the 2 splits a 100-slot session
+    # gets on its own, profiles/r06ah_beam5_key_splits.jsonl; include/whisperhip.h wh_session_create_tuned says so to beam-search callers)
+    beam = run(100, splits=4, beamSize=5)
     beam["note"] = ("NO REFERENCE BEHAVIOUR: the same workload with beam = 5 for the T = 0 pass (20 windows x 5 beams = 100 decoder slots, "
                     "openai/whisper BeamSearchDecoder semantics, host-ranked candidates per step), then the same sampled fallback; the "
                     "reference's BeamSearchTokenSampler is a fatalError stub (Core/Text/TokenSampler.swift:254-290)")

@@ -42,6 +42,9 @@ public final class HIPSession {
     public enum CrossAttentionMode: Int32 { case automatic = -1, keyValueRows = 0, absorbed = 1 }
     /// slots from which `.automatic` picks the absorbed path (wh_xabs_auto_min_slots: 28 since the K / V rows carry 24 bits; WH_XABS_MIN_SLOTS overrides)
     public static var absorbedFromSlots: Int { Int(wh_xabs_auto_min_slots()) }
+    /// key splits per slot an absorbed session of `maxBatch` slots gets with `keySplits: 0` (wh_xabs_auto_splits: slots x splits within one round of the
+    /// 256 CUs - 4 up to 64 slots, 3 up to 85, 2 up to 128, 1 beyond; beam-search callers pass 4, callers with several sessions in flight half of it)
+    public static func automaticKeySplits(maxBatch: Int) -> Int { Int(wh_xabs_auto_splits(Int32(maxBatch))) }
 
     /// slotsPerWorkgroup (wh_session_options, round 6): a workgroup of the absorbed cross-attention streams this many slots one after the other, so a
     /// launch takes ceil(batch / n) x keySplits workgroups whatever the batch (256-slot device batches, 1 split, 2 slots per workgroup = half of the

@@ -215,6 +215,8 @@ int wh_session_max_batch(const wh_session* s);
    decoder step of a window change the results in mode 1 - the reference passes encoder_output_embeds to every call as well. */
 int wh_session_cross_attention_mode(const wh_session* s);
 int wh_xabs_auto_min_slots(void);
+/* the automatic key-split count of an absorbed session of max_batch slots (see wh_session_create_tuned) */
+int wh_xabs_auto_splits(int max_batch);
 /* key splits per slot of the absorbed cross-attention (0 in K / V-row mode): slots x splits workgroups, one per CU, stream the
    encoder output; fixed at creation (bench.py prices the kernel's algorithmic bytes with it) */
 int wh_session_cross_attention_splits(const wh_session* s);
@@ -222,9 +224,14 @@ int wh_session_cross_attention_splits(const wh_session* s);
    (WH_ERR_INVALID_ARGUMENT when the model width does not support it) */
 int wh_session_create_with_mode(wh_model* m, int max_batch, int cross_attention_mode, wh_session** out);
 /* ... and the key splits per slot of the absorbed form: 0 automatic, 1 .. 4.  One workgroup per (slot, split) owns a CU while it
-   streams, so slots x splits is the share of the chip one session's cross-attention takes: 4 is fastest for a session running alone
-   (64 slots: 256 workgroups), 2 when several sessions are in flight on the GPU (the other sessions' kernels keep the other half;
-   profiles/r04ad_*).  Ignored in K / V-row mode. */
+   streams, so slots x splits is the share of the chip one session's cross-attention takes.  Automatic = wh_xabs_auto_splits(max_batch):
+   as many splits as keep slots x splits within one round of the 256 CUs - 4 up to 64 slots, 3 up to 85, 2 up to 128, 1 beyond - which is
+   fastest for a session running alone (profiles/r06ah_lone_session_key_splits.jsonl: 128 slots 7.64 -> 6.86 ms per decoder step against
+   the 4 splits every session got before, 256 slots 12.82 -> 10.92).  A caller that keeps several sessions in flight asks for half of that
+   (the other sessions' kernels keep the other half of the chip; profiles/r04ad_*); a beam-search caller (slots that share an encoder
+   output stream it as L2 hits: more workgroups win) asks for 4.  The split count fixes the order of the key-split combine: results are
+   bit-identical across batch sizes and sessions for EQUAL split counts - two sessions whose max_batch falls into different automatic
+   classes agree to ~1e-6 relative, not bit for bit, unless the caller pins the count.  Ignored in K / V-row mode. */
 int wh_session_create_tuned(wh_model* m, int max_batch, int cross_attention_mode, int cross_attention_splits, wh_session** out);
 /* ... and, since round 6, every creation knob in one struct (zero-initialise or wh_session_options_default; NULL = defaults):
      cross_attention_mode                 -1 automatic, 0 K / V rows, 1 absorbed          (as wh_session_create_with_mode)

@@ -338,6 +338,24 @@ def test_swift_shim_source_names_the_session_entry_points_of_the_header():
     assert "fp32 K / V rows" not in swift and "24-bit rows" in swift
 
 
+def test_automatic_key_splits_keep_a_lone_session_within_one_round_of_the_chip():
+    """csrc/xabs.hip xabs_auto_splits (round 6, profiles/r06ah_lone_session_key_splits.jsonl): an absorbed session created without a split count gets as many key splits per
+    slot as keep slots x splits workgroups within the 256 CUs, at most 4, at least 1 - and the committed sweep says that choice is the fastest column at every batch it measured."""
+    from whisperkit_amd import _lib
+    f = _lib.load().wh_xabs_auto_splits
+    assert [f(b) for b in (1, 28, 32, 64, 65, 85, 86, 100, 128, 129, 192, 256)] == [4, 4, 4, 4, 3, 3, 2, 2, 2, 1, 1, 1]
+    for b in range(1, 257):
+        s = f(b)
+        assert 1 <= s <= 4 and (s == 1 or b * s <= 256) and (s == 4 or b * (s + 1) > 256), b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = [json.loads(l) for l in open(os.path.join(root, "profiles", "r06ah_lone_session_key_splits.jsonl"))]
+    for b in sorted({r["B"] for r in rows}):
+        ms = {r["splits"]: r["ms_per_step_wall"] for r in rows if r["B"] == b}
+        assert ms[f(b)] == min(ms.values()), (b, ms)
+    swift = open(os.path.join(root, "bindings", "swift", "Sources", "WhisperKitHIP", "HIPBackend.swift")).read()
+    assert "wh_xabs_auto_splits(" in swift
+
+
 def test_round5_bench_line_bookkeeping_is_per_bench_step():
     """The committed round-5 bench line (profiles/r05i_*: the final binary): a 128-slot device batch carries two 64-chunk bench steps, so the decoder kernels' launches_per_step is
     32 layers x 223 decoder steps / 2 = 3568 (the event pool used to overflow and report 6467 of 7136), launches x average duration of the dominant kernel

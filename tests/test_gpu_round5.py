@@ -150,7 +150,7 @@ def test_three_batch_tiles_with_a_ragged_last_tile_are_bit_identical_to_a_lone_s
         prompt = big.prefillPrompt(opts)
         res = big.decodeText(prompt, opts, batch=B)
         for b in check:
-            one = api.Session(model, 1, crossAttentionMode=mode)
+            one = api.Session(model, 1, crossAttentionMode=mode, crossAttentionSplits=big.crossAttentionSplits or None)     # (the automatic split count follows max_batch since round 6: 70 slots -> 3, one slot -> 4)
             one.padOrTrim(xs[b], 0)
             one.logMelSpectrogram(1); one.encodeFeatures(1); one.prepareDecoderInputs(1)
             for k, (t, p) in enumerate(steps):

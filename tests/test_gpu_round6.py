@@ -256,3 +256,45 @@ def test_device_batch_shapes_of_the_multi_gpu_runs_decode_every_slot_like_a_lone
         assert r1.tokens == res[b].tokens and r1.tokenLogProbs == res[b].tokenLogProbs, (slots, spw, b)
         one.close()
     big.close(); model.close()
+
+
+def test_automatic_key_splits_follow_the_session_size_and_equal_split_counts_give_equal_bits():
+    """csrc/xabs.hip xabs_auto_splits (round 6): an absorbed session created without a split count takes slots x splits within one round of the 256 CUs (4 / 3 / 2 / 1
+    splits up to 64 / 85 / 128 / 256 slots; K / V-row sessions report 0).  The split count fixes the order of the key-split combine, so a 100-slot session (2 splits on its
+    own) decodes every slot like a ONE-slot session that asks for 2 splits - bit for bit - and within the logits contract of a one-slot session with its own 4."""
+    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    model = api.Model(dims, weights.synthetic_state_dict(dims, seed=7))
+    for B in (28, 64, 65, 86, 129):
+        s = api.Session(model, B, crossAttentionMode=1)
+        assert s.crossAttentionSplits == api.Session.xabsAutoSplits(B) == max(1, min(4, 256 // B)), B
+        s.close()
+    s = api.Session(model, 20, crossAttentionMode=0)
+    assert s.crossAttentionSplits == 0
+    s.close()
+    slots, check = 100, [0, 31, 32, 99]
+    xs = {b: synthetic_chunk(700 + b) for b in check}
+    filler = synthetic_chunk(699)
+    opts = api.DecodingOptions(**NOFALLBACK, sampleLength=16)
+    big = api.Session(model, slots)                      # automatic mode (absorbed from 28 slots) and automatic splits
+    assert big.crossAttentionMode == 1 and big.crossAttentionSplits == 2
+    for b in range(slots):
+        big.padOrTrim(xs.get(b, filler), b)
+    big.logMelSpectrogram(slots); big.encodeFeatures(slots); big.prepareDecoderInputs(slots)
+    prompt = big.prefillPrompt(opts)
+    res = big.decodeText(prompt, opts, batch=slots)
+    for b in check:
+        one = api.Session(model, 1, crossAttentionMode=1, crossAttentionSplits=2)
+        one.padOrTrim(xs[b], 0)
+        one.logMelSpectrogram(1); one.encodeFeatures(1); one.prepareDecoderInputs(1)
+        r1 = one.decodeText(prompt, opts)[0]
+        assert r1.tokens == res[b].tokens and r1.tokenLogProbs == res[b].tokenLogProbs, b
+        one.close()
+        four = api.Session(model, 1, crossAttentionMode=1)
+        assert four.crossAttentionSplits == 4
+        four.padOrTrim(xs[b], 0)
+        four.logMelSpectrogram(1); four.encodeFeatures(1); four.prepareDecoderInputs(1)
+        r4 = four.decodeText(prompt, opts)[0]
+        assert r4.tokens == res[b].tokens, b
+        np.testing.assert_allclose(r4.tokenLogProbs, res[b].tokenLogProbs, rtol=0, atol=1e-3)
+        four.close()
+    big.close(); model.close()

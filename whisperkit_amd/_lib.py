@@ -137,6 +137,7 @@ SYMBOLS = {
     "wh_session_cross_attention_mode": (I, [VP]),
     "wh_session_cross_attention_splits": (I, [VP]),
     "wh_xabs_auto_min_slots": (I, []),
+    "wh_xabs_auto_splits": (I, [I]),
     "wh_session_step_graph_count": (I, [VP]),
     "wh_session_set_window_hooks": (I, [VP, C.POINTER(WhWindowHooks)]),
     "wh_transcription_set_segment_times": (I, [VP, I, F, F]),

@@ -481,6 +481,12 @@ class Session:
         """slots from which a session created without a crossAttentionMode runs the absorbed cross-attention"""
         return int(L.load().wh_xabs_auto_min_slots())
 
+    @staticmethod
+    def xabsAutoSplits(maxBatch: int) -> int:
+        """key splits per slot an absorbed session of maxBatch slots gets when crossAttentionSplits is None: slots x splits within one round of the 256 CUs
+        (4 up to 64 slots, 3 up to 85, 2 up to 128, 1 beyond; beam-search callers ask for 4, callers with several sessions in flight for half of it)"""
+        return int(L.load().wh_xabs_auto_splits(int(maxBatch)))
+
     @property
     def crossAttentionSlotsPerWorkgroup(self) -> int:
         return int(self.lib.wh_session_cross_attention_slots_per_workgroup(self.handle))

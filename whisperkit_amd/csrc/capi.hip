@@ -569,6 +569,8 @@ extern "C" int wh_session_cross_attention_mode(const wh_session* s) { return s ?
 extern "C" int wh_session_step_graph_count(const wh_session* s) { return s ? (int)s->graphs.size() : -1; }
 extern "C" int wh_session_cross_attention_splits(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.n_split : 0) : -1; }
 extern "C" int wh_session_cross_attention_slots_per_workgroup(const wh_session* s) { return s ? (s->use_xabs ? s->xabs.spw : 0) : -1; }
+// key splits per slot an absorbed session of max_batch slots gets when the caller asks for none (xabs.hip xabs_auto_splits)
+extern "C" int wh_xabs_auto_splits(int max_batch) { return wh::xabs_auto_splits(max_batch); }
 // slots from which wh_session_create picks the absorbed cross-attention on its own (models whose width supports it)
 extern "C" int wh_xabs_auto_min_slots(void) {
     const char* e = getenv("WH_XABS_MIN_SLOTS");

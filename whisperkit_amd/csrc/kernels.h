@@ -284,6 +284,7 @@ constexpr int kXabsSplits = 4;      // most key splits per slot (buffer sizes); 
 // key splits of a session: one workgroup per (slot, split) owns a whole CU (LDS, registers), so slots x splits is the number of CUs the
 // kernel takes.  WH_XABS_SPLITS overrides (A/B).
 int xabs_splits(int max_batch);
+int xabs_auto_splits(int max_batch);     // the automatic choice without the WH_XABS_SPLITS override (wh_xabs_auto_splits)
 struct XabsLayerW {
     const f16* wkT;      // W_k^T tiles [H][d / 32][4][64][8] (A fragments of the Q' projection)
     const f16* wv_t;     // W_v in the decoder projection tiling [d / 32][d / 16][64][8]

@@ -592,11 +592,19 @@ static int xabs_env(const char* name, int dflt) { const char* e = getenv(name); 
 
 bool xabs_supported(int d, int n_head) { return d % 256 == 0 && d >= 512 && d <= 1280 && n_head <= 32; }
 
+// Automatic key splits per slot (a constant of the session): as many as keep slots x splits workgroups within ONE round of the chip's 256 CUs, at most kXabsSplits.
+// Up to round 6 the choice was 4 whatever the batch; one large-v3 session alone, ms per decoder step at 4 / 3 / 2 / 1 splits (profiles/r06ah_lone_session_key_splits.jsonl):
+// 32 slots 4.21 / 4.52 / 5.16 / 7.28; 96 slots 6.45 / 7.08 / 5.95 / 7.93; 128 slots 7.64 / 7.97 / 6.86 / 8.72; 192 slots 9.84 / 10.52 / 10.04 / 9.55; 256 slots 12.82 / 12.09 / 11.45 / 10.92 -
+// a second round of workgroups pays the kernel's exposed prologue and epilogue again.  (Slots that share an encoder output - beam search - are the exception: their streams
+// are L2 hits and more workgroups win, 240 audio-s/s with 4 splits against 228 with 2 on configs[4]; such a caller asks for 4: wh_session_create_tuned.)
+int xabs_auto_splits(int max_batch) {
+    const int s = 256 / (max_batch > 0 ? max_batch : 1);
+    return s < 1 ? 1 : (s > kXabsSplits ? kXabsSplits : s);
+}
 int xabs_splits(int max_batch) {
     const int e = xabs_env("WH_XABS_SPLITS", 0);
     if (e >= 1 && e <= kXabsSplits) return e;
-    (void)max_batch;
-    return kXabsSplits;
+    return xabs_auto_splits(max_batch);
 }
 
 void launch_xabs_qk(const XabsArgs& a, int n_bt, hipStream_t st) {
