@@ -389,13 +389,15 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
         ns = sess.crossAttentionSplits
         if ns:
             # the cross-attention takes slots x splits workgroups, one per CU: with several sessions in flight it is configured to leave CUs to
-            # the other sessions' kernels.  The same kernel with 4 splits (the whole chip at 64 slots) is timed beside it, alone on the GPU.
+            # the other sessions' kernels.  The same kernel as a LONE session of this size runs it (the library's automatic key splits: slots x splits within one
+            # round of the 256 CUs, one slot per workgroup) is timed beside it, alone on the GPU.
             spw = max(1, sess.crossAttentionSlotsPerWorkgroup)
             rf["slots_per_workgroup"] = spw
             rf["workgroups"] = -(-slots // spw) * ns
             rf["cu_share"] = round(min(1.0, rf["workgroups"] / 256.0), 3)
-            if (ns != 4 or spw != 1) and whole_chip_leg:
-                s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=4, crossAttentionSlotsPerWorkgroup=max(1, slots * 4 // 256))
+            ns_alone = api.Session.xabsAutoSplits(slots)
+            if (ns != ns_alone or spw != 1) and whole_chip_leg:
+                s4 = api.Session(model, slots, crossAttentionMode=1, crossAttentionSplits=ns_alone, crossAttentionSlotsPerWorkgroup=1)
                 for k in range(G):
                     for b, x in enumerate(audio[k % n_sets]):
                         s4.padOrTrim(x, k * n_local + b)
@@ -405,10 +407,10 @@ def run_config(args, model_name, B, F, steps, warmup, world, rank, local_rank, d
                 s4_spw = max(1, s4.crossAttentionSlotsPerWorkgroup)
                 s4.close()
                 k4 = r4["kernels"]["dec_cross_attn"]
-                rf["same_kernel_alone_on_the_whole_chip"] = {"splits": 4, "slots_per_workgroup": s4_spw, "workgroups": -(-slots // s4_spw) * 4, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
+                rf["same_kernel_alone_on_the_whole_chip"] = {"splits": ns_alone, "slots_per_workgroup": s4_spw, "workgroups": -(-slots // s4_spw) * ns_alone, "avg_us": k4["avg_us"], "alg_per_launch": k4["alg_per_launch"],
                                                               "achieved": k4["achieved"], "unit": k4["unit"], "frac": k4["frac"]}
                 # (the same figures as scalars: a reader that keeps only the flat keys of `roofline` still carries them)
-                rf["whole_chip_splits"], rf["whole_chip_avg_us"], rf["whole_chip_achieved"], rf["whole_chip_frac"] = 4, k4["avg_us"], k4["achieved"], k4["frac"]
+                rf["whole_chip_splits"], rf["whole_chip_avg_us"], rf["whole_chip_achieved"], rf["whole_chip_frac"] = ns_alone, k4["avg_us"], k4["achieved"], k4["frac"]
         # whole step: algorithmic HBM bytes of every bandwidth-bound launch of one step / the step's share of the timed region
         hbm_bytes = sum(k["alg_per_launch"] * k["launches_per_step"] for k in rf["kernels"].values() if k["bound"] == "hbm")
         ms_step = elapsed / steps * 1e3
