@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
         v[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (c < d) v[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const float4*>(xr + c)) : *reinterpret_cast<const float4*>(xr + c);
+        if (c < d) {
+            if constexpr (NT) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + c)); v[i] = float4{t[0], t[1], t[2], t[3]}; }
+            else v[i] = *reinterpret_cast<const float4*>(xr + c);
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)d;
