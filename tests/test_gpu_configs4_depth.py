@@ -34,10 +34,23 @@ def rig():
     model.close()
 
 
+# The two windows' audio.  The beam cases need a fixture whose candidate rankings are decisive (minimum margin > 1e-2 in the oracle's own records): the margins follow the
+# encoder output's Float16 roundings, so a change of the encoder's arithmetic at the last-bit level (round 6: the vectorised LayerNorm) can turn a seed pair into a near-tie -
+# (77, 78) went from > 1e-2 to 3.3e-3 on the second window that way.  tools/configs4_fixture_search.py lists the margins of candidate pairs.
+AUDIO_SEEDS = (77, 78)
+
+
 @pytest.mark.parametrize("beam,mode", [(0, 0), (0, 1), (5, 1), (5, 0)], ids=["greedy-kv-rows", "greedy-absorbed", "beam5-absorbed", "beam5-kv-rows"])
 def test_configs4_two_windows_ladder_at_depth(rig, beam, mode):
+    margins = run_case(rig, beam, mode, AUDIO_SEEDS)
+    if beam:
+        assert min(margins) > 1e-2, margins                 # the rankings compared were decisive
+
+
+def run_case(rig, beam, mode, seeds):
+    """every check of the scenario except the fixture-quality guard; returns the oracle's minimum ranking margins of the T = 0 beam passes (empty for greedy)"""
     dims, model, om, st, langs = rig
-    audio = np.concatenate([synthetic_chunk(77), synthetic_chunk(78)[:200000]])
+    audio = np.concatenate([synthetic_chunk(seeds[0]), synthetic_chunk(seeds[1])[:200000]])
     kw = dict(sampleLength=12, firstTokenLogProbThreshold=None, compressionRatioThreshold=None, logProbThreshold=1000.0,      # +1000: every T = 0 result is rejected (the reference's own way to force a fallback, UnitTests.swift:768-814)
               temperatureFallbackCount=1, temperatureIncrementOnFallback=0.2, seed=11, detectLanguage=False)
     if beam:
@@ -78,7 +91,6 @@ def test_configs4_two_windows_ladder_at_depth(rig, beam, mode):
         assert (a.seek, a.tokens) == (b.seek, b.tokens)
         assert a.start == pytest.approx(b.start, abs=1e-5) and a.end == pytest.approx(b.end, abs=1e-5)
         assert a.temperature == pytest.approx(b.temperature) and a.avgLogprob == pytest.approx(b.avgLogprob, abs=5e-3)
-    if beam:
-        margins = [r["record"][0].minMargin for r in records if r["temperature"] == 0.0]
-        assert min(margins) > 1e-2, margins                 # the rankings compared were decisive
+    margins = [r["record"][0].minMargin for r in records if r["temperature"] == 0.0] if beam else []
     sess.close(); s_enc.close()
+    return margins
