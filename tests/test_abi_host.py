@@ -411,11 +411,11 @@ def test_library_carries_the_grouped_row_tile_projection_kernels():
 
 
 def test_round6_bench_line_bookkeeping_of_the_256_slot_device_batch():
-    """The committed round-6 bench line (profiles/r06aj_*: the final binary under the driver's command line): a 256-slot device batch carries FOUR 64-chunk bench steps and a
+    """The committed round-6 bench line (profiles/r06aq_*: the final binary under the driver's command line): a 256-slot device batch carries FOUR 64-chunk bench steps and a
     cross-attention workgroup streams two slots, so the launch takes 128 workgroups; launches_per_step is 32 layers x 223 decoder steps / 4 = 1784; the algorithmic bytes are the
     formula's at 256 slots; the PMC pass of that configuration (profiles/r06_pmc_traffic.json) is not below them; every other_configs entry carries a roofline of its own."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r06aj_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(root, "profiles", "r06aq_bench_steps20_warmup5.json")).read().strip().splitlines()[-1])
     r, cfg = line["roofline"], line["config"]
     assert cfg["device_batch_slots"] == 256 and cfg["steps_per_device_batch"] == 4 and cfg["steps_in_flight"] == 12 and cfg["audio_sets"] >= 4
     assert r["workgroups"] == 128 and r["slots_per_workgroup"] == 2 and r["cu_share"] == 0.5
