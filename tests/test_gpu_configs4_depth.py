@@ -36,7 +36,7 @@ def rig():
 
 # The two windows' audio.  The beam cases need a fixture whose candidate rankings are decisive (minimum margin > 1e-2 in the oracle's own records): the margins follow the
 # encoder output's Float16 roundings, so a change of the encoder's arithmetic at the last-bit level (round 6: the vectorised LayerNorm) can turn a seed pair into a near-tie -
-# (77, 78) went from > 1e-2 to 3.3e-3 on the second window that way.  tools/configs4_fixture_search.py lists the margins of candidate pairs
+# (77, 78) went from > 1e-2 to 3.3e-3 on the second window that way.  tests/tools/configs4_fixture_search.py lists the margins of candidate pairs
 # (profiles/r06ao_configs4_fixture_search.jsonl: (79, 80) 0.018 / 0.020, (81, 82) 0.039 / 0.085, (83, 84) 0.068 / 0.052, (90, 91) 0.099 / 0.390; every other check passes for all of them).
 AUDIO_SEEDS = (90, 91)
 

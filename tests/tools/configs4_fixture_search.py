@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Development tool (GPU): minimum beam-ranking margins of tests/test_gpu_configs4_depth.py's scenario for candidate audio seed pairs, in both cross-attention modes.
-    python tools/configs4_fixture_search.py "77,78" "79,80" ...
+    python tests/tools/configs4_fixture_search.py "77,78" "79,80" ...
 One JSON line per pair: the oracle's minimum margins of the two windows (absorbed / K-V rows) and whether every other check of the test passed."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401,E402
 import test_gpu_configs4_depth as T  # noqa: E402
