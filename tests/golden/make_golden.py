@@ -19,6 +19,8 @@ Outputs (all small, strided subsets of the full tensors; the stride is stored wi
                           d = 1280, 20 heads, 128 mel, V = 51866, 2 + 2 layers, synthetic weights seed 0 - encoder rows ::50, logits[::29]
                           of 8 teacher-forced tokens, and the CROSS-ATTENTION WEIGHTS (HF output_attentions, eager attention) of the
                           heads (layer 0, head 3) and (layer 1, head 17), frames ::3: the golden of the alignment (word-timestamp) path
+  hf_model_small_l2.npz, hf_model_tiny_en_l2.npz  (round 6, last session; `python tests/golden/make_golden.py small tiny`) the same at the widths of BASELINE
+                          configs[2] (`test-small-l2`: d = 768, 12 heads, 80 mel, V = 51865) and configs[1] (`test-tiny-en-l2`: d = 384, 6 heads, V = 51864)
 """
 import os
 import sys
@@ -52,29 +54,41 @@ def hf_model(dims, sd, attn="sdpa"):
 
 LARGE_HEADS = [(0, 3), (1, 17)]            # (decoder layer, head) whose cross-attention weights are kept
 
+# The widths BASELINE.json benchmarks, each with 2 + 2 layers: (MODEL_DIMS name, fixture file, kept cross-attention heads, teacher-forced ids of that vocabulary)
+WIDTHS = {
+    "large": ("test-large-v3-l2", "hf_model_large_v3_l2.npz", LARGE_HEADS, [50258, 50259, 50360, 464, 1282, 50365, 2, 50401]),      # <|sot|> <|en|> <|transcribe|> + text and timestamp ids of the 51866 vocabulary
+    "small": ("test-small-l2", "hf_model_small_l2.npz", [(0, 5), (1, 11)], [50258, 50259, 50359, 464, 1282, 50364, 2, 50400]),      # configs[2]: d = 768, 12 heads, 80 mel, V = 51865
+    "tiny": ("test-tiny-en-l2", "hf_model_tiny_en_l2.npz", [(0, 2), (1, 5)], [50257, 50362, 464, 1282, 50363, 2, 50400, 50400]),    # configs[1]: d = 384, 6 heads, 80 mel, V = 51864 (English-only ids)
+}
 
-def large():
-    """the headline width (VERDICT r05 "what's weak" 3: the oracle was pinned to HF at d = 128 only, the alignment path not at all)"""
+
+def width(which):
+    """an HF golden at one benchmarked width (VERDICT r05 "what's weak" 3: the oracle was pinned to HF at d = 128 only, the alignment path not at all; round 6: the
+    headline width first, then the widths of configs[1] and configs[2])"""
     import torch
     from transformers import WhisperFeatureExtractor
+    name, fname, heads, tokens = WIDTHS[which]
     jfk = np.load(os.path.join(HERE, "jfk_pcm16.npz"))["pcm16"].astype(np.float32) / 32768.0
-    dims = W.MODEL_DIMS["test-large-v3-l2"]
+    dims = W.MODEL_DIMS[name]
     sd = W.synthetic_state_dict(dims, seed=0)
     model = hf_model(dims, sd, attn="eager")           # eager attention returns the weights
     fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
     mel = fe(jfk, sampling_rate=16000, return_tensors="pt")["input_features"]
-    tokens = [50258, 50259, 50360, 464, 1282, 50365, 2, 50401]   # <|sot|> <|en|> <|transcribe|> + text and timestamp ids of the 51866 vocabulary
     with torch.no_grad():
         enc = model.model.encoder(mel).last_hidden_state
         out = model(input_features=mel, decoder_input_ids=torch.tensor([tokens]), output_attentions=True)
     logits = out.logits[0]
-    xatt = np.stack([out.cross_attentions[l][0, h].numpy() for l, h in LARGE_HEADS])        # [2 heads][8 tokens][1500]
+    xatt = np.stack([out.cross_attentions[l][0, h].numpy() for l, h in heads])        # [2 heads][8 tokens][1500]
     assert xatt.shape == (2, len(tokens), 1500) and np.allclose(xatt.sum(-1), 1.0, atol=1e-4)
-    np.savez_compressed(os.path.join(HERE, "hf_model_large_v3_l2.npz"), tokens=np.array(tokens, np.int32),
+    np.savez_compressed(os.path.join(HERE, fname), tokens=np.array(tokens, np.int32),
                         enc_stride=np.int32(50), enc=enc[0, ::50].numpy().astype(np.float32),
                         logit_stride=np.int32(29), logits=logits[:, ::29].numpy().astype(np.float32),
-                        heads=np.array(LARGE_HEADS, np.int32), xatt_stride=np.int32(3), xatt=xatt[:, :, ::3].astype(np.float32))
-    print("hf_model_large_v3_l2.npz written:", os.path.getsize(os.path.join(HERE, "hf_model_large_v3_l2.npz")), "bytes")
+                        heads=np.array(heads, np.int32), xatt_stride=np.int32(3), xatt=xatt[:, :, ::3].astype(np.float32))
+    print(fname, "written:", os.path.getsize(os.path.join(HERE, fname)), "bytes")
+
+
+def large():
+    width("large")
 
 
 def main():
@@ -127,8 +141,10 @@ def main():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["large"]:
-        large()
+    if sys.argv[1:] and all(a in WIDTHS for a in sys.argv[1:]):
+        for a in sys.argv[1:]:
+            width(a)
     else:
         main()
-        large()
+        for a in WIDTHS:
+            width(a)

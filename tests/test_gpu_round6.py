@@ -132,21 +132,24 @@ def test_callback_exception_comes_out_of_every_entry_point_that_runs_the_callbac
     sess.close()
 
 
-def test_headline_width_against_the_hf_golden_logits_and_cross_attention_weights(jfk_pcm):
+@pytest.mark.parametrize("name,fname,modes", [("test-large-v3-l2", "hf_model_large_v3_l2.npz", (0, 1)), ("test-small-l2", "hf_model_small_l2.npz", (0, 1)),
+                                              ("test-tiny-en-l2", "hf_model_tiny_en_l2.npz", (0,))], ids=["large-v3-width", "small-width", "tiny.en-width"])
+def test_benchmarked_widths_against_the_hf_golden_logits_and_cross_attention_weights(jfk_pcm, name, fname, modes):
     """The device at the headline width (d = 1280, 20 heads, 128 mel, V = 51866; 2 + 2 layers) against the HF-transformers golden itself
     (tests/golden/hf_model_large_v3_l2.npz, written by tests/golden/make_golden.py; the oracle is pinned to the same file on the CPU):
     end to end from the PCM of jfk.wav - encoder rows, teacher-forced logits within BASELINE's 1e-3, and the alignment rows (mean of the
     two alignment heads' cross-attention weights: what DecodingCache.alignmentWeights carries, Core/TextDecoder.swift:272-296) within 1e-4.
-    Both cross-attention modes of the library."""
+    Both cross-attention modes of the library.  Round 6, last session: the same at the widths of BASELINE configs[2] (d = 768, 12 heads, 80 mel, V = 51865: both
+    modes) and configs[1] (d = 384, 6 heads, V = 51864: K / V rows, the only mode at that width)."""
     from conftest import golden
-    g = golden("hf_model_large_v3_l2.npz")
-    dims = weights.MODEL_DIMS["test-large-v3-l2"]
+    g = golden(fname)
+    dims = weights.MODEL_DIMS[name]
     heads = [tuple(int(v) for v in h) for h in g["heads"]]
     model = api.Model(dims, weights.synthetic_state_dict(dims, seed=0), alignment_heads=heads)
     es, ls, xs = int(g["enc_stride"]), int(g["logit_stride"]), int(g["xatt_stride"])
     toks = [int(t) for t in g["tokens"]]
     report = {}
-    for mode in (0, 1):
+    for mode in modes:
         sess = api.Session(model, 2, crossAttentionMode=mode)
         assert sess.crossAttentionMode == mode
         for b in range(2):
@@ -164,7 +167,7 @@ def test_headline_width_against_the_hf_golden_logits_and_cross_attention_weights
         report[mode] = (e_enc, e_log, e_al)
         sess.close()
     model.close()
-    print("headline-width HF golden: mode -> (encoder rows, logits, alignment rows) max abs err", report)
+    print(name, "HF golden: mode -> (encoder rows, logits, alignment rows) max abs err", report)
     for mode, (e_enc, e_log, e_al) in report.items():
         assert e_enc <= 5e-3 and e_log <= 1e-3 and e_al <= 1e-4, report
 

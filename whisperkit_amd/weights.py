@@ -72,6 +72,7 @@ MODEL_DIMS: Dict[str, WhisperDims] = {
     "test-micro-ml": WhisperDims(128, 1500, 128, 2, 2, 51866, 448, 128, 2, 2),
     # headline widths with 2 + 2 layers: the kernel instantiations the benchmark runs (d = 768 / 1280, 12 / 20 heads,
     # 80 / 128 mel, V = 51865 / 51866; shapes pinned by the reference at UnitTests.swift:541-611,721-732) at an oracle cost of seconds
+    "test-tiny-en-l2": WhisperDims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2),
     "test-small-l2": WhisperDims(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2),
     "test-large-v3-l2": WhisperDims(128, 1500, 1280, 20, 2, 51866, 448, 1280, 20, 2),
 }
