@@ -198,3 +198,21 @@ def test_gemm256_staged_epilogue_maps_cover_the_wave_tile_exactly_once(tmp_path)
                     os.path.join(root, "tests", "native", "epi_stage_check.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "EPI_STAGE_OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_vector_layernorm_lanes_cover_every_row_once_with_whole_vectors():
+    """csrc/layernorm.hip layernorm_v4_kernel (round 6): lane l owns channels 4 l .. 4 l + 3 of every 256-channel group (LN_MAXE / 4 = 5 groups): at every width the
+    library runs (multiples of 4 up to 1280) the lanes' vectors tile the row exactly once, never straddle its end, and a wave instruction reads whole 16-byte / writes whole
+    8-byte pieces that are aligned when the row base is (rows are d floats / d halves apart: d % 4 == 0 keeps both alignments)."""
+    NV = 20 // 4
+    for d in (128, 384, 512, 768, 1024, 1280):
+        seen = np.zeros(d, np.int32)
+        for i in range(NV):
+            for lane in range(64):
+                c = 4 * lane + 256 * i
+                if c < d:
+                    assert c + 3 < d and (c * 4) % 16 == 0 and (c * 2) % 8 == 0
+                    seen[c:c + 4] += 1
+        assert (seen == 1).all(), d
+        assert (d * 4) % 16 == 0 and (d * 2) % 8 == 0
+    assert 4 * 63 + 256 * (NV - 1) + 3 == 1279          # the last lane of the last group ends the widest row
