@@ -221,6 +221,28 @@ def compression_ratio(tokens: Sequence[int]) -> float:
 
 
 # ----------------------------------------------------------------------------- logits filters
+def fill_indexes(logits: np.ndarray, indexes: Sequence[Sequence[int]], value) -> np.ndarray:
+    """MLMultiArray.fill(indexes:with:) (ArgmaxCore/MLMultiArrayExtensions.swift:102-109): every multi-dimensional index of `indexes` is set to `value`, in place
+    (the filters' logits are a [1, 1, n] array; an empty list changes nothing).  KAT: UnitTests.swift:1903-1920."""
+    for idx in indexes:
+        logits[tuple(int(i) for i in idx)] = value
+    return logits
+
+
+def fill_last_dimension(logits: np.ndarray, indexes: range, value) -> np.ndarray:
+    """MLMultiArray.fillLastDimension(indexes:with:) (ArgmaxCore/MLMultiArrayExtensions.swift:90-99): a half-open range of the last dimension of a [1, 1, n] array (what
+    TimestampRulesFilter uses, Core/Text/LogitsFilter.swift:91-126); the oracle's filters address the same ranges as slices of their 1-D logits row."""
+    assert logits.ndim == 3 and logits.shape[0] == 1 and logits.shape[1] == 1, "Must have [1, 1, n] shape"
+    logits[0, 0, indexes.start:indexes.stop] = value
+    return logits
+
+
+def batched(items: Sequence, size: int) -> List[list]:
+    """Array.batched(into:) (ArgmaxCore/FoundationExtensions.swift:41-47): how WhisperKit.transcribeWithOptions cuts the audio list into groups of concurrentWorkerCount
+    (Core/WhisperKit.swift:739); the last group may be shorter.  KAT: UnitTests.swift:1922-1931."""
+    return [list(items[i:i + size]) for i in range(0, len(items), size)]
+
+
 class SuppressTokensFilter:
     """Core/Text/LogitsFilter.swift:12-25."""
     def __init__(self, suppressTokens: Sequence[int]):

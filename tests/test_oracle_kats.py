@@ -372,3 +372,23 @@ def test_float16_timestamp_rule_emulation_differs_from_fp32_exactly_where_float1
     assert f(x, tb, True) is False                # Float16: both round to the same value -> not strictly greater
     x[tb + 5] = 3.02
     assert f(x, tb, True) is True
+
+
+def test_fill_indexes_with_value():
+    """UnitTests.swift:1903-1920 (testFillIndexesWithValue): the two in-place writers the logits filters are built from."""
+    base = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7]
+    mk = lambda: np.array(base, np.float32).reshape(1, 1, -1)
+    ninf = -np.inf
+    np.testing.assert_array_equal(D.fill_indexes(mk(), [], ninf)[0, 0], np.array(base, np.float32))
+    np.testing.assert_array_equal(D.fill_indexes(mk(), [[0, 0, 0], [0, 0, 1], [0, 0, 5]], ninf)[0, 0], np.array([ninf, ninf, 0.3, 0.4, 0.5, ninf, 0.7], np.float32))
+    np.testing.assert_array_equal(D.fill_last_dimension(mk(), range(0, 1), ninf)[0, 0], np.array([ninf, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7], np.float32))
+    np.testing.assert_array_equal(D.fill_last_dimension(mk(), range(2, 5), ninf)[0, 0], np.array([0.1, 0.2, ninf, ninf, ninf, 0.6, 0.7], np.float32))
+    with pytest.raises(AssertionError):
+        D.fill_last_dimension(np.zeros((2, 1, 7), np.float32), range(0, 1), ninf)          # the reference's precondition: [1, 1, n]
+
+
+def test_batched_array():
+    """UnitTests.swift:1922-1931 (testBatchedArray): Array.batched(into:), the grouping of WhisperKit.transcribeWithOptions (Core/WhisperKit.swift:739)."""
+    assert D.batched([], 1) == [] and D.batched([1, 2, 3, 4], 1) == [[1], [2], [3], [4]]
+    assert D.batched([], 10) == [] and D.batched([1, 2, 3, 4], 10) == [[1, 2, 3, 4]]
+    assert D.batched([], 3) == [] and D.batched([1, 2, 3, 4], 3) == [[1, 2, 3], [4]]
